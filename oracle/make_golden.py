@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (/root/reference, read-only).
+
+TEST INFRASTRUCTURE, build container only.  The reference is imported unmodified (see
+oracle/ref_import.py + oracle/standins/README.md for the absent third-party wheels), loaded with
+the deterministic synthetic weights of phoregen_amd/weights.py (there are no checkpoints offline)
+and driven on small seeded inputs.  Only *data* is written: inputs, recorded RNG draws, expected
+outputs.  Re-run with:  python oracle/make_golden.py
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_import  # noqa: E402
+
+ref_import.activate()
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(4)
+
+from phoregen_amd.weights import init_deterministic_  # noqa: E402
+
+import models.common as rc  # noqa: E402  (reference)
+import models.transition as rt  # noqa: E402
+import models.uni_denoiser as ru  # noqa: E402
+from models.diffusion import PhoreDiff  # noqa: E402
+from utils.sample_utils import make_edge_data, get_fully_connected_edge  # noqa: E402
+from datasets.get_phore_data import PhoreData_New  # noqa: E402
+from datasets.transform import AddPhoreNoise, FeaturizeLigandBond  # noqa: E402
+from torch_geometric.transforms import Compose  # noqa: E402
+
+
+def seed_all(seed):  # utils/misc.py:29-32
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def npy(t):
+    if torch.is_tensor(t):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays')
+
+
+# --------------------------------------------------------------------------------------------
+# G1  op-level known-answer vectors
+# --------------------------------------------------------------------------------------------
+def g1_ops():
+    g = torch.Generator().manual_seed(11)
+    dist = torch.cat([torch.linspace(0, 12, 40), torch.rand(24, generator=g) * 4])
+    smear = rc.GaussianSmearing(0., 10., num_gaussians=20)(dist)
+    tvals = torch.tensor([0, 1, 2, 57, 111, 500, 998, 999], dtype=torch.long)
+    tsmear = rc.TimeGaussianSmearing(stop=1000, num_gaussians=10, type_='linear')(tvals)
+    ang = torch.cat([torch.linspace(0, np.pi, 17), torch.rand(15, generator=g) * np.pi]).float()
+    ang_code = rc.AngularEncoding()(ang)
+    et = torch.nn.functional.one_hot(torch.randint(0, 4, (64,), generator=g), 4)
+    outer = rc.outer_product(et, smear)
+    ssp_in = torch.linspace(-6, 6, 25)
+    ssp = rc.ShiftedSoftplus()(ssp_in)
+    arrays = dict(dist=dist, smear=smear, tvals=tvals, tsmear=tsmear, ang=ang, ang_code=ang_code,
+                  edge_type=et, outer=outer, ssp_in=ssp_in, ssp=ssp)
+    # make_edge_data + triplets, n = 3, 4, 5 in one batch (utils/sample_utils.py:40-54, uni_denoiser.py:101-121)
+    na = torch.tensor([3, 4, 5])
+    ei, eb = make_edge_data(na)
+    col, row, idx_i, idx_j, idx_k, idx_kj, idx_ji = ru.BondUpdateLayer.triplets(ei, num_nodes=int(na.sum()))
+    arrays.update(med_num_atoms=na, med_edge_index=ei, med_edge_batch=eb, tri_i=idx_i, tri_j=idx_j,
+                  tri_k=idx_k, tri_kj=idx_kj, tri_ji=idx_ji)
+    # compose_context (common.py:180-208)
+    bp = torch.tensor([0, 0, 0, 1, 1, 2, 2, 2, 2])
+    bl = torch.tensor([0, 0, 1, 1, 1, 2])
+    hp = torch.randn(9, 4, generator=g)
+    hl = torch.randn(6, 4, generator=g)
+    pp = torch.randn(9, 3, generator=g)
+    pl = torch.randn(6, 3, generator=g)
+    h_ctx, pos_ctx, batch_ctx, mask_l, mask_la, p_idx, l_idx = rc.compose_context(hp, hl, pp, pl, bp, bl)
+    arrays.update(cc_bp=bp, cc_bl=bl, cc_hp=hp, cc_hl=hl, cc_pp=pp, cc_pl=pl, cc_h=h_ctx, cc_pos=pos_ctx,
+                  cc_batch=batch_ctx, cc_mask=mask_l, cc_pidx=p_idx, cc_lidx=l_idx)
+    arrays.update(fc_index=rc.fully_connect_two_graphs(bp, bp), fce_index=get_fully_connected_edge(4))
+    save('g1_ops', **arrays)
+
+
+# --------------------------------------------------------------------------------------------
+# shared: model + synthetic / real pharmacophores
+# --------------------------------------------------------------------------------------------
+def build_model(seed=0):
+    cfg = ref_import.load_reference_config('train_lig-phore.yml')
+    m = PhoreDiff(cfg.model, cfg.dataset.data_name)
+    init_deterministic_(m, seed)
+    m.eval()
+    return m, cfg
+
+
+def synthetic_phore(gen, p, frac_ex=0.6):
+    """Feature layout of datasets/get_phore_data.py:55-69: 13 type one-hot | alpha | has_norm(2) | EX(2)."""
+    n_ex = int(round(p * frac_ex))
+    types = torch.cat([torch.randint(0, 12, (p - n_ex,), generator=gen), torch.full((n_ex,), 12)])
+    t1 = torch.nn.functional.one_hot(types, 13).float()
+    ex = torch.nn.functional.one_hot((types == 12).long(), 2).float()
+    alpha = 0.5 + torch.rand(p, 1, generator=gen)
+    has_norm = ((torch.rand(p, generator=gen) < 0.4) & (types != 12)).long()
+    hn = torch.nn.functional.one_hot(has_norm, 2).float()
+    norm = torch.randn(p, 3, generator=gen)
+    norm = norm / norm.norm(dim=-1, keepdim=True) * has_norm[:, None].float()
+    pos = 3.0 * torch.randn(p, 3, generator=gen)
+    pos = pos - pos.mean(0, keepdim=True)
+    return torch.cat([t1, alpha, hn, ex], -1), pos, norm
+
+
+def synthetic_batch(seed, n_atoms, n_phore, t_values):
+    """A synthetic PhoreDiff.forward input set (diffusion.py:175-178) for B=len(n_atoms) graphs."""
+    gen = torch.Generator().manual_seed(seed)
+    na = torch.tensor(n_atoms)
+    B = len(n_atoms)
+    batch_node = torch.repeat_interleave(torch.arange(B), na)
+    edge_index, batch_edge = make_edge_data(na)
+    N, E = int(na.sum()), edge_index.size(1)
+    h_node = torch.nn.functional.one_hot(torch.randint(0, 12, (N,), generator=gen), 12).float()
+    h_edge = torch.nn.functional.one_hot(torch.randint(0, 6, (E,), generator=gen), 6).float()
+    pos = 2.5 * torch.randn(N, 3, generator=gen)
+    hp, pp, pn, bp = [], [], [], []
+    for gi, p in enumerate(n_phore):
+        x, ps, nr = synthetic_phore(gen, p)
+        hp.append(x), pp.append(ps), pn.append(nr), bp.append(torch.full((p,), gi))
+    return dict(h_node_pert=h_node, pos_pert=pos, batch_node=batch_node, h_edge_pert=h_edge,
+                edge_index=edge_index, batch_edge=batch_edge, time_step=torch.tensor(t_values),
+                h_phore=torch.cat(hp), pos_phore=torch.cat(pp), phore_norm=torch.cat(pn),
+                batch_phore=torch.cat(bp))
+
+
+# --------------------------------------------------------------------------------------------
+# G2 + G3  one denoiser layer / full PhoreDiff.forward
+# --------------------------------------------------------------------------------------------
+def g23_forward(model, name, seed, n_atoms, n_phore, t_values):
+    inp = synthetic_batch(seed, n_atoms, n_phore, t_values)
+    cap = {}
+
+    def layer_hook(idx):
+        def hook(mod, args, kwargs, out):
+            names = ['h', 'x', 'edge_attr', 'edge_index', 'h_bond', 'bond_index', 'mask_ligand']
+            d = {f'L{idx}_in_{n}': a for n, a in zip(names, args)}
+            d.update({f'L{idx}_in_{k}': v for k, v in kwargs.items()})
+            d.update({f'L{idx}_out_h': out[0], f'L{idx}_out_h_bond': out[1], f'L{idx}_out_x': out[2]})
+            cap.update(d)
+        return hook
+
+    def sub_hook(tag):
+        def hook(mod, args, out):
+            cap[tag] = out
+        return hook
+
+    hs = [model.denoiser.base_block[i].register_forward_hook(layer_hook(i), with_kwargs=True) for i in (0, 5)]
+    blk = model.denoiser.base_block[0]
+    hs += [blk.node_layer_with_edge.register_forward_hook(sub_hook('L0_node_edge')),
+           blk.node_layer_with_bond.register_forward_hook(sub_hook('L0_node_bond')),
+           blk.bond_layer.register_forward_hook(sub_hook('L0_bond_upd')),
+           blk.pos_layer_with_edge.register_forward_hook(sub_hook('L0_pos_edge')),
+           blk.pos_layer_with_bond.register_forward_hook(sub_hook('L0_pos_bond')),
+           model.phore_encoder.register_forward_hook(sub_hook('phore_enc'))]
+    with torch.no_grad():
+        v, x0, bond, (cl, cu) = model(**inp)
+    for h in hs:
+        h.remove()
+    arrays = {f'in_{k}': t for k, t in inp.items()}
+    arrays.update(out_v=v, out_x0=x0, out_bond=bond, out_count_l=cl, out_count_u=cu)
+    arrays.update(cap)
+    save(name, **arrays)
+
+
+# --------------------------------------------------------------------------------------------
+# G4  schedule / transition tables (diffusion.py:89-135, transition.py:14-26,200-215)
+# --------------------------------------------------------------------------------------------
+def g4_tables(model):
+    rows = np.r_[0:5, 498:503, 995:1000]
+    arrays = dict(rows=rows)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if k.startswith(('pos_transition.', 'node_transition.', 'edge_transition.')):
+            a = npy(v)
+            arrays[k + '|rows'] = a[rows]
+            arrays[k + '|sum64'] = np.array([a.astype(np.float64).sum(), np.abs(a.astype(np.float64)).sum()])
+    arrays['node_init_prob'] = model.node_transition.init_prob
+    arrays['edge_init_prob'] = model.edge_transition.init_prob
+    save('g4_tables', **arrays)
+
+
+# --------------------------------------------------------------------------------------------
+# G5  sampler trajectories with the RNG draws recorded
+# --------------------------------------------------------------------------------------------
+class RngTape:
+    """Record every CPU draw the sampler makes, in order."""
+    NAMES = ('rand_like', 'randn_like', 'randn', 'randint', 'normal', 'rand')
+
+    def __init__(self):
+        self.tape, self._orig = [], {}
+
+    def __enter__(self):
+        for n in self.NAMES:
+            self._orig[n] = getattr(torch, n)
+            setattr(torch, n, self._wrap(n))
+        return self
+
+    def _wrap(self, n):
+        def f(*a, **k):
+            out = self._orig[n](*a, **k)
+            self.tape.append((n, out.detach().clone()))
+            return out
+        return f
+
+    def __exit__(self, *exc):
+        for n, f in self._orig.items():
+            setattr(torch, n, f)
+
+
+class StopAfter(Exception):
+    pass
+
+
+def real_phore_data(seed):
+    seed_all(seed)
+    tr = Compose([FeaturizeLigandBond(), AddPhoreNoise(noise_std=0.1, angle=5.0)])  # training_utils.py:86-91
+    ds = PhoreData_New([os.path.join(ref_import.REFERENCE, 'data/phores_for_sampling/P03211_merge.phore')],
+                       transform=tr)
+    return ds[0]
+
+
+def g5_sample(model, name, seed, n_atoms, n_steps, t_total, guidance=None):
+    """Run the reference sampler. `t_total`=1000 -> first `n_steps` steps from t=999 (stopped by a
+    hook after the forward of step n_steps+1, so posteriors of n_steps steps are observed);
+    `t_total`<1000 -> `model.num_timesteps` is set so the loop runs t = t_total-1 .. 0 to the end."""
+    data = real_phore_data(seed)
+    fwd_in, fwd_out = [], []
+
+    ref_forward = model.forward        # sample() calls self.forward directly (diffusion.py:436): wrap it
+
+    def recording_forward(**kwargs):
+        out = ref_forward(**kwargs)
+        fwd_in.append({k: v.detach().clone() for k, v in kwargs.items()})
+        fwd_out.append([out[0].detach().clone(), out[1].detach().clone(), out[2].detach().clone()])
+        if t_total == 1000 and len(fwd_in) == n_steps + 1:
+            raise StopAfter()
+        return out
+
+    # n forced small: the reference's atom-count head runs, its draw is replaced
+    orig_sample_nodes = model.sample_nodes
+    counts = {}
+
+    def forced_nodes(data_, batch_size, device, sample_mode='uniform', normal_scale=4.0):
+        counts['model'] = orig_sample_nodes(data_, batch_size, device, sample_mode, normal_scale)
+        return torch.tensor(n_atoms)
+
+    model.sample_nodes = forced_nodes
+    model.forward = recording_forward
+    old_T = model.num_timesteps
+    res = None
+    with RngTape() as tape:
+        try:
+            if t_total != 1000:
+                model.num_timesteps = t_total
+            res = model.sample(data, len(n_atoms), 'cpu', pos_guidance_opt=guidance)
+        except StopAfter:
+            pass
+        finally:
+            model.num_timesteps = old_T
+            del model.forward
+            model.sample_nodes = orig_sample_nodes
+    arrays = dict(phore_x=data['phore'].x, phore_pos=data['phore'].pos, phore_norm=data['phore'].norm,
+                  center=data.center, n_atoms=np.array(n_atoms), t_total=np.array(t_total),
+                  model_count_draw=counts['model'])
+    for i, (n, t) in enumerate(tape.tape):
+        arrays[f'rng{i:03d}_{n}'] = t
+    for s, (fi, fo) in enumerate(zip(fwd_in, fwd_out)):
+        arrays[f's{s}_h_node'] = fi['h_node_pert']
+        arrays[f's{s}_pos'] = fi['pos_pert']
+        arrays[f's{s}_h_edge'] = fi['h_edge_pert'].argmax(-1).to(torch.int8)
+        arrays[f's{s}_t'] = fi['time_step']
+        arrays[f's{s}_out_v'], arrays[f's{s}_out_x0'], arrays[f's{s}_out_bond'] = fo
+    if res is not None:
+        arrays.update(pred_node=res['pred'][0], pred_pos=res['pred'][1], pred_edge=res['pred'][2],
+                      traj_node=res['traj'][0].argmax(-1).to(torch.int8), traj_pos=res['traj'][1],
+                      traj_edge=res['traj'][2].argmax(-1).to(torch.int8),
+                      lig_batch=res['lig_info'][1], lig_edge_index=res['lig_info'][2],
+                      lig_edge_batch=res['lig_info'][3])
+    save(name, **arrays)
+
+
+# --------------------------------------------------------------------------------------------
+# G7  state_dict manifest
+# --------------------------------------------------------------------------------------------
+def g7_manifest(model):
+    with open(os.path.join(OUT, 'g7_state_dict_manifest.txt'), 'w') as f:
+        for k, v in model.state_dict().items():
+            f.write(f'{k}\t{tuple(v.shape)}\t{str(v.dtype).replace("torch.", "")}\n')
+    print('g7 manifest:', len(model.state_dict()), 'entries')
+
+
+def g_posterior(model):
+    """Posterior-step KATs straight from transition.py:44-63,285-315 and common.py:425-431."""
+    g = torch.Generator().manual_seed(5)
+    batch = torch.tensor([0, 0, 0, 1, 1, 2, 2, 2, 2, 2])
+    t = torch.tensor([999, 500, 0])
+    arrays = dict(batch=batch, t=t)
+    for tag, tr, K in (('node', model.node_transition, 12), ('edge', model.edge_transition, 6)):
+        log_v0 = torch.log_softmax(2 * torch.randn(10, K, generator=g), -1)
+        log_vt = torch.log_softmax(3 * torch.randn(10, K, generator=g), -1)
+        post = tr.q_v_posterior(log_v0, log_vt, t, batch, v0_prob=True)
+        u = torch.rand(10, K, generator=g)
+        gumbel = -torch.log(-torch.log(u + 1e-30) + 1e-30)
+        arrays.update({f'{tag}_log_v0': log_v0, f'{tag}_log_vt': log_vt, f'{tag}_post': post,
+                       f'{tag}_u': u, f'{tag}_sample': (gumbel + post).argmax(-1)})
+    x_t = torch.randn(10, 3, generator=g)
+    x0 = torch.randn(10, 3, generator=g)
+    eps = torch.randn(10, 3, generator=g)
+    orig = torch.randn_like
+    torch.randn_like = lambda m: eps
+    try:
+        prev = model.pos_transition.get_prev_from_recon(x_t, x0, t, batch)
+    finally:
+        torch.randn_like = orig
+    arrays.update(pos_xt=x_t, pos_x0=x0, pos_eps=eps, pos_prev=prev)
+    save('g_posterior', **arrays)
+
+
+if __name__ == '__main__':
+    g1_ops()
+    model, cfg = build_model(seed=0)
+    g7_manifest(model)
+    g4_tables(model)
+    g_posterior(model)
+    g23_forward(model, 'g3_forward_a', seed=101, n_atoms=[5, 9], n_phore=[6, 11], t_values=[700, 30])
+    g23_forward(model, 'g3_forward_b', seed=202, n_atoms=[19, 4, 12], n_phore=[40, 23, 37], t_values=[999, 0, 412])
+    g5_sample(model, 'g5_sample_head3', seed=2032, n_atoms=[6, 9], n_steps=3, t_total=1000)
+    g5_sample(model, 'g5_sample_tail4', seed=2033, n_atoms=[7, 5, 8], n_steps=4, t_total=4)
+    g5_sample(model, 'g5_sample_full25', seed=2034, n_atoms=[8, 6], n_steps=25, t_total=25)
+    g5_sample(model, 'g5_sample_guid3', seed=2035, n_atoms=[6, 7], n_steps=3, t_total=3,
+              guidance=[{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}])

@@ -1,0 +1,159 @@
+"""The CPU oracle (oracle/phoregen_oracle.py) against vectors recorded from the reference itself."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import DIFF_CFG, golden, make_oracle, oracle_state_dict, rel_err, t
+from oracle import phoregen_oracle as po
+
+TOL = 2e-5   # max-abs error <= 2e-5 x max-abs(reference), fp32 re-association
+
+
+@pytest.fixture(scope='module')
+def oracle():
+    torch.set_num_threads(4)
+    return make_oracle(0)
+
+
+def test_g1_small_ops():
+    g = golden('g1_ops')
+    assert np.array_equal(po.gaussian_smearing(t(g['dist'])).numpy(), g['smear'])
+    assert np.allclose(po.time_smearing(t(g['tvals']).float()).numpy(), g['tsmear'], rtol=0, atol=1e-7)
+    assert np.allclose(po.angular_encoding(t(g['ang'])).numpy(), g['ang_code'], rtol=0, atol=1e-7)
+    assert np.allclose(po.shifted_softplus(t(g['ssp_in'])).numpy(), g['ssp'], rtol=0, atol=1e-7)
+    et, sm = t(g['edge_type']).float(), t(g['smear'])
+    assert np.array_equal((et.unsqueeze(-1) * sm.unsqueeze(1)).reshape(64, -1).numpy(), g['outer'])
+
+
+def test_g1_edge_data_and_triplets():
+    g = golden('g1_ops')
+    ei, eb = po.make_edge_data(t(g['med_num_atoms']))
+    assert np.array_equal(ei.numpy(), g['med_edge_index']) and np.array_equal(eb.numpy(), g['med_edge_batch'])
+    i, j, k, kj, ji = po.triplets(ei, int(g['med_num_atoms'].sum()))
+    for mine, ref in zip((i, j, k, kj, ji), ('tri_i', 'tri_j', 'tri_k', 'tri_kj', 'tri_ji')):
+        assert np.array_equal(mine.numpy(), g[ref]), ref
+
+
+def test_g1_compose_context():
+    g = golden('g1_ops')
+    h, pos, batch, mask, pidx, lidx = po.compose_context(t(g['cc_hp']), t(g['cc_hl']), t(g['cc_pp']), t(g['cc_pl']),
+                                                         t(g['cc_bp']), t(g['cc_bl']))
+    for mine, ref in zip((h, pos, batch, mask, pidx, lidx), ('cc_h', 'cc_pos', 'cc_batch', 'cc_mask', 'cc_pidx', 'cc_lidx')):
+        assert np.array_equal(mine.numpy(), g[ref]), ref
+    same = t(g['cc_bp'])[:, None] == t(g['cc_bp'])[None, :]
+    assert np.array_equal(torch.stack(same.nonzero(as_tuple=True)).numpy(), g['fc_index'])
+
+
+def test_g4_tables_bit_exact():
+    g = golden('g4_tables')
+    sd = oracle_state_dict(0)
+    rows = g['rows']
+    n = 0
+    for key in g.files:
+        if key.endswith('|rows'):
+            k = key[:-5]
+            assert np.array_equal(sd[k].numpy()[rows], g[key]), k
+            s = sd[k].numpy().astype(np.float64)
+            assert np.allclose([s.sum(), np.abs(s).sum()], g[k + '|sum64'], rtol=1e-12, atol=0), k
+            n += 1
+    assert n == 11
+    assert np.array_equal(po.categorical_init_prob(12, 'tomask'), g['node_init_prob'])
+    assert np.array_equal(po.categorical_init_prob(6, 'absorb'), g['edge_init_prob'])
+
+
+def test_posterior_kats(oracle):
+    g = golden('g_posterior')
+    batch, tt = t(g['batch']), t(g['t'])
+    for tag, tab in (('node', oracle.tab_node), ('edge', oracle.tab_edge)):
+        post = po.q_v_posterior(tab, t(g[f'{tag}_log_v0']), t(g[f'{tag}_log_vt']), tt, batch)
+        assert np.allclose(post.numpy(), g[f'{tag}_post'], rtol=0, atol=1e-6), tag
+        assert np.array_equal(po.gumbel_argmax(t(g[f'{tag}_post']), t(g[f'{tag}_u'])).numpy(), g[f'{tag}_sample'])
+    prev = po.pos_prev_from_recon(oracle.tab_pos, t(g['pos_xt']), t(g['pos_x0']), tt, batch, t(g['pos_eps']))
+    assert np.allclose(prev.numpy(), g['pos_prev'], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['g3_forward_a', 'g3_forward_b'])
+def test_g23_forward_and_layers(oracle, name):
+    g = golden(name)
+    inp = {k[3:]: t(g[k]) for k in g.files if k.startswith('in_')}
+    cap = {}
+    with torch.no_grad():
+        v, x0, bond, (cl, cu) = oracle.forward(**inp, capture=cap)
+    assert np.array_equal(cap['edge_index'].numpy(), g['L0_in_edge_index'])       # knn graph, identical order
+    assert np.array_equal(cap['edge_type'].numpy(), g['L0_in_edge_attr'])
+    assert np.array_equal(cap['bond_index'].numpy(), g['L0_in_bond_index'])
+    assert np.array_equal(cap['mask'].numpy(), g['L0_in_mask_ligand'])
+    errs = dict(phore=rel_err(cap['phore_enc'], g['phore_enc']), h_all=rel_err(cap['h_all'], g['L0_in_h']),
+                e_w=rel_err(cap['e_w'], g['L0_in_e_w']),
+                L0_h=rel_err(cap['L0_out'][0], g['L0_out_h']), L0_hb=rel_err(cap['L0_out'][1], g['L0_out_h_bond']),
+                L0_x=rel_err(cap['L0_out'][2], g['L0_out_x']),
+                L5_h=rel_err(cap['L5_out'][0], g['L5_out_h']), L5_hb=rel_err(cap['L5_out'][1], g['L5_out_h_bond']),
+                L5_x=rel_err(cap['L5_out'][2], g['L5_out_x']),
+                v=rel_err(v, g['out_v']), x0=rel_err(x0, g['out_x0']), bond=rel_err(bond, g['out_bond']),
+                cl=rel_err(cl, g['out_count_l']), cu=rel_err(cu, g['out_count_u']))
+    print(name, errs)
+    assert max(errs.values()) <= TOL, errs
+
+
+def _tape(g):
+    keys = sorted(k for k in g.files if k.startswith('rng'))
+    return [(k.split('_', 1)[1], g[k]) for k in keys]
+
+
+@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3'])
+def test_g5_sampler(oracle, name):
+    g = golden(name)
+    tape = _tape(g)
+    assert tape[0][0] == 'randint'          # sample_from_interval draw (replaced by the forced atom counts)
+    draws = [a for _, a in tape[1:]]
+    t_total = int(g['t_total'])
+    n_atoms = t(g['n_atoms'])
+    n_steps = sum(1 for k in g.files if k.endswith('_out_v'))
+    guid = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}] if 'guid' in name else None
+    run_T = t_total if t_total != 1000 else 1000
+    # head fixtures stop early: run the oracle sampler for the recorded number of steps only
+    o = oracle
+    if t_total == 1000:
+        class Stop(Exception):
+            pass
+        rng = po.TapeRng(draws + [np.zeros_like(draws[-3]), np.zeros_like(draws[-2]), np.zeros_like(draws[-1])])
+        fwd, count = o.forward, [0]
+        recs = []
+
+        def limited(*a, **k):
+            out = fwd(*a, **k)
+            recs.append((a, out))
+            count[0] += 1
+            if count[0] == n_steps:
+                raise Stop()
+            return out
+        o.forward = limited
+        try:
+            o.sample(t(g['phore_x']), t(g['phore_pos']), t(g['phore_norm']), t(g['center']), n_atoms, rng)
+        except Stop:
+            pass
+        finally:
+            del o.forward
+        steps = [(a[0], a[1], a[3], out[0], out[1], out[2]) for a, out in recs]
+        res = None
+    else:
+        res = o.sample(t(g['phore_x']), t(g['phore_pos']), t(g['phore_norm']), t(g['center']), n_atoms,
+                       po.TapeRng(draws), t_total=run_T, guidance=guid)
+        steps = res['steps']
+    assert len(steps) == n_steps
+    flips = 0
+    for s, (h_node, pos, h_edge, v, x0, bond) in enumerate(steps):
+        # discrete state bit-exact, coordinates / logits within tolerance, at every recorded step
+        assert np.array_equal(h_node.numpy(), g[f's{s}_h_node']), (name, s)
+        assert np.array_equal(h_edge.argmax(-1).numpy(), g[f's{s}_h_edge']), (name, s)
+        assert rel_err(pos, g[f's{s}_pos']) <= TOL, (name, s)
+        assert rel_err(v, g[f's{s}_out_v']) <= 5 * TOL and rel_err(bond, g[f's{s}_out_bond']) <= 5 * TOL, (name, s)
+        assert rel_err(x0, g[f's{s}_out_x0']) <= 5 * TOL, (name, s)
+    if res is not None:
+        assert np.array_equal(res['traj'][0].argmax(-1).numpy(), g['traj_node'])
+        assert np.array_equal(res['traj'][2].argmax(-1).numpy(), g['traj_edge'])
+        rmsd = float(np.sqrt(((res['traj'][1].numpy() - g['traj_pos']) ** 2).sum(-1).mean()))
+        assert rmsd <= 1e-4, rmsd
+        assert rel_err(res['pred'][1], g['pred_pos']) <= 5 * TOL
+        assert np.array_equal(res['lig_info'][2].numpy(), g['lig_edge_index'])
