@@ -1,0 +1,187 @@
+/*
+ * phoregen_hip.h — C ABI of libphoregen_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for PhoreGen's diffusion-denoising hot path.  The reference has no native code
+ * (SURVEY.md 2.1): the arithmetic these entry points replace lives in PyTorch op chains and in the
+ * un-vendored wheels torch-scatter / torch-sparse / torch-cluster.  Each entry point cites the
+ * reference interface it stands in for (file:line under /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the duration of the call; the library allocates
+ *     nothing and keeps nothing (workspaces are passed in by the caller);
+ *   - fp32 row-major tensors, int32 indices;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*), no host synchronisation;
+ *   - return value: 0 = ok, otherwise pg_last_error() describes the failure.
+ *
+ * Context ("ctx") node order is the reference's compose_context order (models/common.py:180-208):
+ * per graph, pharmacophore nodes first, then ligand atoms.
+ */
+#ifndef PHOREGEN_HIP_H
+#define PHOREGEN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* pg_last_error(void);
+int pg_abi_version(void);
+
+/* ---- MFMA lane-map self test (device writes 0 on success) -------------------------------- */
+int pg_selftest_mfma(int* d_result, void* stream);
+
+/* ---- dense linear layers -------------------------------------------------------------------
+ * Y[r, n] = out_scale * act( sum_k Xcat[r,k] * W[n,k] + bias[n] + add1[i1(r), n] + add2[i2(r), n] )
+ * Xcat = [X | X2] along k; if ln_gamma != NULL, X rows first go through LayerNorm(K1, eps 1e-5)+ReLU.
+ * Replaces nn.Linear / MLP second halves (models/common.py:99-119), the per-node / per-edge halves
+ * of the first MLP layer that the reference computes on concatenated gathers
+ * (models/uni_denoiser.py:43-59,141-155,190-201), lin_node (:288) and the heads
+ * (models/diffusion.py:55-59,71-75,223,241). */
+typedef struct {
+  const float* X;   int ldx;  int K1;
+  const float* X2;  int ldx2; int K2;
+  const float* W;   int ldw;
+  const float* bias;
+  const float* ln_gamma; const float* ln_beta;
+  const float* add1; int ld_add1; const int* idx1;
+  const float* add2; int ld_add2; const int* idx2;
+  float out_scale;
+  int   act;                 /* 0 none, 1 shifted softplus (models/common.py:58-64), 2 ReLU */
+  float* Y; int ldy; int M; int N;
+} PgGemm;
+int pg_gemm(const PgGemm* p, void* stream);
+
+/* ---- graph topology of one batch ------------------------------------------------------------
+ * Built once per batch by the host mirror (phoregen_amd/plan.py); constant over the 1000 steps. */
+typedef struct {
+  int n_graphs, n_ctx, n_lig, n_phore, n_bond;
+  const int* g_ctx_off;     /* [B+1] first ctx node of graph g                                   */
+  const int* g_nph;         /* [B]   pharmacophore nodes of graph g (ctx rows g_ctx_off[g]..+nph) */
+  const int* g_nlig;        /* [B]   ligand atoms of graph g (follow the phore nodes)             */
+  const int* g_eid_off;     /* [B+1] offset of graph g's n_lig x n_lig edge-id table in `eid`     */
+  const int* eid;           /* eid[off_g + a_src*n + a_dst] = bond edge id, -1 on the diagonal    */
+  const int* ctx_graph;     /* [n_ctx] graph of a ctx node                                        */
+  const uint8_t* ctx_is_lig;/* [n_ctx]                                                            */
+  const int* lig2ctx;       /* [n_lig] ctx index of ligand atom a (= l_index_in_ctx, common.py:166-177) */
+  const int* bond_src;      /* [n_bond] ctx index of edge source (edge_index[0], diffusion.py:201) */
+  const int* bond_dst;      /* [n_bond] ctx index of edge target                                  */
+} PgTopo;
+
+/* ---- embeddings (models/diffusion.py:180-183,205; models/common.py:34-55) -------------------- */
+int pg_embed_ctx(const PgTopo* t, const float* h_node_pert /*[n_lig,12]*/, const float* pos_pert /*[n_lig,3]*/,
+                 const int64_t* time_step /*[B]*/, const float* W_node /*[118,12]*/,
+                 const float* t_offset /*[10]*/, const float* t_coeff /*[10]*/,
+                 const float* h_phore_emb /*[n_phore,128]*/, const float* pos_phore /*[n_phore,3]*/,
+                 const int* phore2ctx /*[n_phore]*/, float* h_ctx /*[n_ctx,128]*/, float* x_ctx /*[n_ctx,3]*/,
+                 void* stream);
+int pg_embed_bond(const PgTopo* t, const float* h_edge_pert /*[n_bond,6]*/, const int* bond_graph,
+                  const int64_t* time_step, const float* W_edge /*[118,6]*/, const float* t_offset,
+                  const float* t_coeff, float* h_bond /*[n_bond,128]*/, void* stream);
+
+/* ---- neighbour search (torch_cluster.knn_graph via uni_denoiser.py:355 and common.py:301) ----
+ * pg_knn_ctx: k nearest other ctx nodes of the same graph -> nbr[n_ctx,k] (ascending distance, index
+ *   breaks ties), deg[n_ctx] = min(k, nodes_in_graph-1).
+ * pg_lig_normals: nrm[ctx] = mean of the 3 nearest ligand atoms' positions - x  for ligand atoms
+ *   (common.py:300-304), phore_norm rows for pharmacophore nodes (common.py:312-314). */
+int pg_knn_ctx(const PgTopo* t, const float* x_ctx, int k, int* nbr, int* deg, void* stream);
+int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* phore_norm, const int* phore2ctx,
+                   float* nrm, void* stream);
+
+/* global edge gate e_w = sigmoid(MLP(smear(dist)))  (uni_denoiser.py:410-415) */
+int pg_edge_gate(const PgTopo* t, const float* x_ctx, const int* nbr, const int* deg, int k,
+                 const float* W0 /*[128,20]*/, const float* b0, const float* gamma, const float* beta,
+                 const float* W3 /*[128]*/, float b3, float* ew /*[n_ctx,k]*/, void* stream);
+
+/* per-bond Gaussian smearing of the bond length: G[e, 0:20] (uni_denoiser.py:128,137) */
+int pg_bond_smear(const PgTopo* t, const float* x_ctx, float* G /*[n_bond,20]*/, void* stream);
+
+/* ---- segment attention (the hot path) --------------------------------------------------------
+ * One call = one attention sub-layer of AttentionLayerO2TwoUpdateNodeGeneral (uni_denoiser.py:260-298)
+ * with the MLP first layers factored (SURVEY.md 7 "hard parts"):
+ *   hidden_m[row] = Csrc_m[src_row(row)] + Cdst_m[segment] + Wf_m * feat(row)          m in {k, v}
+ *   z_m = ReLU(LayerNorm(hidden_m));  logits[row,h] = z_k . U[segment][:,h]
+ *   alpha = softmax over the rows of a segment;  S[segment][:,h] = sum_row alpha*gate * z_v
+ * U / S are the per-segment query-folded key weights and value pre-images.
+ * Modes: */
+enum {
+  PG_SEG_KNN_NODE = 0,   /* NodeUpdateLayer on knn edges      (uni_denoiser.py:40-72 via :281)  */
+  PG_SEG_KNN_POS  = 1,   /* PosUpdateLayer  on knn edges      (uni_denoiser.py:187-209 via :291) */
+  PG_SEG_BOND_NODE = 2,  /* NodeUpdateLayer on bond edges     (:284)                             */
+  PG_SEG_BOND_POS  = 3,  /* PosUpdateLayer  on bond edges     (:294)                             */
+  PG_SEG_TRIPLET   = 4,  /* BondUpdateLayer                   (uni_denoiser.py:101-165 via :285) */
+  PG_SEG_PHORE     = 5   /* phore encoder NodeUpdateLayer     (diffusion.py:186-191)             */
+};
+
+typedef struct {
+  int mode;
+  int n_seg;
+  const int* seg_ids;        /* [n_seg] ctx node ids (node modes) / NULL = 0..n_seg-1 (triplet: bond edge ids) */
+  /* geometry */
+  const float* x;            /* [n_ctx,3] positions the features are computed from               */
+  const float* nrm;          /* [n_ctx,3] direction vectors (knn modes)                          */
+  const int* nbr; const int* deg; const float* ew; int knn_k;   /* knn modes                      */
+  /* factored first layer */
+  const float* Csrc_k; const float* Csrc_v; int ld_csrc;
+  const float* Cdst_k; const float* Cdst_v; int ld_cdst;
+  const float* Wf_k; const float* Wf_v;  /* lane-fixed [F/4][8][64] feature weights               */
+  const float* Wg2_k; const float* Wg2_v;/* triplet: [20][128] weights of smear(d_ji)             */
+  const float* G;                        /* triplet: [n_bond,20] from pg_bond_smear               */
+  const float* ln_gk; const float* ln_bk; const float* ln_gv; const float* ln_bv;
+  /* attention */
+  const float* U;            /* node modes: [n_ctx][32][64] lane-fixed U (pg_attn_fold_query)      */
+  const float* q;            /* triplet: [n_bond,128] queries, pre-scaled by 1/sqrt(head_dim)      */
+  const float* W2k_l;        /* triplet: lane-fixed second-layer key weights [64][64][4]           */
+  const float* W2v_l; const float* b2v;      /* triplet: lane-fixed value weights + bias          */
+  const float* W2xv_l; const float* b2xv;    /* pos modes: lane-fixed [32][64] + [16]             */
+  /* outputs */
+  float* S; float* swn;      /* node modes: [n_ctx][32][64], [n_ctx][16]                          */
+  const float* resid; float* out;            /* triplet: out[e,:] = resid[e,:] + update           */
+  float* dx;                 /* pos modes: [n_ctx,3]                                              */
+  int accumulate_dx;         /* pos modes: dx += instead of =                                     */
+} PgSegAttn;
+int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
+
+/* U[s][c][h] = sum_d q[s,8h+d] * W2k[8h+d,c]  in lane-fixed layout (key second layer folded into the query) */
+int pg_attn_fold_query(const float* q /*[n,128] pre-scaled*/, int ldq, const float* W2k_l, int n,
+                       const int* ids, float* U, void* stream);
+/* out[s, 8h+d] = sum_c W2v[8h+d,c] * S[s][c][h] + b2v[8h+d] * swn[s][h] */
+int pg_attn_unfold_value(const float* S, const float* swn, const float* W2v_l, const float* b2v, int n,
+                         const int* ids, float* out, int ldo, void* stream);
+
+/* x_new[i] = x[i] + (dx1[i] + dx2[i]) * is_lig[i]   (uni_denoiser.py:295-296) */
+int pg_apply_dx(const PgTopo* t, const float* x, const float* dx1, const float* dx2, float* x_new, void* stream);
+
+/* small per-row linear: Y[r, 0:n_out] = W[n_out,K] . X[rows ? rows[r] : r, 0:K] + b   (n_out <= 16, K <= 256) */
+int pg_rows_linear(const float* X, int ldx, int K, const float* W, const float* b, int n_out, int M,
+                   const int* rows, float* Y, int ldy, void* stream);
+
+/* atom-count heads: per graph mean of sigmoid(logit) over all / non-EX phore nodes, u = l + relu(c - l)
+ * (diffusion.py:148-163); s_all / s_l are the pre-sigmoid outputs of atom_mlp / atom_mlp_1 */
+int pg_atom_count(const float* s_all /*[n_phore]*/, const float* s_l /*[n_phore]*/, const uint8_t* is_ex,
+                  const int* phore_graph, int n_phore, int n_graphs, float* count_l, float* count_u, void* stream);
+
+/* ---- reverse-diffusion step (models/transition.py:44-63,285-315, models/common.py:425-431) ----
+ * categorical: log_softmax(logits) -> q_v_posterior(v0_prob=True) -> Gumbel-argmax -> one-hot.
+ * `uniform` != NULL replays given draws (parity mode); NULL -> counter-based Philox4x32-10 keyed by
+ * (seed, stream_id, step). */
+int pg_posterior_categorical(const float* logits, const float* log_vt_in, const int* row_graph,
+                             const int64_t* time_step, const float* q_mats, const float* q_onestep_T,
+                             int n_rows, int K, const float* uniform, uint64_t seed, uint32_t stream_id,
+                             uint32_t step, float* log_vt_out, float* onehot_out, float* traj_out,
+                             void* stream);
+int pg_posterior_position(const float* x_t, const float* x0, const int* row_graph, const int64_t* time_step,
+                          const float* coef_x0, const float* coef_xt, const float* std_, const float* energy_grad,
+                          const float* eps, uint64_t seed, uint32_t stream_id, uint32_t step, int n_rows,
+                          const float* center /*[3] or NULL*/, float* x_prev, float* traj_out, void* stream);
+
+/* closed-form guidance gradient (models/diffusion.py:476-502, utils/sample_utils.py:135-165) */
+int pg_guidance_grad(const PgTopo* t, const float* x_lig /*[n_lig,3]*/, const float* h_edge_prev /*[n_bond,6]*/,
+                     const int* lig_graph, const int* g_lig_off, int use_atom_prox, float min_d, float max_d,
+                     int use_center_prox, const float* phore_center /*[3]*/, float* cnt_ws /*[B]*/,
+                     float* mean_ws /*[B,3]*/, float* grad /*[n_lig,3]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+// Shared device/host helpers for the PhoreGen gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define PG_OK 0
+#define PG_ERR_ARG 1
+#define PG_ERR_HIP 2
+
+namespace pg {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return PG_ERR_HIP;
+  }
+  return PG_OK;
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_16x16x4_f32: lane l supplies A[row=l&15][k=l>>4], B[k=l>>4][col=l&15];
+// D reg r of lane l is D[row=4*(l>>4)+r][col=l&15].
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x2_f32: lane l supplies A[row=l&31][k=l>>5], B[k=l>>5][col=l&31];
+// D reg r of lane l is D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+__device__ __forceinline__ f16v mfma32(float a, float b, f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// 20 fixed Gaussian offsets of models/common.py:18 (coeff = -0.5, common.py:23)
+__device__ __constant__ const float kSmearOff[20] = {0.f, 1.f, 1.25f, 1.5f, 1.75f, 2.f, 2.25f, 2.5f, 2.75f, 3.f,
+                                                     3.5f, 4.f, 4.5f, 5.f, 5.5f, 6.f, 7.f, 8.f, 9.f, 10.f};
+
+__device__ __forceinline__ float smear(float d, int i) {
+  float t = d - kSmearOff[i];
+  return expf(-0.5f * t * t);
+}
+
+constexpr int kNumCU = 256;
+
+}  // namespace pg

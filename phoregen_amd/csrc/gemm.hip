@@ -1,0 +1,185 @@
+// fp32 MFMA GEMM for the dense node / edge linear layers:  Y = act(Xcat . W^T + bias + gathered adds).
+// 128x128 block tile, 4 waves x (64x64) of v_mfma_f32_32x32x2_f32, K streamed through LDS in 32-wide
+// chunks (row stride 33 floats: conflict-free ds_read_b32 for both operands).  Optional
+// LayerNorm(128)+ReLU folded into the A-tile load (second half of models/common.py:99-119 MLPs).
+#include "common.h"
+#include "../../include/phoregen_hip.h"
+
+namespace pg {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 1;
+
+__device__ __forceinline__ float ssp(float v) {  // softplus(v) - ln 2, torch threshold 20
+  float sp = v > 20.f ? v : log1pf(expf(v));
+  return sp - 0.69314718055994530942f;
+}
+
+__global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
+  __shared__ float As[BM * LDT];
+  __shared__ float Bs[BN * LDT];
+  __shared__ float rstat[BM * 2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  const int K = p.K1 + p.K2;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;  // wave sub-tile origin
+  const bool ln = p.ln_gamma != nullptr;
+
+  if (ln) {  // per-row mean / rstd over K1 (= 128) columns; two threads per row
+    const int r = tid >> 1, half = tid & 1, grow = row0 + r;
+    float s = 0.f;
+    const int kh = p.K1 >> 1;
+    if (grow < p.M)
+      for (int k = 0; k < kh; ++k) s += p.X[(size_t)grow * p.ldx + half * kh + k];
+    s += __shfl_xor(s, 1);
+    const float mu = s / (float)p.K1;
+    float v = 0.f;
+    if (grow < p.M)
+      for (int k = 0; k < kh; ++k) {
+        float d = p.X[(size_t)grow * p.ldx + half * kh + k] - mu;
+        v += d * d;
+      }
+    v += __shfl_xor(v, 1);
+    if (half == 0) {
+      rstat[r * 2] = mu;
+      rstat[r * 2 + 1] = 1.0f / sqrtf(v / (float)p.K1 + 1e-5f);
+    }
+    __syncthreads();
+  }
+
+  f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool fastX = (p.ldx & 3) == 0 && (p.K1 & 3) == 0 && ((size_t)p.X & 15) == 0;
+  const bool fastW = (p.ldw & 3) == 0 && (K & 3) == 0 && ((size_t)p.W & 15) == 0;
+
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // ---- stage A (X rows) and B (W rows) chunks: each thread 4 x (4 consecutive k) ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (tid >> 3) + 32 * i, kq = (tid & 7) * 4, kk = k0 + kq;
+      const int grow = row0 + r;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (grow < p.M) {
+        if (fastX && kk + 3 < p.K1) {
+          const float4 t = *reinterpret_cast<const float4*>(p.X + (size_t)grow * p.ldx + kk);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = kk + j;
+            if (k < p.K1) v[j] = p.X[(size_t)grow * p.ldx + k];
+            else if (k < K) v[j] = p.X2[(size_t)grow * p.ldx2 + (k - p.K1)];
+          }
+        }
+        if (ln) {
+          const float mu = rstat[r * 2], rs = rstat[r * 2 + 1];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kk + j < p.K1) v[j] = fmaxf((v[j] - mu) * rs * p.ln_gamma[kk + j] + p.ln_beta[kk + j], 0.f);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[r * LDT + kq + j] = v[j];
+
+      const int gcol = col0 + r;
+      float w[4] = {0.f, 0.f, 0.f, 0.f};
+      if (gcol < p.N) {
+        if (fastW && kk + 3 < K) {
+          const float4 t = *reinterpret_cast<const float4*>(p.W + (size_t)gcol * p.ldw + kk);
+          w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kk + j < K) w[j] = p.W[(size_t)gcol * p.ldw + kk + j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bs[r * LDT + kq + j] = w[j];
+    }
+    __syncthreads();
+    // ---- 16 k-steps of 2 ----
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll 4
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int k = ks * 2 + kh;
+      const float a0 = As[(wr + l31) * LDT + k], a1 = As[(wr + 32 + l31) * LDT + k];
+      const float b0 = Bs[(wc + l31) * LDT + k], b1 = Bs[(wc + 32 + l31) * LDT + k];
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int grow = row0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (grow >= p.M) continue;
+      const int a1 = p.add1 ? (p.idx1 ? p.idx1[grow] : grow) : 0;
+      const int a2 = p.add2 ? (p.idx2 ? p.idx2[grow] : grow) : 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int gcol = col0 + wc + 32 * j + l31;
+        if (gcol >= p.N) continue;
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[gcol];
+        if (p.add1) v += p.add1[(size_t)a1 * p.ld_add1 + gcol];
+        if (p.add2) v += p.add2[(size_t)a2 * p.ld_add2 + gcol];
+        if (p.act == 1) v = ssp(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        p.Y[(size_t)grow * p.ldy + gcol] = v * p.out_scale;
+      }
+    }
+}
+
+// ---- small per-row linear (n_out <= 16): one wave per row ----------------------------------------
+__global__ __launch_bounds__(256) void rows_linear_kernel(const float* X, int ldx, int K, const float* W, const float* b,
+                                                          int n_out, int M, const int* rows, float* Y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const int src = rows ? rows[r] : r;
+  float x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = (lane + 64 * i) < K ? X[(size_t)src * ldx + lane + 64 * i] : 0.f;
+  for (int o = 0; o < n_out; ++o) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < K) s += x[i] * W[o * K + lane + 64 * i];
+    s = wave_sum(s);
+    if (lane == 0) Y[(size_t)r * ldy + o] = s + (b ? b[o] : 0.f);
+  }
+}
+
+}  // namespace pg
+
+extern "C" int pg_gemm(const PgGemm* p, void* stream) {
+  if (!p || !p->X || !p->W || !p->Y || p->M < 0 || p->N <= 0) { pg::set_error("pg_gemm: bad arguments"); return PG_ERR_ARG; }
+  if (p->M == 0) return PG_OK;
+  if (p->K2 > 0 && !p->X2) { pg::set_error("pg_gemm: K2 > 0 without X2"); return PG_ERR_ARG; }
+  if (p->ln_gamma && (p->K2 != 0 || (p->K1 & 1))) { pg::set_error("pg_gemm: LayerNorm-on-load needs K2 == 0"); return PG_ERR_ARG; }
+  dim3 grid((p->M + pg::BM - 1) / pg::BM, (p->N + pg::BN - 1) / pg::BN);
+  hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+  return pg::check_launch("pg_gemm");
+}
+
+extern "C" int pg_rows_linear(const float* X, int ldx, int K, const float* W, const float* b, int n_out, int M,
+                              const int* rows, float* Y, int ldy, void* stream) {
+  if (n_out > 16 || n_out <= 0 || K <= 0 || K > 256) { pg::set_error("pg_rows_linear: n_out must be 1..16, K 1..256"); return PG_ERR_ARG; }
+  if (M == 0) return PG_OK;
+  hipLaunchKernelGGL(pg::rows_linear_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, K, W, b,
+                     n_out, M, rows, Y, ldy);
+  return pg::check_launch("pg_rows_linear");
+}

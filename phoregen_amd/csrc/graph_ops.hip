@@ -1,0 +1,307 @@
+// Graph-side kernels of the denoising step: embeddings, exact in-graph kNN, direction vectors,
+// global edge gate, bond-length smearing, coordinate update, atom-count pooling.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+#include "../../include/phoregen_hip.h"
+
+namespace pg {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeddings  (models/diffusion.py:180-183,205 ; TimeGaussianSmearing models/common.py:51-55)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float time_smear(float t, const float* off, const float* coeff, int i) {
+  t = fminf(fmaxf(t, 0.f), 1000.f);
+  const float d = t - off[i];
+  return expf(coeff[i] * (d * d));
+}
+
+__global__ void embed_ctx_kernel(PgTopo t, const float* h_node, const float* pos, const int64_t* time_step,
+                                 const float* W_node, const float* t_off, const float* t_coeff,
+                                 const float* h_phore_emb, const float* pos_phore, const int* phore2ctx,
+                                 float* h_ctx, float* x_ctx) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int node = idx >> 7, c = idx & 127;
+  if (node >= t.n_lig + t.n_phore) return;
+  if (node < t.n_lig) {
+    const int ctx = t.lig2ctx[node];
+    float v;
+    if (c < 118) {
+      v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v += h_node[node * 12 + k] * W_node[c * 12 + k];
+    } else {
+      v = time_smear((float)time_step[t.ctx_graph[ctx]], t_off, t_coeff, c - 118);
+    }
+    h_ctx[(size_t)ctx * 128 + c] = v;
+    if (c < 3) x_ctx[ctx * 3 + c] = pos[node * 3 + c];
+  } else {
+    const int p = node - t.n_lig, ctx = phore2ctx[p];
+    h_ctx[(size_t)ctx * 128 + c] = h_phore_emb[(size_t)p * 128 + c];
+    if (c < 3) x_ctx[ctx * 3 + c] = pos_phore[p * 3 + c];
+  }
+}
+
+__global__ void embed_bond_kernel(int n_bond, const float* h_edge, const int* bond_graph, const int64_t* time_step,
+                                  const float* W_edge, const float* t_off, const float* t_coeff, float* h_bond) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t e = idx >> 7;
+  const int c = idx & 127;
+  if (e >= (size_t)n_bond) return;
+  float v;
+  if (c < 118) {
+    v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v += h_edge[e * 6 + k] * W_edge[c * 6 + k];
+  } else {
+    v = time_smear((float)time_step[bond_graph[e]], t_off, t_coeff, c - 118);
+  }
+  h_bond[e * 128 + c] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact kNN inside a graph, one wave per centre (torch_cluster.knn_graph, loop=False)
+//   key = (bits(d2) << 32) | candidate  -> ascending distance, index breaks ties
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_MAXC = 8;  // candidates per lane -> graphs of up to 512 nodes
+
+__device__ __forceinline__ float dist2_rn(const float* a, const float* b) {
+  // (dx^2 + dy^2) + dz^2 with every product / sum rounded separately (no fma contraction), the order
+  // a torch (x[:,None]-x[None]).pow(2).sum(-1) uses
+  const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    unsigned long long w = __shfl_xor(v, o);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+// first..first+count = candidate ctx range; `self` excluded; writes k slots (-1 beyond deg)
+__device__ void wave_knn(const float* x, int first, int count, int self, int k, int* out_slots, int* out_deg) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long key[KNN_MAXC];
+  const float xs[3] = {x[self * 3], x[self * 3 + 1], x[self * 3 + 2]};
+#pragma unroll
+  for (int i = 0; i < KNN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    key[i] = ~0ull;
+    if (c < count && first + c != self) {
+      const float d2 = dist2_rn(x + (size_t)(first + c) * 3, xs);
+      key[i] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
+    }
+  }
+  const int deg = min(k, count - 1);
+  for (int s = 0; s < k; ++s) {
+    unsigned long long best = key[0];
+#pragma unroll
+    for (int i = 1; i < KNN_MAXC; ++i) best = key[i] < best ? key[i] : best;
+    best = wave_min_u64(best);
+    const int c = (int)(best & 0xffffffffu);
+    if (s < deg) {
+#pragma unroll
+      for (int i = 0; i < KNN_MAXC; ++i)
+        if (key[i] == best) key[i] = ~0ull;
+    }
+    if (lane == 0) out_slots[s] = s < deg ? first + c : -1;
+  }
+  if (lane == 0 && out_deg) *out_deg = deg;
+}
+
+__global__ __launch_bounds__(256) void knn_ctx_kernel(PgTopo t, const float* x, int k, int* nbr, int* deg) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= t.n_ctx) return;
+  const int g = t.ctx_graph[node];
+  const int first = t.g_ctx_off[g], count = t.g_ctx_off[g + 1] - first;
+  wave_knn(x, first, count, node, k, nbr + (size_t)node * k, deg + node);
+}
+
+// direction vectors (models/common.py:300-314)
+__global__ __launch_bounds__(256) void lig_normals_kernel(PgTopo t, const float* x, const float* phore_norm,
+                                                          const int* phore2ctx, float* nrm) {
+  __shared__ int slots[4][4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + w;
+  if (item >= t.n_lig + t.n_phore) return;
+  if (item >= t.n_lig) {
+    const int p = item - t.n_lig;
+    if (lane < 3) nrm[phore2ctx[p] * 3 + lane] = phore_norm[p * 3 + lane];
+    return;
+  }
+  const int ctx = t.lig2ctx[item], g = t.ctx_graph[ctx];
+  const int first = t.g_ctx_off[g] + t.g_nph[g], count = t.g_nlig[g];
+  int d;
+  wave_knn(x, first, count, ctx, 3, slots[w], &d);
+  d = min(3, count - 1);
+  if (lane < 3) {
+    float s = 0.f;
+    for (int i = 0; i < d; ++i) s += x[slots[w][i] * 3 + lane];       // scatter(mean): sum in edge order / count
+    nrm[ctx * 3 + lane] = s / (float)max(d, 1) - x[ctx * 3 + lane];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// global edge gate  e_w = sigmoid(W3 . ReLU(LN(W0 . smear(d) + b0)) + b3)   (uni_denoiser.py:410-415)
+// one wave per (node, slot); lane owns hidden units lane and lane+64
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_gate_kernel(int n_ctx, const float* x, const int* nbr, const int* deg,
+                                                        int k, const float* W0, const float* b0, const float* gamma,
+                                                        const float* beta, const float* W3, float b3, float* ew) {
+  const int lane = threadIdx.x & 63;
+  float w0[2][20];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int i = 0; i < 20; ++i) w0[u][i] = W0[(lane + 64 * u) * 20 + i];
+  const float bb[2] = {b0[lane], b0[lane + 64]}, gg[2] = {gamma[lane], gamma[lane + 64]},
+              be[2] = {beta[lane], beta[lane + 64]}, w3[2] = {W3[lane], W3[lane + 64]};
+  const long total = (long)n_ctx * k;
+  for (long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (long)gridDim.x * 4) {
+    const int node = (int)(e / k), slot = (int)(e % k);
+    if (slot >= deg[node]) {
+      if (lane == 0) ew[e] = 0.f;
+      continue;
+    }
+    const int src = nbr[e];
+    const float dx = x[node * 3] - x[src * 3], dy = x[node * 3 + 1] - x[src * 3 + 1], dz = x[node * 3 + 2] - x[src * 3 + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    float h[2] = {bb[0], bb[1]};
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+      const float s = smear(d, i);
+      h[0] += w0[0][i] * s;
+      h[1] += w0[1][i] * s;
+    }
+    const float mu = wave_sum(h[0] + h[1]) * (1.f / 128.f);
+    const float d0 = h[0] - mu, d1 = h[1] - mu;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    const float z0 = fmaxf(d0 * rs * gg[0] + be[0], 0.f), z1 = fmaxf(d1 * rs * gg[1] + be[1], 0.f);
+    const float o = wave_sum(z0 * w3[0] + z1 * w3[1]) + b3;
+    if (lane == 0) ew[e] = 1.f / (1.f + expf(-o));
+  }
+}
+
+__global__ void bond_smear_kernel(int n_bond, const int* bsrc, const int* bdst, const float* x, float* G) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = idx / 20, i = idx % 20;
+  if (e >= n_bond) return;
+  const int s = bsrc[e], d = bdst[e];
+  const float dx = x[d * 3] - x[s * 3], dy = x[d * 3 + 1] - x[s * 3 + 1], dz = x[d * 3 + 2] - x[s * 3 + 2];
+  G[idx] = smear(sqrtf(dx * dx + dy * dy + dz * dz), i);
+}
+
+__global__ void apply_dx_kernel(int n_ctx, const uint8_t* is_lig, const float* x, const float* dx1, const float* dx2,
+                                float* x_new) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_ctx * 3) return;
+  const float m = is_lig[idx / 3] ? 1.f : 0.f;
+  x_new[idx] = x[idx] + (dx1[idx] + dx2[idx]) * m;
+}
+
+// per-graph means of the two count heads (models/diffusion.py:148-159); one block per graph
+__global__ void atom_count_kernel(const float* s_all, const float* s_l, const uint8_t* is_ex, const int* phore_graph,
+                                  int n_phore, float* count_l, float* count_u) {
+  const int g = blockIdx.x;
+  __shared__ float red[4][64];
+  float a = 0.f, na = 0.f, l = 0.f, nl = 0.f;
+  for (int p = threadIdx.x; p < n_phore; p += 64)
+    if (phore_graph[p] == g) {
+      a += 1.f / (1.f + expf(-s_all[p]));
+      na += 1.f;
+      if (!is_ex[p]) { l += 1.f / (1.f + expf(-s_l[p])); nl += 1.f; }
+    }
+  a = wave_sum(a); na = wave_sum(na); l = wave_sum(l); nl = wave_sum(nl);
+  if (threadIdx.x == 0) {
+    const float ca = a / fmaxf(na, 1.f), cl = l / fmaxf(nl, 1.f);
+    count_l[g] = cl;
+    count_u[g] = cl + fmaxf(ca - cl, 0.f);
+  }
+  (void)red;
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" const char* pg_last_error(void) { return pg::g_err; }
+extern "C" int pg_abi_version(void) { return 1; }
+
+extern "C" int pg_embed_ctx(const PgTopo* t, const float* h_node_pert, const float* pos_pert, const int64_t* time_step,
+                            const float* W_node, const float* t_off, const float* t_coeff, const float* h_phore_emb,
+                            const float* pos_phore, const int* phore2ctx, float* h_ctx, float* x_ctx, void* stream) {
+  const long n = (long)(t->n_lig + t->n_phore) * 128;
+  if (n == 0) return PG_OK;
+  hipLaunchKernelGGL(embed_ctx_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *t, h_node_pert,
+                     pos_pert, time_step, W_node, t_off, t_coeff, h_phore_emb, pos_phore, phore2ctx, h_ctx, x_ctx);
+  return check_launch("pg_embed_ctx");
+}
+
+extern "C" int pg_embed_bond(const PgTopo* t, const float* h_edge_pert, const int* bond_graph, const int64_t* time_step,
+                             const float* W_edge, const float* t_off, const float* t_coeff, float* h_bond, void* stream) {
+  const long n = (long)t->n_bond * 128;
+  if (n == 0) return PG_OK;
+  hipLaunchKernelGGL(embed_bond_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->n_bond,
+                     h_edge_pert, bond_graph, time_step, W_edge, t_off, t_coeff, h_bond);
+  return check_launch("pg_embed_bond");
+}
+
+extern "C" int pg_knn_ctx(const PgTopo* t, const float* x_ctx, int k, int* nbr, int* deg, void* stream) {
+  if (k < 1 || k > 64) { set_error("pg_knn_ctx: k out of range"); return PG_ERR_ARG; }
+  hipLaunchKernelGGL(knn_ctx_kernel, dim3((t->n_ctx + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, k, nbr, deg);
+  return check_launch("pg_knn_ctx");
+}
+
+extern "C" int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* phore_norm, const int* phore2ctx,
+                              float* nrm, void* stream) {
+  const int n = t->n_lig + t->n_phore;
+  hipLaunchKernelGGL(lig_normals_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, phore_norm,
+                     phore2ctx, nrm);
+  return check_launch("pg_lig_normals");
+}
+
+extern "C" int pg_edge_gate(const PgTopo* t, const float* x_ctx, const int* nbr, const int* deg, int k, const float* W0,
+                            const float* b0, const float* gamma, const float* beta, const float* W3, float b3,
+                            float* ew, void* stream) {
+  const long total = (long)t->n_ctx * k;
+  const int blocks = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
+  hipLaunchKernelGGL(edge_gate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t->n_ctx, x_ctx, nbr, deg, k,
+                     W0, b0, gamma, beta, W3, b3, ew);
+  return check_launch("pg_edge_gate");
+}
+
+extern "C" int pg_bond_smear(const PgTopo* t, const float* x_ctx, float* G, void* stream) {
+  const long n = (long)t->n_bond * 20;
+  if (n == 0) return PG_OK;
+  hipLaunchKernelGGL(bond_smear_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->n_bond,
+                     t->bond_src, t->bond_dst, x_ctx, G);
+  return check_launch("pg_bond_smear");
+}
+
+extern "C" int pg_apply_dx(const PgTopo* t, const float* x, const float* dx1, const float* dx2, float* x_new,
+                           void* stream) {
+  const int n = t->n_ctx * 3;
+  hipLaunchKernelGGL(apply_dx_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->n_ctx,
+                     t->ctx_is_lig, x, dx1, dx2, x_new);
+  return check_launch("pg_apply_dx");
+}
+
+extern "C" int pg_atom_count(const float* s_all, const float* s_l, const uint8_t* is_ex, const int* phore_graph,
+                             int n_phore, int n_graphs, float* count_l, float* count_u, void* stream) {
+  hipLaunchKernelGGL(atom_count_kernel, dim3(n_graphs), dim3(64), 0, (hipStream_t)stream, s_all, s_l, is_ex,
+                     phore_graph, n_phore, count_l, count_u);
+  return check_launch("pg_atom_count");
+}

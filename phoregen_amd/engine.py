@@ -1,0 +1,305 @@
+"""Launch sequence of the denoiser on one batch plan.
+
+`Engine` owns the persistent workspace of a (weights, plan) pair and a pre-built launch list: every
+C-ABI argument struct is created once, so a denoise step is ~200 ctypes calls with no allocation, no
+host synchronisation and no Python tensor arithmetic.  Stream = torch's current stream at run time.
+
+Data flow of one layer (reference: AttentionLayerO2TwoUpdateNodeGeneral.forward, uni_denoiser.py:260-298):
+  Y1   = h @ W_node1^T            15 first-layer blocks (knn-node, bond-node, triplet; k/v dst+src halves, q)
+  q*   = LN/ReLU/W2 of the q blocks (pre-scaled by 1/sqrt(8)),  U = fold(q, W2k)
+  Cs*  = h_bond @ W_hb^T + gathered node halves                (bond-node, triplet P, triplet q)
+  aggE = unfold(seg_attn<KNN_NODE>),  aggB = unfold(seg_attn<BOND_NODE>),  h_bond' = h_bond + seg_attn<TRIPLET>
+  h'   = h + lin_node(aggE + aggB)
+  Y2   = h' @ W_node2^T; same for the two position sub-layers;  x' = x + mask * (dx_knn + dx_bond)
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .packing import HEAD_SCALE, ModelPack
+
+
+def _f(*shape, device, zero=False):
+    return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=device)
+
+
+class Engine:
+    def __init__(self, pack: ModelPack, plan, knn_k=32, full=True):
+        self.lib = hip.lib()
+        self.pack, self.plan, self.k = pack, plan, knn_k
+        self.dev = plan.device
+        self._keep = []          # ctypes structs / tensors referenced by raw pointer
+        self.debug = None
+        self._alloc()
+        if full:
+            self.prog_phore = self._build_phore_program()
+            self.prog_fwd = self._build_forward_program()
+
+    # ------------------------------------------------------------------ workspace
+    def _alloc(self):
+        p, d = self.plan, self.dev
+        n, E, k = p.n_ctx, p.n_bond, self.k
+        w = self.ws = type('WS', (), {})()
+        w.in_h_node, w.in_pos = _f(p.n_lig, 12, device=d), _f(p.n_lig, 3, device=d)
+        w.in_h_edge = _f(E, 6, device=d)
+        w.in_t = torch.zeros(p.n_graphs, dtype=torch.int64, device=d)
+        w.h_phore_ctx, w.x_phore_ctx = _f(n, 18, device=d, zero=True), _f(n, 3, device=d, zero=True)
+        w.pos_phore, w.phore_norm = _f(p.n_phore, 3, device=d), _f(p.n_phore, 3, device=d)
+        w.is_ex = torch.zeros(p.n_phore, dtype=torch.uint8, device=d)
+        w.hp_ctx, w.Yp = _f(n, 128, device=d), _f(n, 640, device=d)
+        w.enc_ctx = _f(n, 128, device=d, zero=True)
+        w.hp_emb = _f(p.n_phore, 128, device=d)
+        w.cnt_hid = _f(n, 256, device=d)
+        w.s_all, w.s_l = _f(p.n_phore, device=d), _f(p.n_phore, device=d)
+        w.count_l, w.count_u = _f(p.n_graphs, device=d), _f(p.n_graphs, device=d)
+        w.h = [_f(n, 128, device=d), _f(n, 128, device=d)]
+        w.x = [_f(n, 3, device=d), _f(n, 3, device=d)]
+        w.hb = [_f(E, 128, device=d), _f(E, 128, device=d)]
+        w.nbr = torch.zeros(n, k, dtype=torch.int32, device=d)
+        w.deg = torch.zeros(n, dtype=torch.int32, device=d)
+        w.ew, w.nrm, w.G = _f(n, k, device=d), _f(n, 3, device=d), _f(E, 20, device=d)
+        w.Y1, w.Y2 = _f(n, 1920, device=d), _f(n, 1280, device=d)
+        w.q = _f(n, 128, device=d)
+        w.U, w.S, w.swn = _f(n, 2048, device=d), _f(n, 2048, device=d), _f(n, 16, device=d)
+        w.aggE, w.aggB = _f(n, 128, device=d, zero=True), _f(n, 128, device=d, zero=True)
+        w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)
+        w.qhid, w.qT = _f(E, 128, device=d), _f(E, 128, device=d)
+        w.dxe, w.dxb = _f(n, 3, device=d, zero=True), _f(n, 3, device=d, zero=True)
+        w.head = _f(n, 128, device=d)
+        w.head_b = _f(E, 128, device=d)
+        w.out_v, w.out_bond = _f(p.n_lig, 12, device=d), _f(E, 6, device=d)
+
+    # ------------------------------------------------------------------ call builders
+    def _call(self, prog, fn, *args):
+        prog.append((fn, args))
+
+    def _mark(self, prog, name, *tensors):
+        """Debug tap: when `self.debug` is a dict, clone the named tensors at this point of the launch list."""
+        def tap(_stream):
+            if self.debug is not None:
+                self.debug[name] = tuple(t.clone() for t in tensors)
+            return 0
+        tap.__name__ = 'tap_' + name
+        prog.append((tap, ()))
+
+    def _gemm(self, prog, X, K1, W, Y, M, N, bias=None, X2=None, K2=0, ln=None, add1=None, idx1=None, add2=None,
+              idx2=None, scale=1.0, act=hip.ACT_NONE):
+        g = hip.PgGemm()
+        g.X, g.ldx, g.K1 = X.data_ptr(), X.stride(0), K1
+        g.X2, g.ldx2, g.K2 = (X2.data_ptr(), X2.stride(0), K2) if X2 is not None else (None, 0, 0)
+        g.W, g.ldw = W.data_ptr(), W.stride(0)
+        g.bias = hip.ptr(bias)
+        g.ln_gamma, g.ln_beta = (ln[0].data_ptr(), ln[1].data_ptr()) if ln is not None else (None, None)
+        g.add1, g.ld_add1, g.idx1 = (add1.data_ptr(), add1.stride(0), hip.ptr(idx1)) if add1 is not None else (None, 0, None)
+        g.add2, g.ld_add2, g.idx2 = (add2.data_ptr(), add2.stride(0), hip.ptr(idx2)) if add2 is not None else (None, 0, None)
+        g.out_scale, g.act = scale, act
+        g.Y, g.ldy, g.M, g.N = Y.data_ptr(), Y.stride(0), M, N
+        self._keep += [g, X, W, Y, bias, X2, ln, add1, idx1, add2, idx2]
+        self._call(prog, self.lib.pg_gemm, C.byref(g))
+
+    def _seg(self, prog, mode, n_seg, seg_ids, a, **kw):
+        s = hip.PgSegAttn()
+        s.mode, s.n_seg, s.seg_ids = mode, n_seg, hip.ptr(seg_ids)
+        s.knn_k = self.k
+        s.ln_gk, s.ln_bk, s.ln_gv, s.ln_bv = (t.data_ptr() for t in (a.ln_gk, a.ln_bk, a.ln_gv, a.ln_bv))
+        for key, val in kw.items():
+            setattr(s, key, val.data_ptr() if torch.is_tensor(val) else val)
+            self._keep.append(val)
+        self._keep += [s, seg_ids, a]
+        self._call(prog, self.lib.pg_seg_attn, self.plan.topo_ref, C.byref(s))
+
+    def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None):
+        """Shared tail of the four node-target sub-layers.  Y[:, col0 + 128*b] blocks: k_dst, v_dst, k_src, v_src, q_hid."""
+        w, p, n = self.ws, self.plan, self.plan.n_ctx
+        blk = lambda b: Y[:, col0 + 128 * b: col0 + 128 * (b + 1)]
+        # q = W2q . ReLU(LN(q_hid)) + b2q, scaled by 1/sqrt(head_dim)
+        self._gemm(prog, blk(4), 128, a.W2q, w.q, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
+        knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
+        pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
+        for seg_ids, n_seg, is_lig in h_dst_lists:
+            self._call(prog, self.lib.pg_attn_fold_query, w.q.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
+                       seg_ids.data_ptr(), w.U.data_ptr())
+            kw = dict(x=x, Cdst_k=blk(0), Cdst_v=blk(1), ld_cdst=Y.stride(0), U=w.U)
+            if knn:
+                kw.update(nrm=w.nrm, nbr=w.nbr, deg=w.deg, ew=w.ew, Csrc_k=blk(2), Csrc_v=blk(3), ld_csrc=Y.stride(0),
+                          Wf_k=a.Wf_k[is_lig], Wf_v=a.Wf_v[is_lig])
+            elif mode == hip.SEG_PHORE:
+                kw.update(Csrc_k=blk(2), Csrc_v=blk(3), ld_csrc=Y.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v)
+            else:
+                kw.update(Csrc_k=csrc[:, 0:128], Csrc_v=csrc[:, 128:256], ld_csrc=csrc.stride(0))
+            if pos:
+                kw.update(W2xv_l=a.W2xv_l, b2xv=a.b2xv, dx=dx, accumulate_dx=0)
+            else:
+                kw.update(S=w.S, swn=w.swn)
+            self._seg(prog, mode, n_seg, seg_ids, a, **kw)
+            if not pos:
+                self._call(prog, self.lib.pg_attn_unfold_value, w.S.data_ptr(), w.swn.data_ptr(), a.W2v_l.data_ptr(),
+                           a.b2v.data_ptr(), n_seg, seg_ids.data_ptr(), out.data_ptr(), out.stride(0))
+
+    # ------------------------------------------------------------------ phore encoder + count heads (per plan)
+    def _build_phore_program(self):
+        w, p, pk, prog = self.ws, self.plan, self.pack, []
+        n = p.n_ctx
+        # diffusion.py:186: phore_embedding on ctx-ordered rows (ligand rows are zero and unused)
+        self._gemm(prog, w.h_phore_ctx, 18, pk.W_pe, w.hp_ctx, n, 128, bias=pk.b_pe)
+        self._gemm(prog, w.hp_ctx, 128, pk.W_ph, w.Yp, n, 640, bias=pk.b_ph)
+        self._node_attention(prog, hip.SEG_PHORE, pk.PH, w.Yp, 0, w.x_phore_ctx,
+                             [(p.phore2ctx, p.n_phore, False)], out=w.enc_ctx)
+        # diffusion.py:148-163 count heads on the encoded pharmacophore
+        for (W0, b0, W2, b2), dst in zip(pk.cnt, (w.s_all, w.s_l)):
+            self._gemm(prog, w.enc_ctx, 128, W0, w.cnt_hid, n, 256, bias=b0, act=hip.ACT_RELU)
+            self._call(prog, self.lib.pg_rows_linear, w.cnt_hid.data_ptr(), 256, 256, W2.data_ptr(), b2.data_ptr(), 1,
+                       p.n_phore, p.phore2ctx.data_ptr(), dst.data_ptr(), 1)
+        self._call(prog, self.lib.pg_atom_count, w.s_all.data_ptr(), w.s_l.data_ptr(), w.is_ex.data_ptr(),
+                   p.phore_graph.data_ptr(), p.n_phore, p.n_graphs, w.count_l.data_ptr(), w.count_u.data_ptr())
+        return prog
+
+    def encode_phore(self, h_phore, pos_phore, phore_norm, ex_col=12):
+        """Time-independent part of PhoreDiff.forward (diffusion.py:186-191,244): run once per batch."""
+        w, p = self.ws, self.plan
+        w.h_phore_ctx.index_copy_(0, p.phore2ctx_long, h_phore.float())
+        w.x_phore_ctx.index_copy_(0, p.phore2ctx_long, pos_phore.float())
+        w.pos_phore.copy_(pos_phore)
+        w.phore_norm.copy_(phore_norm)
+        w.is_ex.copy_((h_phore[:, ex_col] == 1).to(torch.uint8))
+        self._run(self.prog_phore)
+        torch.index_select(w.enc_ctx, 0, p.phore2ctx_long, out=w.hp_emb)
+
+    # ------------------------------------------------------------------ one denoiser forward
+    def _build_forward_program(self):
+        w, p, pk, prog, lib = self.ws, self.plan, self.pack, [], self.lib
+        n, E, t = p.n_ctx, p.n_bond, p.topo_ref
+        lig = [(p.lig2ctx, p.n_lig, True)]
+        both = [(p.lig2ctx, p.n_lig, True), (p.phore2ctx, p.n_phore, False)]
+        h, x, hb = w.h, w.x, w.hb
+        self._call(prog, lib.pg_embed_ctx, t, w.in_h_node.data_ptr(), w.in_pos.data_ptr(), w.in_t.data_ptr(),
+                   pk.W_node_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), w.hp_emb.data_ptr(),
+                   w.pos_phore.data_ptr(), p.phore2ctx.data_ptr(), h[0].data_ptr(), x[0].data_ptr())
+        self._call(prog, lib.pg_embed_bond, t, w.in_h_edge.data_ptr(), p.bond_graph.data_ptr(), w.in_t.data_ptr(),
+                   pk.W_edge_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), hb[0].data_ptr())
+        self._denoiser_program(prog, lig, both)
+        cur = self.final_idx
+        # heads (diffusion.py:221-241)
+        W0, b0, W2, b2 = pk.v0
+        self._gemm(prog, h[cur], 128, W0, w.head, n, 128, bias=b0, act=hip.ACT_SSP)
+        self._call(prog, lib.pg_rows_linear, w.head.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 12, p.n_lig,
+                   p.lig2ctx.data_ptr(), w.out_v.data_ptr(), 12)
+        W0, b0, W2, b2 = pk.b0
+        self._gemm(prog, hb[cur], 128, W0, w.head_b, E, 128, bias=b0, act=hip.ACT_SSP)
+        self._call(prog, lib.pg_rows_linear, w.head_b.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 6, E, None,
+                   w.out_bond.data_ptr(), 6)
+        return prog
+
+    def _denoiser_program(self, prog, lig, both):
+        """uni_denoiser.py:396-430: knn graph + gate once, then the layers.  State starts in slot 0."""
+        w, p, pk, lib = self.ws, self.plan, self.pack, self.lib
+        n, E, t = p.n_ctx, p.n_bond, p.topo_ref
+        h, x, hb = w.h, w.x, w.hb
+        g = pk.gate
+        self._call(prog, lib.pg_knn_ctx, t, x[0].data_ptr(), self.k, w.nbr.data_ptr(), w.deg.data_ptr())
+        self._call(prog, lib.pg_edge_gate, t, x[0].data_ptr(), w.nbr.data_ptr(), w.deg.data_ptr(), self.k,
+                   g['W0'].data_ptr(), g['b0'].data_ptr(), g['g'].data_ptr(), g['b'].data_ptr(), g['W3'].data_ptr(),
+                   C.c_float(g['b3']), w.ew.data_ptr())
+        cur = 0
+        self._mark(prog, 'graph', w.nbr, w.deg, w.ew)
+        for li, L in enumerate(pk.layers):
+            nxt = 1 - cur
+            hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
+            self._call(prog, lib.pg_lig_normals, t, xc.data_ptr(), w.phore_norm.data_ptr(), p.phore2ctx.data_ptr(),
+                       w.nrm.data_ptr())
+            self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
+            self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
+            # ---- node update over knn edges (:281)
+            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE)
+            # ---- node update over bond edges (:284)
+            self._gemm(prog, hbc, 128, L.NB.W_hb, w.CsB, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB)
+            # ---- bond update over triplets (:285)
+            self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
+                       add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
+                       add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)
+            self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
+            self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
+                       scale=HEAD_SCALE)
+            a = L.TB
+            self._seg(prog, hip.SEG_TRIPLET, E, None, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
+                      ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
+                      W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn)
+            # ---- h' = h + lin_node(aggE + aggB) (:288)
+            self._gemm(prog, w.aggE, 128, L.W_lin2, hn, n, 128, bias=L.b_lin, X2=w.aggB, K2=128, add1=hc)
+            # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
+            self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
+            self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe)
+            self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB)
+            self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
+            self._mark(prog, f'L{li}', hn, hbn, xn, w.aggE, w.aggB, w.dxe, w.dxb, w.nrm, hbc)
+            cur = nxt
+        self.final_idx = cur
+
+    def _run(self, prog):
+        s = hip.stream_ptr()
+        for fn, args in prog:
+            rc = fn(*args, s)
+            if rc:
+                hip.check(rc, fn.__name__)
+
+    def forward(self, h_node_pert, pos_pert, h_edge_pert, time_step):
+        """Returns (logits_v [N_lig,12], x0 [N_lig,3], logits_bond [E,6]) as views of the workspace."""
+        w = self.ws
+        w.in_h_node.copy_(h_node_pert)
+        w.in_pos.copy_(pos_pert)
+        w.in_h_edge.copy_(h_edge_pert)
+        w.in_t.copy_(time_step)
+        return self.forward_inplace()
+
+    def forward_inplace(self):
+        w = self.ws
+        self._run(self.prog_fwd)
+        x0 = torch.index_select(w.x[self.final_idx], 0, self.plan.lig2ctx_long)
+        return w.out_v, x0, w.out_bond
+
+
+def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, batch, phore_norm, return_all):
+    """Entry used by models.uni_denoiser.UniTransformerO2TwoUpdateGeneralBond.forward (ctx-ordered inputs)."""
+    from .plan import BatchPlan
+    dev = h.device
+    if dev.type != 'cuda':
+        raise RuntimeError('phoregen_amd: the denoiser runs on the MI355X HIP path only (no CPU fallback)')
+    mask = mask_ligand.bool()
+    B = int(batch.max().item()) + 1
+    lig_ctx = mask.nonzero().squeeze(-1)
+    ph_ctx = (~mask).nonzero().squeeze(-1)
+    ctx2lig = torch.full((h.size(0),), -1, dtype=torch.long, device=dev)
+    ctx2lig[lig_ctx] = torch.arange(lig_ctx.numel(), device=dev)
+    edge_index = ctx2lig[bond_index]
+    plan = BatchPlan(batch[lig_ctx], batch[ph_ctx], edge_index, batch[lig_ctx][edge_index[0]], B, dev)
+    if not torch.equal(plan.lig2ctx_long, lig_ctx):
+        raise ValueError('phoregen_amd: context must be ordered [phore..., ligand...] per graph (compose_context)')
+    sd = {'denoiser.' + k: v for k, v in module.state_dict().items()}
+    eng = Engine(_DenoiserOnlyPack(sd, module.num_layers), plan, knn_k=module.k, full=False)
+    w = eng.ws
+    w.h[0].copy_(h)
+    w.x[0].copy_(x)
+    w.hb[0].copy_(h_bond)
+    w.phore_norm.copy_(phore_norm)
+    prog = []
+    eng._denoiser_program(prog, [(plan.lig2ctx, plan.n_lig, True)],
+                          [(plan.lig2ctx, plan.n_lig, True), (plan.phore2ctx, plan.n_phore, False)])
+    eng._run(prog)
+    c = eng.final_idx
+    out = {'x': w.x[c].clone(), 'h': w.h[c].clone(), 'h_bond': w.hb[c].clone()}
+    if return_all:
+        out.update(all_x=[x, out['x']], all_h=[h, out['h']], all_h_bond=[h_bond, out['h_bond']])
+    return out
+
+
+class _DenoiserOnlyPack(ModelPack):
+    def __init__(self, sd, num_layers):
+        from .packing import LayerPack, _mlp
+        sd = {k: v.detach() for k, v in sd.items()}
+        self.layers = [LayerPack(sd, f'denoiser.base_block.{l}') for l in range(num_layers)]
+        g = _mlp(sd, 'denoiser.edge_pred_layer')
+        self.gate = dict(W0=g['W1'].contiguous(), b0=g['b1'].contiguous(), g=g['g'], b=g['b'],
+                         W3=g['W2'].reshape(-1).contiguous(), b3=float(g['b2'].reshape(-1)[0]))

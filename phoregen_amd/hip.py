@@ -1,0 +1,125 @@
+"""ctypes binding of libphoregen_hip.so (the C ABI declared in include/phoregen_hip.h).
+
+There is NO fallback: if the library is missing or no GPU is visible the product path raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lib', 'libphoregen_hip.so')
+
+c_fp = C.c_void_p
+c_ip = C.c_void_p
+
+
+class PgGemm(C.Structure):
+    _fields_ = [('X', c_fp), ('ldx', C.c_int), ('K1', C.c_int),
+                ('X2', c_fp), ('ldx2', C.c_int), ('K2', C.c_int),
+                ('W', c_fp), ('ldw', C.c_int),
+                ('bias', c_fp),
+                ('ln_gamma', c_fp), ('ln_beta', c_fp),
+                ('add1', c_fp), ('ld_add1', C.c_int), ('idx1', c_ip),
+                ('add2', c_fp), ('ld_add2', C.c_int), ('idx2', c_ip),
+                ('out_scale', C.c_float), ('act', C.c_int),
+                ('Y', c_fp), ('ldy', C.c_int), ('M', C.c_int), ('N', C.c_int)]
+
+
+class PgTopo(C.Structure):
+    _fields_ = [('n_graphs', C.c_int), ('n_ctx', C.c_int), ('n_lig', C.c_int), ('n_phore', C.c_int),
+                ('n_bond', C.c_int),
+                ('g_ctx_off', c_ip), ('g_nph', c_ip), ('g_nlig', c_ip), ('g_eid_off', c_ip), ('eid', c_ip),
+                ('ctx_graph', c_ip), ('ctx_is_lig', c_ip), ('lig2ctx', c_ip), ('bond_src', c_ip),
+                ('bond_dst', c_ip)]
+
+
+class PgSegAttn(C.Structure):
+    _fields_ = [('mode', C.c_int), ('n_seg', C.c_int), ('seg_ids', c_ip),
+                ('x', c_fp), ('nrm', c_fp), ('nbr', c_ip), ('deg', c_ip), ('ew', c_fp), ('knn_k', C.c_int),
+                ('Csrc_k', c_fp), ('Csrc_v', c_fp), ('ld_csrc', C.c_int),
+                ('Cdst_k', c_fp), ('Cdst_v', c_fp), ('ld_cdst', C.c_int),
+                ('Wf_k', c_fp), ('Wf_v', c_fp), ('Wg2_k', c_fp), ('Wg2_v', c_fp), ('G', c_fp),
+                ('ln_gk', c_fp), ('ln_bk', c_fp), ('ln_gv', c_fp), ('ln_bv', c_fp),
+                ('U', c_fp), ('q', c_fp), ('W2k_l', c_fp), ('W2v_l', c_fp), ('b2v', c_fp),
+                ('W2xv_l', c_fp), ('b2xv', c_fp),
+                ('S', c_fp), ('swn', c_fp), ('resid', c_fp), ('out', c_fp), ('dx', c_fp),
+                ('accumulate_dx', C.c_int)]
+
+
+SEG_KNN_NODE, SEG_KNN_POS, SEG_BOND_NODE, SEG_BOND_POS, SEG_TRIPLET, SEG_PHORE = range(6)
+ACT_NONE, ACT_SSP, ACT_RELU = 0, 1, 2
+
+_lib = None
+
+_PROTOS = {
+    'pg_last_error': (C.c_char_p, []),
+    'pg_abi_version': (C.c_int, []),
+    'pg_selftest_mfma': (C.c_int, [c_ip, C.c_void_p]),
+    'pg_gemm': (C.c_int, [C.POINTER(PgGemm), C.c_void_p]),
+    'pg_embed_ctx': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 10 + [C.c_void_p]),
+    'pg_embed_bond': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 7 + [C.c_void_p]),
+    'pg_knn_ctx': (C.c_int, [C.POINTER(PgTopo), c_fp, C.c_int, c_ip, c_ip, C.c_void_p]),
+    'pg_lig_normals': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_ip, c_fp, C.c_void_p]),
+    'pg_edge_gate': (C.c_int, [C.POINTER(PgTopo), c_fp, c_ip, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
+                               C.c_float, c_fp, C.c_void_p]),
+    'pg_bond_smear': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, C.c_void_p]),
+    'pg_seg_attn': (C.c_int, [C.POINTER(PgTopo), C.POINTER(PgSegAttn), C.c_void_p]),
+    'pg_attn_fold_query': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_ip, c_fp, C.c_void_p]),
+    'pg_attn_unfold_value': (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, C.c_int, C.c_void_p]),
+    'pg_apply_dx': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
+    'pg_rows_linear': (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_ip, c_fp, C.c_int,
+                                 C.c_void_p]),
+    'pg_atom_count': (C.c_int, [c_fp, c_fp, c_ip, c_ip, C.c_int, C.c_int, c_fp, c_fp, C.c_void_p]),
+    'pg_posterior_categorical': (C.c_int, [c_fp, c_fp, c_ip, c_ip, c_fp, c_fp, C.c_int, C.c_int, c_fp,
+                                           C.c_uint64, C.c_uint32, C.c_uint32, c_fp, c_fp, c_fp, C.c_void_p]),
+    'pg_posterior_position': (C.c_int, [c_fp, c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_uint64,
+                                        C.c_uint32, C.c_uint32, C.c_int, c_fp, c_fp, c_fp, C.c_void_p]),
+    'pg_guidance_grad': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_ip, c_ip, C.c_int, C.c_float, C.c_float,
+                                   C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+def load_library(path=None):
+    """Load the shared library and declare every prototype (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f'phoregen_amd: HIP extension not built: {path} is missing. '
+                           f'Run `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
+                           f'There is no CPU fallback.')
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def lib():
+    """The library, for compute calls: additionally requires a visible GPU."""
+    l = load_library()
+    if not torch.cuda.is_available():
+        raise RuntimeError('phoregen_amd: no MI355X / ROCm device visible; the HIP path has no CPU fallback.')
+    return l
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load_library().pg_last_error().decode()
+        raise RuntimeError(f'phoregen_hip {what} failed ({rc}): {msg}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

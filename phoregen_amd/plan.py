@@ -1,0 +1,117 @@
+"""Batch topology ("plan") of one ligand-pharmacophore batch, constant over the 1000 denoise steps.
+
+Host-side mirror of what the reference recomputes every step: compose_context's stable sort
+(models/common.py:180-208), the bond index remap (models/diffusion.py:201) and the triplet
+enumeration (models/uni_denoiser.py:101-121, here an n x n edge-id table per ligand).
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+
+class BatchPlan:
+    def __init__(self, batch_node, batch_phore, edge_index, batch_edge, n_graphs, device):
+        """batch_node [N_lig], batch_phore [N_ph] (graph id per ligand atom / phore node, ascending),
+        edge_index [2,E] ligand-local atom ids (fully connected directed ligand graphs), batch_edge [E]."""
+        bn, bp = batch_node.detach().cpu().long(), batch_phore.detach().cpu().long()
+        ei, be = edge_index.detach().cpu().long(), batch_edge.detach().cpu().long()
+        B = int(n_graphs)
+        if bn.numel() and (bn[1:] < bn[:-1]).any() or bp.numel() and (bp[1:] < bp[:-1]).any():
+            raise ValueError('phoregen_amd: batch vectors must be sorted by graph id')
+        nlig = torch.bincount(bn, minlength=B)
+        nph = torch.bincount(bp, minlength=B)
+        self.n_graphs, self.n_lig, self.n_phore, self.n_bond = B, int(bn.numel()), int(bp.numel()), int(ei.size(1))
+        self.n_ctx = self.n_lig + self.n_phore
+        if int((nlig * (nlig - 1)).sum()) != self.n_bond:
+            raise ValueError('phoregen_amd: the bond graph must be the fully connected directed ligand graph '
+                             '(utils/sample_utils.py:40-54 / datasets/transform.py:488-501)')
+        tot = nlig + nph
+        g_ctx_off = torch.zeros(B + 1, dtype=torch.long)
+        g_ctx_off[1:] = tot.cumsum(0)
+        lig_off = torch.zeros(B + 1, dtype=torch.long)
+        lig_off[1:] = nlig.cumsum(0)
+        ph_off = torch.zeros(B + 1, dtype=torch.long)
+        ph_off[1:] = nph.cumsum(0)
+        a = torch.arange(self.n_lig)
+        lig2ctx = g_ctx_off[bn] + nph[bn] + (a - lig_off[bn])
+        p = torch.arange(self.n_phore)
+        phore2ctx = g_ctx_off[bp] + (p - ph_off[bp])
+        ctx_graph = torch.empty(self.n_ctx, dtype=torch.long)
+        ctx_graph[lig2ctx] = bn
+        ctx_graph[phore2ctx] = bp
+        is_lig = torch.zeros(self.n_ctx, dtype=torch.uint8)
+        is_lig[lig2ctx] = 1
+        g_eid_off = torch.zeros(B + 1, dtype=torch.long)
+        g_eid_off[1:] = (nlig * nlig).cumsum(0)
+        eid = torch.full((int(g_eid_off[-1]),), -1, dtype=torch.long)
+        ls, ld = ei[0] - lig_off[be], ei[1] - lig_off[be]
+        if self.n_bond and ((ls < 0).any() or (ld < 0).any() or (ls >= nlig[be]).any() or (ld >= nlig[be]).any()
+                            or (bn[ei[0]] != be).any()):
+            raise ValueError('phoregen_amd: edge_index / batch_edge inconsistent with batch_node')
+        eid[g_eid_off[be] + ls * nlig[be] + ld] = torch.arange(self.n_bond)
+        if int((eid >= 0).sum()) != self.n_bond:
+            raise ValueError('phoregen_amd: duplicate bond edges')
+
+        self.device = device
+        i32 = lambda t: t.to(torch.int32).to(device)
+        self.num_atoms = nlig
+        self.g_ctx_off, self.g_nph, self.g_nlig, self.g_eid_off = i32(g_ctx_off), i32(nph), i32(nlig), i32(g_eid_off)
+        self.eid, self.ctx_graph, self.ctx_is_lig = i32(eid), i32(ctx_graph), is_lig.to(device)
+        self.lig2ctx, self.phore2ctx = i32(lig2ctx), i32(phore2ctx)
+        self.lig2ctx_long = lig2ctx.to(device)
+        self.phore2ctx_long = phore2ctx.to(device)
+        self.bond_src, self.bond_dst = i32(lig2ctx[ei[0]]), i32(lig2ctx[ei[1]])
+        self.bond_graph, self.lig_graph, self.phore_graph = i32(be), i32(bn), i32(bp)
+        self.g_lig_off = i32(lig_off)
+        self.batch_node, self.batch_edge, self.edge_index = bn.to(device), be.to(device), ei.to(device)
+
+        t = hip.PgTopo()
+        t.n_graphs, t.n_ctx, t.n_lig, t.n_phore, t.n_bond = B, self.n_ctx, self.n_lig, self.n_phore, self.n_bond
+        for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
+                     'bond_src', 'bond_dst'):
+            setattr(t, name, getattr(self, name).data_ptr())
+        self.topo = t
+        self.topo_ref = C.byref(t)
+        self.key = (bn.numel(), bp.numel(), ei.size(1), B)
+        self._cpu_sig = (bn, bp, ei)
+        self.ws = None   # engine workspace, attached lazily
+
+    def matches(self, batch_node, batch_phore, edge_index):
+        bn, bp, ei = self._cpu_sig
+        return (batch_node.numel() == bn.numel() and batch_phore.numel() == bp.numel() and
+                edge_index.shape == ei.shape and torch.equal(batch_node.cpu(), bn) and
+                torch.equal(batch_phore.cpu(), bp) and torch.equal(edge_index.cpu(), ei))
+
+
+def make_edge_data(num_atoms, device=None):
+    """Fully connected directed bond edges in the sampler's order: per graph all (a<b) pairs, then all
+    reversed pairs (same contract as utils/sample_utils.py:40-54), built without a per-graph Python loop."""
+    num_atoms = num_atoms.detach().cpu().long()
+    device = device if device is not None else num_atoms.device
+    B = num_atoms.numel()
+    off = torch.zeros(B + 1, dtype=torch.long)
+    off[1:] = num_atoms.cumsum(0)
+    nmax = int(num_atoms.max()) if B else 0
+    iu = torch.triu_indices(nmax, nmax, offset=1)                    # row-major (a<b) pairs of the largest graph
+    srcs, dsts, bats = [], [], []
+    # pairs of a graph with n atoms are exactly the (a<b) pairs of the nmax table with b < n, in the same order
+    keep = iu[1][None, :] < num_atoms[:, None]                       # [B, P]
+    g_idx, p_idx = keep.nonzero(as_tuple=True)
+    a = iu[0][p_idx] + off[g_idx]
+    b = iu[1][p_idx] + off[g_idx]
+    half_cnt = keep.sum(1)
+    # per graph: [half pairs..., reversed half pairs...]
+    pos_in_g = torch.arange(g_idx.numel()) - torch.repeat_interleave(half_cnt.cumsum(0) - half_cnt, half_cnt)
+    e_off = torch.zeros(B + 1, dtype=torch.long)
+    e_off[1:] = (2 * half_cnt).cumsum(0)
+    E = int(e_off[-1])
+    src = torch.empty(E, dtype=torch.long)
+    dst = torch.empty(E, dtype=torch.long)
+    i1 = e_off[g_idx] + pos_in_g
+    i2 = i1 + half_cnt[g_idx]
+    src[i1], dst[i1] = a, b
+    src[i2], dst[i2] = b, a
+    batch = torch.repeat_interleave(torch.arange(B), 2 * half_cnt)
+    return torch.stack([src, dst]).to(device), batch.to(device)

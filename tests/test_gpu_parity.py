@@ -1,0 +1,238 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle and the committed reference goldens.
+
+Tolerances: forward tensors max-abs error <= 2e-5 x max-abs(reference) (fp32 re-association:
+the kernels factor the first MLP layers and fold the second key/value layers); discrete types
+bit-exact; trajectory RMSD <= 1e-4."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, make_oracle, oracle_state_dict, rel_err, t
+from oracle import phoregen_oracle as po
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def model():
+    from phoregen_amd.config import default_model_config
+    from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.weights import init_deterministic_
+    m = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to(DEV)
+    return m
+
+
+@pytest.fixture(scope='module')
+def oracle():
+    torch.set_num_threads(8)
+    return make_oracle(0)
+
+
+def test_mfma_lane_maps():
+    from phoregen_amd import hip
+    lib = hip.lib()
+    res = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+    hip.check(lib.pg_selftest_mfma(res.data_ptr(), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert int(res.item()) == 0
+
+
+@pytest.mark.parametrize('M,N,K1,K2', [(300, 128, 128, 0), (1000, 256, 128, 20), (77, 1920, 128, 0), (130, 12, 18, 0),
+                                         (513, 128, 128, 128)])
+def test_gemm_against_torch(M, N, K1, K2):
+    from phoregen_amd import hip
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(M + N)
+    X, W, b = torch.randn(M, K1, generator=g), torch.randn(N, K1 + K2, generator=g) * 0.1, torch.randn(N, generator=g)
+    X2 = torch.randn(M, max(K2, 1), generator=g)
+    A1, A2 = torch.randn(50, N, generator=g), torch.randn(M, N, generator=g)
+    i1 = torch.randint(0, 50, (M,), generator=g, dtype=torch.int32)
+    ref = torch.cat([X, X2[:, :K2]], 1).double() @ W.double().t() + b.double() + A1.double()[i1.long()] + A2.double()
+    ref = 0.5 * (torch.nn.functional.softplus(ref) - np.log(2.0))
+    Xd, Wd, bd, X2d, A1d, A2d, i1d = (v.to(DEV) for v in (X, W, b, X2, A1, A2, i1))
+    Y = torch.empty(M, N, device=DEV)
+    p = hip.PgGemm()
+    p.X, p.ldx, p.K1 = Xd.data_ptr(), K1, K1
+    p.X2, p.ldx2, p.K2 = (X2d.data_ptr(), X2d.stride(0), K2) if K2 else (None, 0, 0)
+    p.W, p.ldw, p.bias = Wd.data_ptr(), K1 + K2, bd.data_ptr()
+    p.add1, p.ld_add1, p.idx1 = A1d.data_ptr(), N, i1d.data_ptr()
+    p.add2, p.ld_add2, p.idx2 = A2d.data_ptr(), N, None
+    p.out_scale, p.act = 0.5, hip.ACT_SSP
+    p.Y, p.ldy, p.M, p.N = Y.data_ptr(), N, M, N
+    hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
+    assert rel_err(Y.cpu(), ref) < 1e-5
+    # LayerNorm+ReLU on load
+    if K2 == 0 and K1 == 128:
+        gam, bet = torch.randn(128, generator=g), torch.randn(128, generator=g)
+        ref = torch.relu(torch.nn.functional.layer_norm(X.double(), (128,), gam.double(), bet.double())) @ W.double().t()
+        p.add1 = p.add2 = p.bias = None
+        p.act, p.out_scale = hip.ACT_NONE, 1.0
+        gd, bd2 = gam.to(DEV), bet.to(DEV)
+        p.ln_gamma, p.ln_beta = gd.data_ptr(), bd2.data_ptr()
+        hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
+        assert rel_err(Y.cpu(), ref) < 1e-5
+
+
+def _fwd_inputs(g):
+    return {k[3:]: t(g[k]) for k in g.files if k.startswith('in_')}
+
+
+@pytest.mark.parametrize('name', ['g3_forward_a', 'g3_forward_b'])
+def test_forward_against_reference_golden(model, name):
+    g = golden(name)
+    inp = {k: v.to(DEV) for k, v in _fwd_inputs(g).items()}
+    with torch.no_grad():
+        model(**inp)                                      # builds plan + engine
+        eng = model._engine
+        eng.debug = {}
+        v, x0, bond, (cl, cu) = model(**inp)
+        dbg, eng.debug = eng.debug, None
+    torch.cuda.synchronize()
+    plan = eng.plan
+    lig, ph = plan.lig2ctx_long.cpu(), plan.phore2ctx_long.cpu()
+    # knn graph: same neighbour sets in the same (distance) order as the reference's edge list
+    nbr, deg, ew = (a.cpu() for a in dbg['graph'])
+    ref_ei = g['L0_in_edge_index']
+    mine_src = torch.cat([nbr[i, :deg[i]] for i in range(nbr.size(0))]).numpy()
+    mine_dst = torch.repeat_interleave(torch.arange(nbr.size(0)), deg.long()).numpy()
+    assert np.array_equal(mine_src, ref_ei[0]) and np.array_equal(mine_dst, ref_ei[1])
+    ew_flat = torch.cat([ew[i, :deg[i]] for i in range(nbr.size(0))])
+    errs = {'e_w': rel_err(ew_flat, g['L0_in_e_w'][:, 0]), 'phore_enc': rel_err(eng.ws.hp_emb.cpu(), g['phore_enc'])}
+    hn, hbn, xn, aggE, aggB, dxe, dxb, nrm, hbc = (a.cpu() for a in dbg['L0'])
+    errs.update(L0_node_edge=rel_err(aggE, g['L0_node_edge']), L0_node_bond=rel_err(aggB, g['L0_node_bond']),
+                L0_bond_upd=rel_err(hbn - hbc, g['L0_bond_upd']),
+                L0_pos_edge=rel_err(dxe[lig], g['L0_pos_edge'][lig.numpy()]),
+                L0_pos_bond=rel_err(dxb[lig], g['L0_pos_bond'][lig.numpy()]),
+                L0_h=rel_err(hn, g['L0_out_h']), L0_hb=rel_err(hbn, g['L0_out_h_bond']), L0_x=rel_err(xn, g['L0_out_x']))
+    h5, hb5, x5 = (a.cpu() for a in dbg['L5'][:3])
+    errs.update(L5_h=rel_err(h5, g['L5_out_h']), L5_hb=rel_err(hb5, g['L5_out_h_bond']), L5_x=rel_err(x5, g['L5_out_x']),
+                v=rel_err(v.cpu(), g['out_v']), x0=rel_err(x0.cpu(), g['out_x0']), bond=rel_err(bond.cpu(), g['out_bond']),
+                cl=rel_err(cl.cpu(), g['out_count_l']), cu=rel_err(cu.cpu(), g['out_count_u']))
+    print(name, {k: f'{v:.2e}' for k, v in errs.items()})
+    assert max(errs.values()) <= TOL, errs
+
+
+def test_forward_against_oracle_larger_graphs(model, oracle):
+    """Sizes the goldens do not cover: > 32 atoms (3+ row tiles), tiny graphs (degree < 32), n = 2 (empty triplet segments)."""
+    from oracle.make_inputs import synthetic_batch
+    inp = synthetic_batch(7, [41, 2, 33, 17], [60, 9, 130, 25], [999, 0, 500, 250])
+    with torch.no_grad():
+        ref = oracle.forward(**inp)
+        out = model(**{k: v.to(DEV) for k, v in inp.items()})
+    errs = dict(v=rel_err(out[0].cpu(), ref[0]), x0=rel_err(out[1].cpu(), ref[1]), bond=rel_err(out[2].cpu(), ref[2]),
+                cl=rel_err(out[3][0].cpu(), ref[3][0]), cu=rel_err(out[3][1].cpu(), ref[3][1]))
+    print(errs)
+    assert max(errs.values()) <= TOL, errs
+
+
+def test_posterior_kats(model):
+    from phoregen_amd import hip
+    lib, pk = hip.lib(), model.packed()
+    g = golden('g_posterior')
+    rg = t(g['batch']).to(torch.int32).to(DEV)
+    tt = t(g['t']).to(DEV)
+    for tag, tab, K in (('node', pk.node_tab, 12), ('edge', pk.edge_tab, 6)):
+        # the kernel takes raw logits and applies log_softmax; log-probabilities are a fixed point of log_softmax
+        lv0, lvt, u = (t(g[f'{tag}_{n}']).to(DEV).contiguous() for n in ('log_v0', 'log_vt', 'u'))
+        out, oh = torch.empty_like(lv0), torch.empty_like(lv0)
+        hip.check(lib.pg_posterior_categorical(lv0.data_ptr(), lvt.data_ptr(), rg.data_ptr(), tt.data_ptr(),
+                                               tab[0].data_ptr(), tab[1].data_ptr(), lv0.size(0), K, u.data_ptr(), 0, 0, 0,
+                                               out.data_ptr(), oh.data_ptr(), None, hip.stream_ptr()))
+        assert np.allclose(out.cpu().numpy(), g[f'{tag}_post'], rtol=0, atol=2e-6)
+        assert np.array_equal(oh.argmax(-1).cpu().numpy(), g[f'{tag}_sample'])
+    xt, x0, eps = (t(g[n]).to(DEV).contiguous() for n in ('pos_xt', 'pos_x0', 'pos_eps'))
+    prev = torch.empty_like(xt)
+    hip.check(lib.pg_posterior_position(xt.data_ptr(), x0.data_ptr(), rg.data_ptr(), tt.data_ptr(), pk.pos_tab[0].data_ptr(),
+                                        pk.pos_tab[1].data_ptr(), pk.pos_tab[2].data_ptr(), None, eps.data_ptr(), 0, 0, 0,
+                                        xt.size(0), None, prev.data_ptr(), None, hip.stream_ptr()))
+    assert np.allclose(prev.cpu().numpy(), g['pos_prev'], rtol=0, atol=1e-6)
+
+
+def _tape(g):
+    return [g[k] for k in sorted(k for k in g.files if k.startswith('rng'))][1:]
+
+
+class _ReplayCpuRng:
+    """Patches torch.rand/randn so the sampler's rng='cpu' path replays the reference's recorded draws."""
+
+    def __init__(self, draws):
+        self.draws, self.i = draws, 0
+
+    def __enter__(self):
+        self._rand, self._randn = torch.rand, torch.randn
+
+        def nxt(*shape, **kw):
+            shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (list, tuple)) else tuple(shape)
+            if self.i >= len(self.draws):                       # head fixtures stop early
+                return torch.zeros(shape, dtype=kw.get('dtype', torch.float32))
+            a = torch.as_tensor(self.draws[self.i])
+            self.i += 1
+            assert tuple(a.shape) == shape and a.dtype == kw.get('dtype', torch.float32), (a.shape, shape, a.dtype)
+            return a
+        torch.rand = torch.randn = nxt
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn = self._rand, self._randn
+
+
+@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3'])
+def test_sampler_against_reference_trajectories(model, name):
+    from phoregen_amd.data import PhoreGraph
+    g = golden(name)
+    data = PhoreGraph(t(g['phore_x']), t(g['phore_pos']), t(g['phore_norm']), t(g['center'])).to(DEV)
+    t_total = int(g['t_total'])
+    n_rec = sum(1 for k in g.files if k.endswith('_out_v'))
+    guid = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}] if 'guid' in name else None
+    recs = []
+
+    def on_step(i, step, v, x0, bond):
+        w = model._engine.ws
+        recs.append((v.cpu().clone(), x0.cpu().clone(), bond.cpu().clone()))
+
+    states = []
+    old_T = model.num_timesteps
+    try:
+        if t_total != 1000:
+            model.num_timesteps = t_total
+        with _ReplayCpuRng(_tape(g)):
+            res = model.sample(data, len(g['n_atoms']), DEV, pos_guidance_opt=guid, rng='cpu',
+                               num_atoms=t(g['n_atoms']), num_steps=n_rec if t_total == 1000 else None, on_step=on_step)
+    finally:
+        model.num_timesteps = old_T
+    torch.cuda.synchronize()
+    traj_n, traj_p, traj_e = (a.cpu() for a in res['traj'])
+    for s in range(n_rec):
+        # state fed to step s == traj[s] (positions without the centre, which the traj adds from step 1 on)
+        assert np.array_equal(traj_n[s].numpy(), g[f's{s}_h_node']), (name, s)
+        assert np.array_equal(traj_e[s].argmax(-1).numpy(), g[f's{s}_h_edge']), (name, s)
+        pos_in = traj_p[s] - (t(g['center']) if s > 0 else 0)
+        assert rel_err(pos_in, g[f's{s}_pos']) <= 5 * TOL, (name, s)
+        v, x0, bond = recs[s]
+        assert max(rel_err(v, g[f's{s}_out_v']), rel_err(x0, g[f's{s}_out_x0']), rel_err(bond, g[f's{s}_out_bond'])) <= 10 * TOL, (name, s)
+    if 'traj_node' in g.files:
+        assert np.array_equal(traj_n.argmax(-1).numpy(), g['traj_node'])
+        assert np.array_equal(traj_e.argmax(-1).numpy(), g['traj_edge'])
+        rmsd = float(np.sqrt(((traj_p.numpy() - g['traj_pos']) ** 2).sum(-1).mean()))
+        assert rmsd <= 1e-4, rmsd
+        assert rel_err(res['pred'][1].cpu(), g['pred_pos']) <= 10 * TOL
+        assert np.array_equal(res['lig_info'][2].cpu().numpy(), g['lig_edge_index'])
+
+
+def test_device_rng_sampler_runs_and_is_reproducible(model):
+    from oracle.make_inputs import synthetic_phore
+    gen = torch.Generator().manual_seed(5)
+    hp, pp, pn = synthetic_phore(gen, 30)
+    na = torch.tensor([9, 12, 7])
+    bp = torch.repeat_interleave(torch.arange(3), 30)
+    args = (hp.repeat(3, 1), pp.repeat(3, 1), pn.repeat(3, 1), bp, na, torch.zeros(3, 3))
+    a = model.sample_batch(*args, rng='device', seed=11, num_steps=6)
+    b = model.sample_batch(*args, rng='device', seed=11, num_steps=6)
+    c = model.sample_batch(*args, rng='device', seed=12, num_steps=6)
+    assert torch.equal(a['traj'][0], b['traj'][0]) and torch.equal(a['traj'][1], b['traj'][1])
+    assert not torch.equal(a['traj'][1], c['traj'][1])
+    assert torch.isfinite(a['pred'][1]).all() and a['traj'][0].sum(-1).eq(1).all()

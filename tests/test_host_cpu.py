@@ -1,0 +1,158 @@
+"""CPU-side checks of the host mirror: state_dict schema, tables, packing layouts, C-ABI exports, plan."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, golden, manifest, oracle_state_dict
+from oracle import phoregen_oracle as po
+from phoregen_amd import hip, packing
+from phoregen_amd.config import default_model_config
+from phoregen_amd.models.diffusion import PhoreDiff
+from phoregen_amd.plan import BatchPlan, make_edge_data
+from phoregen_amd.weights import init_deterministic_
+
+
+@pytest.fixture(scope='module')
+def model():
+    return init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval()
+
+
+def test_state_dict_matches_reference_manifest(model):
+    sd = model.state_dict()
+    ref = manifest()
+    assert [k for k, _, _ in ref] == list(sd.keys())                 # same names, same order (641 entries)
+    for k, shape, dt in ref:
+        assert tuple(sd[k].shape) == shape and str(sd[k].dtype).replace('torch.', '') == dt, k
+
+
+def test_tables_and_weights_equal_oracle_state_dict(model):
+    sd, osd = model.state_dict(), oracle_state_dict(0)
+    for k in sd:
+        assert torch.equal(sd[k], osd[k]), k                          # tables bit-exact vs the (golden-pinned) oracle
+
+
+def test_frozen_tables_not_trainable(model):
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    n_all = sum(p.numel() for p in model.parameters())
+    assert (n_all, n_train) == (5568785, 5201785)
+
+
+def test_product_fails_loudly_without_gpu(model):
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model.packed()
+    with pytest.raises(NotImplementedError):
+        model.compute_loss(None)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip.load_library()
+    header = open(os.path.join(ROOT, 'include', 'phoregen_hip.h')).read()
+    declared = set(re.findall(r'\b(pg_[a-z_0-9]+)\s*\(', header))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pg_abi_version() == 1
+    assert isinstance(lib.pg_last_error(), bytes)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'phoregen_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M) or 'root/reference' in src:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_make_edge_data_matches_reference_order():
+    g = golden('g1_ops')
+    ei, eb = make_edge_data(torch.as_tensor(g['med_num_atoms']))
+    assert np.array_equal(ei.numpy(), g['med_edge_index']) and np.array_equal(eb.numpy(), g['med_edge_batch'])
+    na = torch.tensor([1, 7, 2, 12, 3])
+    a, b = make_edge_data(na)
+    c, d = po.make_edge_data(na)
+    assert torch.equal(a, c) and torch.equal(b, d)
+
+
+def test_plan_topology_matches_compose_context():
+    g = golden('g3_forward_b')
+    bn, bp = torch.as_tensor(g['in_batch_node']), torch.as_tensor(g['in_batch_phore'])
+    ei, be = torch.as_tensor(g['in_edge_index']), torch.as_tensor(g['in_batch_edge'])
+    plan = BatchPlan(bn, bp, ei, be, 3, torch.device('cpu'))
+    assert np.array_equal(plan.ctx_is_lig.numpy().astype(bool), g['L0_in_mask_ligand'])
+    assert np.array_equal(plan.ctx_graph.numpy(), g['L0_in_batch'])
+    assert np.array_equal(torch.stack([plan.bond_src, plan.bond_dst]).numpy(), g['L0_in_bond_index'])
+    # edge-id table enumerates exactly the reference triplets (uni_denoiser.py:101-121)
+    i, j, k, kj, ji = po.triplets(torch.as_tensor(g['L0_in_bond_index']), plan.n_ctx)
+    eid, off, nl = plan.eid.numpy(), plan.g_eid_off.numpy(), plan.g_nlig.numpy()
+    lig0 = (plan.g_ctx_off[:-1] + plan.g_nph).numpy()
+    gr = plan.ctx_graph.numpy()
+    mine = []
+    for e in range(plan.n_bond):
+        cj, ci = int(plan.bond_src[e]), int(plan.bond_dst[e])
+        gi = gr[cj]
+        n, lj, li = nl[gi], cj - lig0[gi], ci - lig0[gi]
+        for kk in range(n):
+            if kk != lj and kk != li:
+                mine.append((lig0[gi] + kk, eid[off[gi] + kk * n + lj], e))
+    assert mine == list(zip(k.tolist(), kj.tolist(), ji.tolist()))
+    with pytest.raises(ValueError):
+        BatchPlan(bn, bp, ei[:, :-1], be[:-1], 3, torch.device('cpu'))
+
+
+def test_lane_fixed_layouts():
+    W = torch.arange(128 * 128, dtype=torch.float32).view(128, 128)
+    L = packing.lane_fixed_w2(W)
+    assert L.shape == (64, 64, 4)
+    for (i, lane, j) in [(0, 0, 0), (5, 17, 3), (63, 63, 3), (34, 40, 1)]:
+        n, g, h = i * 4 + j, lane >> 4, lane & 15
+        tau, r, d = n >> 5, (n >> 3) & 3, n & 7
+        assert L[i, lane, j] == W[8 * h + d, 16 * tau + 4 * g + r]
+    F = torch.arange(128 * 48, dtype=torch.float32).view(128, 48)
+    LF = packing.lane_fixed_feat(F)
+    assert LF.shape == (12, 8, 64)
+    for (st, tau, lane) in [(0, 0, 0), (11, 7, 63), (4, 2, 37)]:
+        assert LF[st, tau, lane] == F[16 * tau + (lane & 15), 4 * st + (lane >> 4)]
+    X = torch.arange(16 * 128, dtype=torch.float32).view(16, 128)
+    LX = packing.lane_fixed_xv(X)
+    for (i, lane) in [(0, 0), (31, 63), (9, 21)]:
+        assert LX[i, lane] == X[lane & 15, 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3)]
+
+
+def test_factored_first_layer_algebra(model):
+    """packing's column maps: factored pieces re-assemble the reference's concatenated first layer."""
+    sd = {k: v.double() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    p = 'denoiser.base_block.2'
+    # triplet k: [h_bond_kj | smear(d_kj) | smear(d_ji) | ang13 | h_k | h_j]
+    W1, b1 = sd[p + '.bond_layer.hk_func.net.0.weight'], sd[p + '.bond_layer.hk_func.net.0.bias']
+    hb, gkj, gji, hk, hj = (torch.randn(n, generator=g, dtype=torch.float64) for n in (128, 20, 20, 128, 128))
+    th = torch.rand(1, generator=g, dtype=torch.float64) * 3.1
+    ang = po.angular_encoding(th)[0]
+    ref = W1 @ torch.cat([hb, gkj, gji, ang, hk, hj]) + b1
+    f = torch.tensor([1., 2., 3., .5, 1 / 3], dtype=torch.float64)
+    feat = torch.cat([th, torch.sin(th * f), torch.cos(th * f), torch.zeros(1, dtype=torch.float64)])
+    Wf = packing._tri_feat(W1)
+    mine = (W1[:, 0:148] @ torch.cat([hb, gkj]) + W1[:, 181:309] @ hk + (W1[:, 309:437] @ hj + b1)
+            + W1[:, 148:168] @ gji + Wf @ feat)
+    assert torch.allclose(mine, ref, atol=1e-10)
+    # knn k, dst ligand, src phore (type 2)
+    W1, b1 = sd[p + '.node_layer_with_edge.hk_func.net.0.weight'], sd[p + '.node_layer_with_edge.hk_func.net.0.bias']
+    Wd, bd = sd[p + '.dire_embedding.weight'], sd[p + '.dire_embedding.bias']
+    sm, dots, hd, hs = (torch.randn(n, generator=g, dtype=torch.float64) for n in (20, 3, 128, 128))
+    et = torch.zeros(4, dtype=torch.float64)
+    et[2] = 1
+    e = torch.cat([(et[:, None] * sm[None]).reshape(-1), et, Wd @ dots + bd])
+    ref = W1 @ torch.cat([e, hd, hs]) + b1
+    Wfe = packing._knn_feat(W1, W1[:, 84:93] @ Wd, True)
+    feat = torch.cat([torch.zeros(20, dtype=torch.float64), sm, dots, torch.tensor([0., 1., 0., 0., 0.], dtype=torch.float64)])
+    mine = Wfe @ feat + W1[:, 93:221] @ hd + b1 + W1[:, 84:93] @ bd + W1[:, 221:349] @ hs
+    assert torch.allclose(mine, ref, atol=1e-10)
