@@ -31,6 +31,7 @@ class Engine:
         self.dev = plan.device
         self._keep = []          # ctypes structs / tensors referenced by raw pointer
         self.debug = None
+        self.timers = None
         self._alloc()
         if full:
             self.prog_phore = self._build_phore_program()
@@ -72,7 +73,24 @@ class Engine:
 
     # ------------------------------------------------------------------ call builders
     def _call(self, prog, fn, *args):
+        assert len(args) + 1 == len(fn.argtypes), (fn.__name__, len(args) + 1, len(fn.argtypes))
         prog.append((fn, args))
+
+    def _event(self, prog, name, start):
+        """Timing tap: when `self.timers` is a dict, record a HIP event on the launch stream around a kernel."""
+        def tap(_stream):
+            if self.timers is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self.timers.setdefault(name, []).append((start, ev))
+            return 0
+        tap.__name__ = 'event_' + name
+        prog.append((tap, ()))
+
+    def kernel_ms(self, name):
+        """Per-launch durations (ms) collected since `self.timers = {}`; call after a device synchronize."""
+        evs = self.timers.get(name, [])
+        return [a.elapsed_time(b) for (sa, a), (sb, b) in zip(evs[0::2], evs[1::2]) if sa and not sb]
 
     def _mark(self, prog, name, *tensors):
         """Debug tap: when `self.debug` is a dict, clone the named tensors at this point of the launch list."""
@@ -223,9 +241,11 @@ class Engine:
             self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
                        scale=HEAD_SCALE)
             a = L.TB
+            self._event(prog, 'triplet', True)
             self._seg(prog, hip.SEG_TRIPLET, E, None, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
                       ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
                       W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn)
+            self._event(prog, 'triplet', False)
             # ---- h' = h + lin_node(aggE + aggB) (:288)
             self._gemm(prog, w.aggE, 128, L.W_lin2, hn, n, 128, bias=L.b_lin, X2=w.aggB, K2=128, add1=hc)
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)

@@ -57,7 +57,7 @@ _PROTOS = {
     'pg_abi_version': (C.c_int, []),
     'pg_selftest_mfma': (C.c_int, [c_ip, C.c_void_p]),
     'pg_gemm': (C.c_int, [C.POINTER(PgGemm), C.c_void_p]),
-    'pg_embed_ctx': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 10 + [C.c_void_p]),
+    'pg_embed_ctx': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 11 + [C.c_void_p]),
     'pg_embed_bond': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 7 + [C.c_void_p]),
     'pg_knn_ctx': (C.c_int, [C.POINTER(PgTopo), c_fp, C.c_int, c_ip, c_ip, C.c_void_p]),
     'pg_lig_normals': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_ip, c_fp, C.c_void_p]),

@@ -157,31 +157,48 @@ class PhoreDiff(nn.Module):
                      rng='device', seed=0, return_traj=True, guidance_center=None, num_steps=None, on_step=None):
         """Sampler over a batch of (possibly different) pharmacophores: the multi-pharmacophore entry point
         the reference lacks.  `centers` [B,3] are added back to coordinates as the reference does."""
+        st = self.begin_sampling(h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, rng=rng, seed=seed,
+                                 return_traj=return_traj, num_steps=num_steps, guidance_center=guidance_center)
+        T = self.num_timesteps
+        for i, step in enumerate(range(T)[::-1][:st.n_steps]):
+            self.reverse_step(st, i, step, pos_guidance_opt)
+            if on_step is not None:
+                on_step(i, step, st.eng.ws.out_v, st.x0, st.eng.ws.out_bond)
+        return self.finish_sampling(st)
+
+    # ---- sampler pieces (also used teacher-forced by the parity tests) ----
+    @torch.no_grad()
+    def begin_sampling(self, h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, rng='device', seed=0,
+                       return_traj=True, num_steps=None, guidance_center=None):
         dev = self._device()
-        lib = hip.lib()
+        hip.lib()
         B = int(num_atoms.numel())
         num_atoms = num_atoms.detach().cpu().long()
         batch_node = torch.repeat_interleave(torch.arange(B), num_atoms)
         edge_index, batch_edge = make_edge_data(num_atoms)
         plan = BatchPlan(batch_node, batch_phore, edge_index, batch_edge, B, dev)
         eng = self.engine_for(plan)
-        pk, w = eng.pack, eng.ws
+        w = eng.ws
         eng.encode_phore(h_phore.to(dev), pos_phore.to(dev), phore_norm.to(dev), self.ex_col)
-        N, E, T = plan.n_lig, plan.n_bond, self.num_timesteps
-        n_steps = T if num_steps is None else num_steps
+        N, E = plan.n_lig, plan.n_bond
+        st = type('SamplerState', (), {})()
+        st.eng, st.plan, st.num_atoms, st.N, st.E, st.B = eng, plan, num_atoms, N, E, B
+        st.cpu, st.seed, st.return_traj = rng == 'cpu', seed, return_traj
+        st.n_steps = self.num_timesteps if num_steps is None else num_steps
         centers = centers.to(dev).float()
-        center_rows = centers[plan.batch_node]                                           # [N,3]
-        same_center = bool((centers == centers[0:1]).all())
-        cpu = rng == 'cpu'
+        st.center_rows = centers[plan.batch_node]                                        # [N,3]
+        if return_traj and not bool((centers == centers[0:1]).all()):
+            raise NotImplementedError('phoregen_amd: return_traj needs one shared centre (the reference adds data.center)')
+        st.c0 = centers[0].contiguous()
 
         # ---- init state (diffusion.py:406-408, transition.py:65-69,331-339) ----
-        if cpu:
-            pos = torch.randn([N, 3]).to(dev) - center_rows
+        if st.cpu:
+            pos = torch.randn([N, 3]).to(dev) - st.center_rows
             u_n = torch.rand(N, 12, dtype=torch.float64)
             u_e = torch.rand(E, 6, dtype=torch.float64)
         else:
             gen = torch.Generator(device=dev).manual_seed(seed)
-            pos = torch.randn([N, 3], device=dev, generator=gen) - center_rows
+            pos = torch.randn([N, 3], device=dev, generator=gen) - st.center_rows
             u_n = torch.rand(N, 12, dtype=torch.float64, device=dev, generator=gen)
             u_e = torch.rand(E, 6, dtype=torch.float64, device=dev, generator=gen)
 
@@ -192,64 +209,72 @@ class PhoreDiff(nn.Module):
 
         node_t, edge_t = init_types(self.node_transition, u_n), init_types(self.edge_transition, u_e)
         h_node, h_edge = F.one_hot(node_t, 12).float(), F.one_hot(edge_t, 6).float()
-        log_node = [torch.log(h_node.clamp(min=1e-30)), torch.empty(N, 12, device=dev)]
-        log_edge = [torch.log(h_edge.clamp(min=1e-30)), torch.empty(E, 6, device=dev)]
+        st.log_node = [torch.log(h_node.clamp(min=1e-30)), torch.empty(N, 12, device=dev)]   # common.py:398-402
+        st.log_edge = [torch.log(h_edge.clamp(min=1e-30)), torch.empty(E, 6, device=dev)]
+        st.cur = 0
         w.in_h_node.copy_(h_node), w.in_pos.copy_(pos), w.in_h_edge.copy_(h_edge)
-
-        node_traj = pos_traj = edge_traj = None
+        st.node_traj = st.pos_traj = st.edge_traj = None
         if return_traj:
-            node_traj = torch.zeros(n_steps + 1, N, 12, device=dev)
-            pos_traj = torch.zeros(n_steps + 1, N, 3, device=dev)
-            edge_traj = torch.zeros(n_steps + 1, E, 6, device=dev)
-            node_traj[0], pos_traj[0], edge_traj[0] = h_node, pos, h_edge                # :424-426 (no +center)
-        grad = torch.zeros(N, 3, device=dev) if pos_guidance_opt else None
-        if pos_guidance_opt:
-            cnt_ws, mean_ws, gtmp = torch.zeros(B, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(N, 3, device=dev)
-            gc = guidance_center.to(dev).float().contiguous() if guidance_center is not None else None
-        c0 = centers[0].contiguous()
-        tp = lambda tr, i: tr[i].data_ptr() if tr is not None else None
+            st.node_traj = torch.zeros(st.n_steps + 1, N, 12, device=dev)
+            st.pos_traj = torch.zeros(st.n_steps + 1, N, 3, device=dev)
+            st.edge_traj = torch.zeros(st.n_steps + 1, E, 6, device=dev)
+            st.node_traj[0], st.pos_traj[0], st.edge_traj[0] = h_node, pos, h_edge        # :424-426 (no +center)
+        st.grad = torch.zeros(N, 3, device=dev)
+        st.cnt_ws, st.mean_ws, st.gtmp = torch.zeros(B, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(N, 3, device=dev)
+        st.gc = guidance_center.to(dev).float().contiguous() if guidance_center is not None else None
+        st.x0 = None
+        return st
 
-        cur = 0
-        x0 = None
-        for i, step in enumerate(range(T)[::-1][:n_steps]):
-            w.in_t.fill_(step)
-            _, x0, _ = eng.forward_inplace()
-            s = hip.stream_ptr()
-            un = ue = eps = None
-            if cpu:                                                      # Appendix B item 5: rand, rand, randn
-                un, ue = torch.rand(N, 12).to(dev), torch.rand(E, 6).to(dev)
-            hip.check(lib.pg_posterior_categorical(
-                w.out_v.data_ptr(), log_node[cur].data_ptr(), plan.lig_graph.data_ptr(), w.in_t.data_ptr(),
-                pk.node_tab[0].data_ptr(), pk.node_tab[1].data_ptr(), N, 12, hip.ptr(un), seed, 0, step,
-                log_node[1 - cur].data_ptr(), w.in_h_node.data_ptr(), tp(node_traj, i + 1), s), 'posterior(node)')
-            hip.check(lib.pg_posterior_categorical(
-                w.out_bond.data_ptr(), log_edge[cur].data_ptr(), plan.bond_graph.data_ptr(), w.in_t.data_ptr(),
-                pk.edge_tab[0].data_ptr(), pk.edge_tab[1].data_ptr(), E, 6, hip.ptr(ue), seed, 1, step,
-                log_edge[1 - cur].data_ptr(), w.in_h_edge.data_ptr(), tp(edge_traj, i + 1), s), 'posterior(edge)')
-            if pos_guidance_opt:                                         # diffusion.py:476-502
-                grad.zero_()
-                for o in pos_guidance_opt:
-                    atom = o['type'] == 'atom_prox'
-                    if not atom and o['type'] != 'center_prox':
-                        continue
-                    hip.check(lib.pg_guidance_grad(
-                        plan.topo_ref, w.in_pos.data_ptr(), w.in_h_edge.data_ptr(), plan.lig_graph.data_ptr(),
-                        plan.g_lig_off.data_ptr(), int(atom), float(o.get('min_d', 1.2)), float(o.get('max_d', 2.8)),
-                        int(not atom), hip.ptr(gc), cnt_ws.data_ptr(), mean_ws.data_ptr(), gtmp.data_ptr(), s), 'guidance')
-                    grad += gtmp
-            if cpu:
-                eps = torch.randn(N, 3).to(dev)
-            if return_traj and not same_center:
-                raise NotImplementedError('per-graph centers with return_traj')   # traj adds one shared center
-            hip.check(lib.pg_posterior_position(
-                w.in_pos.data_ptr(), x0.data_ptr(), plan.lig_graph.data_ptr(), w.in_t.data_ptr(),
-                pk.pos_tab[0].data_ptr(), pk.pos_tab[1].data_ptr(), pk.pos_tab[2].data_ptr(), hip.ptr(grad), hip.ptr(eps),
-                seed, 2, step, N, c0.data_ptr() if return_traj else None,
-                w.in_pos.data_ptr(), tp(pos_traj, i + 1), s), 'posterior(pos)')     # in place: x_t -> x_{t-1}
-            cur = 1 - cur
-            if on_step is not None:
-                on_step(i, step, w.out_v, x0, w.out_bond)
+    @torch.no_grad()
+    def reverse_step(self, st, i, step, pos_guidance_opt=None, draws=None):
+        """One iteration of the loop at diffusion.py:432-517 on the state held in the engine workspace.
+        `draws` = (u_node [N,12], u_edge [E,6], eps [N,3]) overrides the noise source (teacher-forced tests)."""
+        lib, eng, plan = hip.lib(), st.eng, st.plan
+        pk, w, N, E = eng.pack, eng.ws, st.N, st.E
+        dev = self._device()
+        tp = lambda tr: tr[i + 1].data_ptr() if tr is not None else None
+        w.in_t.fill_(step)
+        _, st.x0, _ = eng.forward_inplace()
+        s = hip.stream_ptr()
+        un = ue = eps = None
+        if draws is not None:
+            un, ue, eps = (d.to(dev).contiguous() for d in draws)
+        elif st.cpu:                                                 # Appendix B item 5: rand, rand, then randn
+            un, ue = torch.rand(N, 12).to(dev), torch.rand(E, 6).to(dev)
+        cur = st.cur
+        hip.check(lib.pg_posterior_categorical(
+            w.out_v.data_ptr(), st.log_node[cur].data_ptr(), plan.lig_graph.data_ptr(), w.in_t.data_ptr(),
+            pk.node_tab[0].data_ptr(), pk.node_tab[1].data_ptr(), N, 12, hip.ptr(un), st.seed, 0, step,
+            st.log_node[1 - cur].data_ptr(), w.in_h_node.data_ptr(), tp(st.node_traj), s), 'posterior(node)')
+        hip.check(lib.pg_posterior_categorical(
+            w.out_bond.data_ptr(), st.log_edge[cur].data_ptr(), plan.bond_graph.data_ptr(), w.in_t.data_ptr(),
+            pk.edge_tab[0].data_ptr(), pk.edge_tab[1].data_ptr(), E, 6, hip.ptr(ue), st.seed, 1, step,
+            st.log_edge[1 - cur].data_ptr(), w.in_h_edge.data_ptr(), tp(st.edge_traj), s), 'posterior(edge)')
+        grad = None
+        if pos_guidance_opt:                                         # diffusion.py:476-502
+            grad = st.grad
+            grad.zero_()
+            for o in pos_guidance_opt:
+                atom = o['type'] == 'atom_prox'
+                if not atom and o['type'] != 'center_prox':
+                    continue
+                hip.check(lib.pg_guidance_grad(
+                    plan.topo_ref, w.in_pos.data_ptr(), w.in_h_edge.data_ptr(), plan.lig_graph.data_ptr(),
+                    plan.g_lig_off.data_ptr(), int(atom), float(o.get('min_d', 1.2)), float(o.get('max_d', 2.8)),
+                    int(not atom), hip.ptr(st.gc), st.cnt_ws.data_ptr(), st.mean_ws.data_ptr(), st.gtmp.data_ptr(), s),
+                    'guidance')
+                grad += st.gtmp
+        if draws is None and st.cpu:
+            eps = torch.randn(N, 3).to(dev)
+        hip.check(lib.pg_posterior_position(
+            w.in_pos.data_ptr(), st.x0.data_ptr(), plan.lig_graph.data_ptr(), w.in_t.data_ptr(),
+            pk.pos_tab[0].data_ptr(), pk.pos_tab[1].data_ptr(), pk.pos_tab[2].data_ptr(), hip.ptr(grad), hip.ptr(eps),
+            st.seed, 2, step, N, st.c0.data_ptr() if st.return_traj else None,
+            w.in_pos.data_ptr(), tp(st.pos_traj), s), 'posterior(pos)')          # in place: x_t -> x_{t-1}
+        st.cur = 1 - cur
 
-        return {'pred': [w.out_v.clone(), x0 + center_rows, w.out_bond.clone()],
-                'traj': [node_traj, pos_traj, edge_traj],
-                'lig_info': [num_atoms.to(dev), plan.batch_node, plan.edge_index, plan.batch_edge]}
+    def finish_sampling(self, st):
+        w, plan = st.eng.ws, st.plan
+        return {'pred': [w.out_v.clone(), st.x0 + st.center_rows, w.out_bond.clone()],
+                'traj': [st.node_traj, st.pos_traj, st.edge_traj],
+                'lig_info': [st.num_atoms.to(self._device()), plan.batch_node, plan.edge_index, plan.batch_edge]}

@@ -180,47 +180,105 @@ class _ReplayCpuRng:
         torch.rand, torch.randn = self._rand, self._randn
 
 
-@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3'])
-def test_sampler_against_reference_trajectories(model, name):
+GUID = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}]
+
+
+def _replay(model, g, name, closed_loop_steps=None):
     from phoregen_amd.data import PhoreGraph
-    g = golden(name)
     data = PhoreGraph(t(g['phore_x']), t(g['phore_pos']), t(g['phore_norm']), t(g['center'])).to(DEV)
     t_total = int(g['t_total'])
     n_rec = sum(1 for k in g.files if k.endswith('_out_v'))
-    guid = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}] if 'guid' in name else None
     recs = []
-
-    def on_step(i, step, v, x0, bond):
-        w = model._engine.ws
-        recs.append((v.cpu().clone(), x0.cpu().clone(), bond.cpu().clone()))
-
-    states = []
     old_T = model.num_timesteps
     try:
         if t_total != 1000:
             model.num_timesteps = t_total
         with _ReplayCpuRng(_tape(g)):
-            res = model.sample(data, len(g['n_atoms']), DEV, pos_guidance_opt=guid, rng='cpu',
-                               num_atoms=t(g['n_atoms']), num_steps=n_rec if t_total == 1000 else None, on_step=on_step)
+            res = model.sample(data, len(g['n_atoms']), DEV, pos_guidance_opt=GUID if 'guid' in name else None, rng='cpu',
+                               num_atoms=t(g['n_atoms']), num_steps=closed_loop_steps or n_rec,
+                               on_step=lambda i, step, v, x0, bond: recs.append((v.cpu().clone(), x0.cpu().clone(), bond.cpu().clone())))
     finally:
         model.num_timesteps = old_T
     torch.cuda.synchronize()
+    return res, recs, n_rec
+
+
+def test_sampler_closed_loop_matches_reference_trajectory(model):
+    """Free-running sampler, same seeds (recorded CPU draws), t = 999..996: discrete types bit-exact, coordinates
+    within tolerance.  (At small t a randomly initialised network amplifies a 1e-6 input perturbation several
+    hundred-fold per step - measured on the oracle itself - so free-running comparisons are only meaningful
+    where the dynamics are stable; every step of every fixture is covered teacher-forced below.)"""
+    g = golden('g5_sample_head3')
+    res, recs, n_rec = _replay(model, g, 'g5_sample_head3')
     traj_n, traj_p, traj_e = (a.cpu() for a in res['traj'])
     for s in range(n_rec):
-        # state fed to step s == traj[s] (positions without the centre, which the traj adds from step 1 on)
-        assert np.array_equal(traj_n[s].numpy(), g[f's{s}_h_node']), (name, s)
-        assert np.array_equal(traj_e[s].argmax(-1).numpy(), g[f's{s}_h_edge']), (name, s)
+        assert np.array_equal(traj_n[s].numpy(), g[f's{s}_h_node']), s
+        assert np.array_equal(traj_e[s].argmax(-1).numpy(), g[f's{s}_h_edge']), s
         pos_in = traj_p[s] - (t(g['center']) if s > 0 else 0)
-        assert rel_err(pos_in, g[f's{s}_pos']) <= 5 * TOL, (name, s)
+        rmsd = float(np.sqrt(((pos_in.numpy() - g[f's{s}_pos']) ** 2).sum(-1).mean()))
+        assert rmsd <= 1e-4, (s, rmsd)
         v, x0, bond = recs[s]
-        assert max(rel_err(v, g[f's{s}_out_v']), rel_err(x0, g[f's{s}_out_x0']), rel_err(bond, g[f's{s}_out_bond'])) <= 10 * TOL, (name, s)
-    if 'traj_node' in g.files:
-        assert np.array_equal(traj_n.argmax(-1).numpy(), g['traj_node'])
-        assert np.array_equal(traj_e.argmax(-1).numpy(), g['traj_edge'])
-        rmsd = float(np.sqrt(((traj_p.numpy() - g['traj_pos']) ** 2).sum(-1).mean()))
-        assert rmsd <= 1e-4, rmsd
-        assert rel_err(res['pred'][1].cpu(), g['pred_pos']) <= 10 * TOL
-        assert np.array_equal(res['lig_info'][2].cpu().numpy(), g['lig_edge_index'])
+        assert max(rel_err(v, g[f's{s}_out_v']), rel_err(x0, g[f's{s}_out_x0']), rel_err(bond, g[f's{s}_out_bond'])) <= TOL, s
+
+
+@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3'])
+def test_sampler_teacher_forced_every_step(model, oracle, name):
+    """Every recorded step of every fixture: load the reference's state, run ONE HIP step (forward + transition with
+    the reference's recorded draws) and compare with the reference's next state.  Types bit-exact, positions <= 1e-4 RMSD."""
+    import torch.nn.functional as F
+    from phoregen_amd.data import PhoreGraph
+    g = golden(name)
+    tape = _tape(g)
+    n_rec = sum(1 for k in g.files if k.endswith('_out_v'))
+    t_total = int(g['t_total'])
+    na = t(g['n_atoms'])
+    B, p = len(na), g['phore_x'].shape[0]
+    bp = torch.repeat_interleave(torch.arange(B), p)
+    old_T = model.num_timesteps
+    try:
+        if t_total != 1000:
+            model.num_timesteps = t_total
+        st = model.begin_sampling(t(g['phore_x']).repeat(B, 1), t(g['phore_pos']).repeat(B, 1), t(g['phore_norm']).repeat(B, 1),
+                                  bp, na, t(g['center']).unsqueeze(0).expand(B, 3), rng='device', seed=0, num_steps=1,
+                                  guidance_center=t(g['phore_pos'])[t(g['phore_x'])[:, 12] != 1].mean(0))
+    finally:
+        model.num_timesteps = old_T
+    w = st.eng.ws
+    bn, be = st.plan.batch_node.cpu(), st.plan.batch_edge.cpu()
+    # the carried log-posterior chain of the reference, rebuilt from its recorded logits (diffusion.py:453-463)
+    log_node = torch.log(t(g['s0_h_node']).clamp(min=1e-30))
+    log_edge = torch.log(F.one_hot(t(g['s0_h_edge']).long(), 6).float().clamp(min=1e-30))
+    n_checked = 0
+    for s in range(n_rec - 1 if t_total == 1000 else n_rec):
+        step = int(g[f's{s}_t'][0])
+        w.in_h_node.copy_(t(g[f's{s}_h_node']))
+        w.in_pos.copy_(t(g[f's{s}_pos']))
+        w.in_h_edge.copy_(F.one_hot(t(g[f's{s}_h_edge']).long(), 6).float())
+        st.log_node[st.cur].copy_(log_node)
+        st.log_edge[st.cur].copy_(log_edge)
+        draws = tuple(t(a) for a in tape[3 + 3 * s: 6 + 3 * s])
+        model.reverse_step(st, 0, step, GUID if 'guid' in name else None, draws=draws)
+        torch.cuda.synchronize()
+        errs = (rel_err(w.out_v.cpu(), g[f's{s}_out_v']), rel_err(st.x0.cpu(), g[f's{s}_out_x0']),
+                rel_err(w.out_bond.cpu(), g[f's{s}_out_bond']))
+        # low-t states are ill-conditioned (the oracle itself turns a 2e-6 input perturbation into 1e-4..2e-3 output
+        # changes there, DESIGN.md "parity"), hence 5x the forward tolerance for teacher-forced sampler steps
+        assert max(errs) <= 5 * TOL, (name, s, errs)
+        tt = torch.full((B,), step)
+        log_node = po.q_v_posterior(oracle.tab_node, F.log_softmax(t(g[f's{s}_out_v']), -1), log_node, tt, bn)
+        log_edge = po.q_v_posterior(oracle.tab_edge, F.log_softmax(t(g[f's{s}_out_bond']), -1), log_edge, tt, be)
+        assert np.allclose(st.log_node[st.cur].cpu().numpy(), log_node.numpy(), rtol=0, atol=2e-4), (name, s)
+        if f's{s + 1}_h_node' in g.files:
+            nxt_n, nxt_e, nxt_p = g[f's{s + 1}_h_node'], g[f's{s + 1}_h_edge'], g[f's{s + 1}_pos']
+        else:                                                   # last step of a finished run: compare with the trajectory
+            nxt_n = np.eye(12, dtype=np.float32)[g['traj_node'][-1]]
+            nxt_e, nxt_p = g['traj_edge'][-1], g['traj_pos'][-1] - g['center']
+        assert np.array_equal(w.in_h_node.cpu().numpy(), nxt_n), (name, s)                   # atom types bit-exact
+        assert np.array_equal(w.in_h_edge.argmax(-1).cpu().numpy(), nxt_e), (name, s)        # bond types bit-exact
+        rmsd = float(np.sqrt(((w.in_pos.cpu().numpy() - nxt_p) ** 2).sum(-1).mean()))
+        assert rmsd <= 1e-4, (name, s, rmsd)
+        n_checked += 1
+    assert n_checked >= 3
 
 
 def test_device_rng_sampler_runs_and_is_reproducible(model):
