@@ -56,6 +56,7 @@ int pg_gemm(const PgGemm* p, void* stream);
  * Built once per batch by the host mirror (phoregen_amd/plan.py); constant over the 1000 steps. */
 typedef struct {
   int n_graphs, n_ctx, n_lig, n_phore, n_bond;
+  int max_nlig;             /* largest ligand of the batch (selects the triplet kernel variant)           */
   const int* g_ctx_off;     /* [B+1] first ctx node of graph g                                   */
   const int* g_nph;         /* [B]   pharmacophore nodes of graph g (ctx rows g_ctx_off[g]..+nph) */
   const int* g_nlig;        /* [B]   ligand atoms of graph g (follow the phore nodes)             */
@@ -117,6 +118,7 @@ typedef struct {
   int mode;
   int n_seg;
   const int* seg_ids;        /* [n_seg] ctx node ids (node modes) / NULL = 0..n_seg-1 (triplet: bond edge ids) */
+  const int* seg_chunks;     /* triplet: [257] cost-balanced segment ranges, one per workgroup; NULL = equal split */
   /* geometry */
   const float* x;            /* [n_ctx,3] positions the features are computed from               */
   const float* nrm;          /* [n_ctx,3] direction vectors (knn modes)                          */

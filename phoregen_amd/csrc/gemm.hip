@@ -15,8 +15,9 @@ __device__ __forceinline__ float ssp(float v) {  // softplus(v) - ln 2, torch th
 }
 
 __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
-  __shared__ float As[BM * LDT];
-  __shared__ float Bs[BN * LDT];
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];   // staging tiles; reused by the epilogue
+  float* const As = smem;
+  float* const Bs = smem + BM * LDT;
   __shared__ float rstat[BM * 2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -25,24 +26,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
   const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;  // wave sub-tile origin
   const bool ln = p.ln_gamma != nullptr;
 
-  if (ln) {  // per-row mean / rstd over K1 (= 128) columns; two threads per row
-    const int r = tid >> 1, half = tid & 1, grow = row0 + r;
-    float s = 0.f;
-    const int kh = p.K1 >> 1;
-    if (grow < p.M)
-      for (int k = 0; k < kh; ++k) s += p.X[(size_t)grow * p.ldx + half * kh + k];
-    s += __shfl_xor(s, 1);
-    const float mu = s / (float)p.K1;
-    float v = 0.f;
-    if (grow < p.M)
-      for (int k = 0; k < kh; ++k) {
-        float d = p.X[(size_t)grow * p.ldx + half * kh + k] - mu;
-        v += d * d;
+  if (ln) {  // per-row mean / rstd over K1 = 128 columns: 8 lanes per row, each 4 x float4 (coalesced 128-B pieces)
+    const int sub = tid & 7;
+    for (int r = tid >> 3; r < BM; r += 32) {
+      const int grow = row0 + r;
+      f4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (grow < p.M) v[i] = *reinterpret_cast<const f4*>(p.X + (size_t)grow * p.ldx + (i * 8 + sub) * 4);
       }
-    v += __shfl_xor(v, 1);
-    if (half == 0) {
-      rstat[r * 2] = mu;
-      rstat[r * 2 + 1] = 1.0f / sqrtf(v / (float)p.K1 + 1e-5f);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      const float mu = s * (1.f / 128.f);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mu; q = fmaf(d, d, q); }
+      q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+      if (sub == 0) {
+        rstat[r * 2] = mu;
+        rstat[r * 2 + 1] = 1.0f / sqrtf(q * (1.f / 128.f) + 1e-5f);
+      }
     }
     __syncthreads();
   }
@@ -118,29 +126,64 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
     __syncthreads();
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: accumulators -> LDS (one 64-row half at a time, reusing the staging buffers) -> row-wise float4
+  // pieces: bias + gathered adds + activation, 16-byte loads/stores when the operands allow it ----
+  float* const Cs = smem;                     // 64 x 132 floats = 33792 B = sizeof(smem)
+  static_assert(64 * (BN + 4) <= (BM + BN) * LDT, "epilogue tile must fit the staging buffer");
+  constexpr int LDC = BN + 4;
   const int l31 = lane & 31, lh = lane >> 5;
+  const bool vec_ok = (p.ldy & 3) == 0 && ((size_t)p.Y & 15) == 0 && (p.N & 3) == 0 &&
+                      (!p.add1 || ((p.ld_add1 & 3) == 0 && ((size_t)p.add1 & 15) == 0)) &&
+                      (!p.add2 || ((p.ld_add2 & 3) == 0 && ((size_t)p.add2 & 15) == 0));
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if ((wave >> 1) == half) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int grow = row0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (grow >= p.M) continue;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Cs[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wc + 32 * j + l31] = acc[i][j][r];
+    }
+    __syncthreads();
+    // 64 rows x 32 float4 = 2048 pieces over 256 threads
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int piece = it * 256 + tid;
+      const int r = piece >> 5, c4 = (piece & 31) * 4;
+      const int grow = row0 + half * 64 + r, gcol = col0 + c4;
+      if (grow >= p.M || gcol >= p.N) continue;
+      f4 v = *reinterpret_cast<const f4*>(Cs + r * LDC + c4);
       const int a1 = p.add1 ? (p.idx1 ? p.idx1[grow] : grow) : 0;
       const int a2 = p.add2 ? (p.idx2 ? p.idx2[grow] : grow) : 0;
+      if (vec_ok) {
+        if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + gcol);
+        if (p.add1) v += *reinterpret_cast<const f4*>(p.add1 + (size_t)a1 * p.ld_add1 + gcol);
+        if (p.add2) v += *reinterpret_cast<const f4*>(p.add2 + (size_t)a2 * p.ld_add2 + gcol);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int gcol = col0 + wc + 32 * j + l31;
-        if (gcol >= p.N) continue;
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[gcol];
-        if (p.add1) v += p.add1[(size_t)a1 * p.ld_add1 + gcol];
-        if (p.add2) v += p.add2[(size_t)a2 * p.ld_add2 + gcol];
-        if (p.act == 1) v = ssp(v);
-        else if (p.act == 2) v = fmaxf(v, 0.f);
-        p.Y[(size_t)grow * p.ldy + gcol] = v * p.out_scale;
+        for (int j = 0; j < 4; ++j) {
+          if (p.act == 1) v[j] = ssp(v[j]);
+          else if (p.act == 2) v[j] = fmaxf(v[j], 0.f);
+          v[j] *= p.out_scale;
+        }
+        *reinterpret_cast<f4*>(p.Y + (size_t)grow * p.ldy + gcol) = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (gcol + j >= p.N) break;
+          float x = v[j];
+          if (p.bias) x += p.bias[gcol + j];
+          if (p.add1) x += p.add1[(size_t)a1 * p.ld_add1 + gcol + j];
+          if (p.add2) x += p.add2[(size_t)a2 * p.ld_add2 + gcol + j];
+          if (p.act == 1) x = ssp(x);
+          else if (p.act == 2) x = fmaxf(x, 0.f);
+          p.Y[(size_t)grow * p.ldy + gcol + j] = x * p.out_scale;
+        }
       }
     }
+  }
 }
 
 // ---- small per-row linear (n_out <= 16): one wave per row ----------------------------------------
@@ -169,7 +212,7 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   if (!p || !p->X || !p->W || !p->Y || p->M < 0 || p->N <= 0) { pg::set_error("pg_gemm: bad arguments"); return PG_ERR_ARG; }
   if (p->M == 0) return PG_OK;
   if (p->K2 > 0 && !p->X2) { pg::set_error("pg_gemm: K2 > 0 without X2"); return PG_ERR_ARG; }
-  if (p->ln_gamma && (p->K2 != 0 || (p->K1 & 1))) { pg::set_error("pg_gemm: LayerNorm-on-load needs K2 == 0"); return PG_ERR_ARG; }
+  if (p->ln_gamma && (p->K2 != 0 || p->K1 != 128 || (p->ldx & 3) || ((size_t)p->X & 15))) { pg::set_error("pg_gemm: LayerNorm-on-load needs K1 == 128, K2 == 0, 16-byte aligned rows"); return PG_ERR_ARG; }
   dim3 grid((p->M + pg::BM - 1) / pg::BM, (p->N + pg::BN - 1) / pg::BN);
   hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
   return pg::check_launch("pg_gemm");

@@ -14,6 +14,8 @@
 
 namespace pg {
 
+int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // triplet.hip
+
 constexpr float NEG_BIG = -1.0e30f;
 
 template <int MODE> struct ModeTraits;
@@ -656,7 +658,9 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
     case PG_SEG_KNN_POS: return launch_seg<PG_SEG_KNN_POS>(t, p, st);
     case PG_SEG_BOND_NODE: return launch_seg<PG_SEG_BOND_NODE>(t, p, st);
     case PG_SEG_BOND_POS: return launch_seg<PG_SEG_BOND_POS>(t, p, st);
-    case PG_SEG_TRIPLET: return launch_seg<PG_SEG_TRIPLET>(t, p, st);
+    case PG_SEG_TRIPLET:
+      // the occupancy-tuned kernel holds the logits of <= 5 row tiles in registers (ligands of <= 80 atoms)
+      return t->max_nlig <= 80 ? launch_triplet(t, p, st) : launch_seg<PG_SEG_TRIPLET>(t, p, st);
     case PG_SEG_PHORE: return launch_seg<PG_SEG_PHORE>(t, p, st);
   }
   set_error("pg_seg_attn: unknown mode %d", p->mode);

@@ -32,6 +32,7 @@ class Engine:
         self._keep = []          # ctypes structs / tensors referenced by raw pointer
         self.debug = None
         self.timers = None
+        self.tri_calls = []      # indices of the triplet launches in the forward program (profiling)
         self._alloc()
         if full:
             self.prog_phore = self._build_phore_program()
@@ -242,9 +243,10 @@ class Engine:
                        scale=HEAD_SCALE)
             a = L.TB
             self._event(prog, 'triplet', True)
+            self.tri_calls.append(len(prog))
             self._seg(prog, hip.SEG_TRIPLET, E, None, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
                       ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
-                      W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn)
+                      W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks)
             self._event(prog, 'triplet', False)
             # ---- h' = h + lin_node(aggE + aggB) (:288)
             self._gemm(prog, w.aggE, 128, L.W_lin2, hn, n, 128, bias=L.b_lin, X2=w.aggB, K2=128, add1=hc)

@@ -28,14 +28,14 @@ class PgGemm(C.Structure):
 
 class PgTopo(C.Structure):
     _fields_ = [('n_graphs', C.c_int), ('n_ctx', C.c_int), ('n_lig', C.c_int), ('n_phore', C.c_int),
-                ('n_bond', C.c_int),
+                ('n_bond', C.c_int), ('max_nlig', C.c_int),
                 ('g_ctx_off', c_ip), ('g_nph', c_ip), ('g_nlig', c_ip), ('g_eid_off', c_ip), ('eid', c_ip),
                 ('ctx_graph', c_ip), ('ctx_is_lig', c_ip), ('lig2ctx', c_ip), ('bond_src', c_ip),
                 ('bond_dst', c_ip)]
 
 
 class PgSegAttn(C.Structure):
-    _fields_ = [('mode', C.c_int), ('n_seg', C.c_int), ('seg_ids', c_ip),
+    _fields_ = [('mode', C.c_int), ('n_seg', C.c_int), ('seg_ids', c_ip), ('seg_chunks', c_ip),
                 ('x', c_fp), ('nrm', c_fp), ('nbr', c_ip), ('deg', c_ip), ('ew', c_fp), ('knn_k', C.c_int),
                 ('Csrc_k', c_fp), ('Csrc_v', c_fp), ('ld_csrc', C.c_int),
                 ('Cdst_k', c_fp), ('Cdst_v', c_fp), ('ld_cdst', C.c_int),

@@ -69,6 +69,14 @@ class BatchPlan:
 
         t = hip.PgTopo()
         t.n_graphs, t.n_ctx, t.n_lig, t.n_phore, t.n_bond = B, self.n_ctx, self.n_lig, self.n_phore, self.n_bond
+        t.max_nlig = int(nlig.max()) if B else 0
+        # cost-balanced chunks of consecutive bond edges for the 256 persistent triplet workgroups:
+        # cost(edge) ~ row tiles of its ligand + a fixed per-segment part (query fold / value unfold)
+        cost = ((nlig[be] + 15) // 16).double() + 1.0
+        csum = torch.cat([torch.zeros(1, dtype=torch.double), cost.cumsum(0)])
+        targets = torch.linspace(0, float(csum[-1]), 257, dtype=torch.double)
+        self.tri_chunks = i32(torch.searchsorted(csum, targets).clamp(max=self.n_bond))
+        self.tri_chunks[0], self.tri_chunks[-1] = 0, self.n_bond
         for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
                      'bond_src', 'bond_dst'):
             setattr(t, name, getattr(self, name).data_ptr())

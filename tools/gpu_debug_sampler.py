@@ -11,7 +11,7 @@ from phoregen_amd.weights import init_deterministic_
 from phoregen_amd.data import PhoreGraph
 
 model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to('cuda')
-for name in ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3']:
+for name in ['g5_sample_head3']:
     g = golden(name)
     data = PhoreGraph(t(g['phore_x']), t(g['phore_pos']), t(g['phore_norm']), t(g['center'])).to('cuda')
     t_total = int(g['t_total']); n_rec = sum(1 for k in g.files if k.endswith('_out_v'))
@@ -33,4 +33,4 @@ for name in ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sampl
         x0ref = t(g[f's{s}_out_x0'])
         print(f"  s{s}: node_eq={np.array_equal(tn[s].numpy(), g[f's{s}_h_node'])} edge_eq={np.array_equal(te[s].argmax(-1).numpy(), g[f's{s}_h_edge'])} "
               f"pos_in={rel_err(pos_in, g[f's{s}_pos']):.2e} abs_pos={float((pos_in - t(g[f's{s}_pos'])).abs().max()):.2e} "
-              f"v={rel_err(v, g[f's{s}_out_v']):.2e} x0={rel_err(x0, x0ref):.2e} abs_x0={float((x0-x0ref).abs().max()):.2e} bond={rel_err(bond, g[f's{s}_out_bond']):.2e}")
+              f"v={rel_err(v, g[f's{s}_out_v']):.2e} x0={rel_err(x0, x0ref):.2e} abs_x0={float((x0-x0ref).abs().max()):.2e} rmsd_x0={float(((x0-x0ref)**2).sum(-1).mean().sqrt()):.2e} bond={rel_err(bond, g[f's{s}_out_bond']):.2e}")
