@@ -158,19 +158,13 @@ def main():
     st.eng.timers = None
     res = model.finish_sampling(st)
 
-    # the one collective of the path: gather `pred` to rank 0 (variable-length per rank -> padded all_gather)
+    # the one collective of the path: re-assemble `pred` of all ranks (phoregen_amd/parallel.py), after the timed loop
     gather_ms = None
     if world > 1:
+        from phoregen_amd.parallel import gather_predictions
         tg = time.perf_counter()
-        pos = res['pred'][1]
-        n = torch.tensor([pos.size(0)], device=dev)
-        ns = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(ns, n)
-        nmax = int(max(int(x) for x in ns))
-        pad = torch.zeros(nmax, 3, device=dev)
-        pad[:pos.size(0)] = pos
-        out = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(out, pad)
+        gids = torch.arange(args.graphs) + rank * args.graphs
+        gather_predictions(res['pred'], work['num_atoms'], gids)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
     tmax = torch.tensor([dt], device=dev)

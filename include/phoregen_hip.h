@@ -117,7 +117,7 @@ enum {
 typedef struct {
   int mode;
   int n_seg;
-  const int* seg_ids;        /* [n_seg] ctx node ids (node modes) / NULL = 0..n_seg-1 (triplet: bond edge ids) */
+  const int* seg_ids;        /* [n_seg] ctx node ids (node modes); triplet: bond edge ids in visiting order, NULL = 0..n_seg-1 */
   const int* seg_chunks;     /* triplet: [257] cost-balanced segment ranges, one per workgroup; NULL = equal split */
   /* geometry */
   const float* x;            /* [n_ctx,3] positions the features are computed from               */

@@ -72,63 +72,49 @@ __device__ __forceinline__ RowInfo row_info(const PgTopo& t, const PgSegAttn& p,
   return r;
 }
 
-// LayerNorm + ReLU on a K-path tile: hid[tau][r] = hidden[c = 16 tau + 4g + r][row = m]
-__device__ __forceinline__ void ln_relu_kpath(f4 (&hid)[8], const float* gam, const float* bet, int g) {
-  float s = 0.f;
-#pragma unroll
-  for (int tq = 0; tq < 8; ++tq) s += (hid[tq][0] + hid[tq][1]) + (hid[tq][2] + hid[tq][3]);
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
-  const float mu = s * (1.f / 128.f);
+// Folded LayerNorm + ReLU (packing._kv_mlp: hidden is centred and sign-normalised, |gamma| lives in the next Linear):
+// z = ReLU(hidden + b' * sigma); returns 1/sigma, which the caller applies to the row's logits / attention weights.
+// K-path tile: hid[tau][r] = hidden[c = 16 tau + 4g + r][row = m]
+__device__ __forceinline__ float ln_relu_kpath(f4 (&hid)[8], const float* bp, int g) {
   float q = 0.f;
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      hid[tq][r] -= mu;
-      q += hid[tq][r] * hid[tq][r];
-    }
+    for (int r = 0; r < 4; ++r) q = fmaf(hid[tq][r], hid[tq][r], q);
   q += __shfl_xor(q, 16);
   q += __shfl_xor(q, 32);
-  const float rs = 1.0f / sqrtf(q * (1.f / 128.f) + 1e-5f);
+  const float sigma = sqrtf(q * (1.f / 128.f) + 1e-5f);
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq) {
-    const f4 gm = *reinterpret_cast<const f4*>(gam + 16 * tq + 4 * g);
-    const f4 bt = *reinterpret_cast<const f4*>(bet + 16 * tq + 4 * g);
+    const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hid[tq][r] = fmaxf(hid[tq][r] * rs * gm[r] + bt[r], 0.f);
+    for (int r = 0; r < 4; ++r) hid[tq][r] = fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f);
   }
+  return 1.0f / sigma;
 }
 
-// LayerNorm + ReLU on a V-path tile: hid[tau][r] = hidden[row = 4g + r][c = 16 tau + m]
-__device__ __forceinline__ void ln_relu_vpath(f4 (&hid)[8], const float* gam, const float* bet, int m) {
-  f4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int tq = 0; tq < 8; ++tq) s += hid[tq];
-#pragma unroll
-  for (int o = 1; o <= 8; o <<= 1)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s[r] += __shfl_xor(s[r], o);
-  const f4 mu = s * (1.f / 128.f);
+// V-path tile: hid[tau][r] = hidden[row = 4g + r][c = 16 tau + m]; returns 1/sigma per row r
+__device__ __forceinline__ f4 ln_relu_vpath(f4 (&hid)[8], const float* bp, int m) {
   f4 q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int tq = 0; tq < 8; ++tq) {
-    hid[tq] -= mu;
-    q += hid[tq] * hid[tq];
-  }
+  for (int tq = 0; tq < 8; ++tq) q += hid[tq] * hid[tq];
 #pragma unroll
   for (int o = 1; o <= 8; o <<= 1)
 #pragma unroll
     for (int r = 0; r < 4; ++r) q[r] += __shfl_xor(q[r], o);
-  f4 rs;
+  f4 sg, rs;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) rs[r] = 1.0f / sqrtf(q[r] * (1.f / 128.f) + 1e-5f);
+  for (int r = 0; r < 4; ++r) {
+    sg[r] = sqrtf(q[r] * (1.f / 128.f) + 1e-5f);
+    rs[r] = 1.0f / sg[r];
+  }
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq) {
-    const float gm = gam[16 * tq + m], bt = bet[16 * tq + m];
+    const float bt = bp[16 * tq + m];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hid[tq][r] = fmaxf(hid[tq][r] * rs[r] * gm + bt, 0.f);
+    for (int r = 0; r < 4; ++r) hid[tq][r] = fmaxf(fmaf(bt, sg[r], hid[tq][r]), 0.f);
   }
+  return rs;
 }
 
 struct Lds {
@@ -385,12 +371,14 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
       for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(L.wf_k[(st * 8 + tq) * 64 + lane], feat[st], hid[tq]);
-      ln_relu_kpath(hid, gk, bk, g);
+      const float rs_k = ln_relu_kpath(hid, bk, g);
       f4 lg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
         for (int r = 0; r < 4; ++r) lg = mfma16(hid[tq][r], U[tq][r], lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lg[r] *= __shfl(rs_k, 4 * g + r);     // rstd of row 4g+r lives in lane m = 4g+r
 
       // ---------- online softmax (rows 4g + r of this tile, head m) ----------
       float tmax = NEG_BIG;
@@ -435,11 +423,12 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
         for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(feat[st], L.wf_v[(st * 8 + tq) * 64 + lane], hv[tq]);
-        ln_relu_vpath(hv, gv, bv, m);
+        const f4 rs_v = ln_relu_vpath(hv, bv, m);
+        const f4 pwr = pw * rs_v;
 #pragma unroll
-        for (int tq = 0; tq < 8; ++tq)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sT[tq] = mfma16(hv[tq][r], pw[r], sT[tq]);
+          for (int tq = 0; tq < 8; ++tq) sT[tq] = mfma16(hv[tq][r], pwr[r], sT[tq]);
       } else {
         // ---------- pos modes: second K-path MLP (xv), v[row,h] = z . W2xv[h,:] + b ----------
         f4 hv[8];
@@ -456,12 +445,14 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
         for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(L.wf_v[(st * 8 + tq) * 64 + lane], feat[st], hv[tq]);
-        ln_relu_kpath(hv, gv, bv, g);
+        const float rs_x = ln_relu_kpath(hv, bv, g);
         f4 vv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
           for (int r = 0; r < 4; ++r) vv = mfma16(hv[tq][r], L.w2xv_l[(tq * 4 + r) * 64 + lane], vv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[r] *= __shfl(rs_x, 4 * g + r);
         const float bx = L.b2xv[m];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll

@@ -58,7 +58,7 @@ __device__ __constant__ const float kTriFreq[12] = {0.f, 1.f, 2.f, 3.f, 0.5f, (f
                                                      (float)(1.0 / 3.0), 0.f};
 
 template <int TRI_THREADS, int TRI_MAX_TILES>
-__global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAttn p) {
+__global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAttn p, int ablate) {
   constexpr int TRI_WAVES = TRI_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const ln = lds;                      // gk bk gv bv
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     s_end = min(p.n_seg, s_begin + per);
   }
 
-  for (int seg = s_begin + wave; seg < s_end; seg += TRI_WAVES) {
+  for (int si = s_begin + wave; si < s_end; si += TRI_WAVES) {
+    const int seg = p.seg_ids ? p.seg_ids[si] : si;   // edges ordered by source atom j: neighbours in time share P[.->j]
     const int cj = t.bond_src[seg], ci = t.bond_dst[seg];
     const int gi = t.ctx_graph[cj];
     const int n = t.g_nlig[gi];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
       float qk0 = 0.f, qk1 = 0.f, qv0 = 0.f, qv1 = 0.f;
       const float* Gs = p.G + (size_t)seg * 20;
 #pragma unroll 5
-      for (int i = 0; i < 20; ++i) {
+      for (int i = 0; i < ((ablate & 16) ? 0 : 20); ++i) {
         const float gv_ = Gs[i];
         qk0 = fmaf(p.Wg2_k[i * 128 + lane], gv_, qk0);
         qk1 = fmaf(p.Wg2_k[i * 128 + 64 + lane], gv_, qk1);
@@ -130,7 +131,10 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     // =============================== pass A: logits of every row ===============================
     {
       f4 U[8];
-      {
+      if (ablate & 2) {
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) U[tq] = (f4){0.01f * lane, 0.02f, 0.03f, 0.04f};
+      } else {
         const float* qp = p.q + (size_t)seg * 128 + 8 * m;
         const f4 qa = *reinterpret_cast<const f4*>(qp), qb = *reinterpret_cast<const f4*>(qp + 4);
 #pragma unroll
@@ -148,13 +152,13 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
       for (int tile = 0; tile < TRI_MAX_TILES; ++tile) {
         lg[tile] = (f4){TRI_NEG, TRI_NEG, TRI_NEG, TRI_NEG};
         feat[tile][0] = feat[tile][1] = feat[tile][2] = 0.f;
-        if (tile < n_tiles) {
+        if (tile < n_tiles && !(ablate & 64)) {
           const int k = tile * 16 + m;
           const bool valid = k < n && k != li && k != lj;
           const int e_kj = valid ? eid_g[k * n + lj] : 0;
           // angular features of row k for f = 4 step + g  (uni_denoiser.py:131-135, common.py:85)
           float theta = 0.f;
-          if (valid) {
+          if (valid && !(ablate & 8)) {
             const int ck = lig0 + k;
             const float v0 = p.x[ck * 3] - xi0, v1 = p.x[ck * 3 + 1] - xi1, v2 = p.x[ck * 3 + 2] - xi2;
             const float a = u0 * v0 + u1 * v1 + u2 * v2;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
 #pragma unroll
           for (int st = 0; st < 3; ++st) {
             const int f = 4 * st + g;
-            float v = sincos_sel(theta * kTriFreq[f], f >= 6);
+            float v = (ablate & 8) ? 0.5f : sincos_sel(theta * kTriFreq[f], f >= 6);
             v = f == 0 ? theta : v;
             feat[tile][st] = (valid && f != 11) ? v : 0.f;
           }
@@ -174,45 +178,39 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) {
             f4 c = {0.f, 0.f, 0.f, 0.f};
-            if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+            if (valid && !(ablate & 1)) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
             hid[tq] = c + *reinterpret_cast<const f4*>(sc + 16 * tq + 4 * g);
           }
 #pragma unroll
           for (int st = 0; st < 3; ++st)
 #pragma unroll
             for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf_k[(st * 8 + tq) * 64 + lane], feat[tile][st], hid[tq]);
-          // LayerNorm + ReLU over c (in-lane 32 values + the 4 lane groups)
-          float s = 0.f;
-#pragma unroll
-          for (int tq = 0; tq < 8; ++tq) s += (hid[tq][0] + hid[tq][1]) + (hid[tq][2] + hid[tq][3]);
-          s += __shfl_xor(s, 16);
-          s += __shfl_xor(s, 32);
-          const float mu = s * (1.f / 128.f);
+          // LayerNorm + ReLU over c in the folded form (packing._kv_mlp): hidden is centred and sign-normalised,
+          // z = ReLU(hidden + b' * sigma); the row's 1/sigma multiplies its 16 logits below
           float q2 = 0.f;
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              hid[tq][r] -= mu;
-              q2 = fmaf(hid[tq][r], hid[tq][r], q2);
-            }
+            for (int r = 0; r < 4; ++r) q2 = fmaf(hid[tq][r], hid[tq][r], q2);
           q2 += __shfl_xor(q2, 16);
           q2 += __shfl_xor(q2, 32);
-          const float rs = 1.0f / sqrtf(q2 * (1.f / 128.f) + 1e-5f);
+          const float sigma = sqrtf(q2 * (1.f / 128.f) + 1e-5f);
+          const float rs = 1.0f / sigma;
           f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: 40-cycle dependent latency
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) {
-            const f4 gm = *reinterpret_cast<const f4*>(gk + 16 * tq + 4 * g);
             const f4 bt = *reinterpret_cast<const f4*>(bk + 16 * tq + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-              const float z0 = fmaxf(fmaf(hid[tq][r] * rs, gm[r], bt[r]), 0.f);
-              const float z1 = fmaxf(fmaf(hid[tq][r + 1] * rs, gm[r + 1], bt[r + 1]), 0.f);
+              const float z0 = fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f);
+              const float z1 = fmaxf(fmaf(bt[r + 1], sigma, hid[tq][r + 1]), 0.f);
               acc = mfma16(z0, U[tq][r], acc);
               acc2 = mfma16(z1, U[tq][r + 1], acc2);
             }
           }
           acc += acc2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] *= __shfl(rs, 4 * g + r);     // rstd of row 4g+r lives in lane m = 4g+r
           // rows of the logits layout: k = 16 tile + 4g + r
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -250,7 +248,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     for (int tq = 0; tq < 8; ++tq) sT[tq] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tile = 0; tile < TRI_MAX_TILES; ++tile) {
-      if (tile < n_tiles) {
+      if (tile < n_tiles && !(ablate & 32)) {
         f4 hv[8];
         float qv[8];
 #pragma unroll
@@ -262,42 +260,41 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
           const int e_kj = valid ? eid_g[kr * n + lj] : 0;
           const float* pv = p.Csrc_v + (size_t)e_kj * p.ld_csrc + m;
 #pragma unroll
-          for (int tq = 0; tq < 8; ++tq) hv[tq][r] = (valid ? pv[16 * tq] : 0.f) + qv[tq];
+          for (int tq = 0; tq < 8; ++tq) hv[tq][r] = ((valid && !(ablate & 1)) ? pv[16 * tq] : 0.f) + qv[tq];
         }
 #pragma unroll
         for (int st = 0; st < 3; ++st)
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(feat[tile][st], wf_v[(st * 8 + tq) * 64 + lane], hv[tq]);
-        // LayerNorm + ReLU per row r over c = (tau in-lane, m across the DPP row)
-        f4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tq = 0; tq < 8; ++tq) s += hv[tq];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = row16_sum(s[r]) * (1.f / 128.f);
+        // folded LayerNorm + ReLU per row r over c = (tau in-lane, m across the DPP row)
         f4 q2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tq = 0; tq < 8; ++tq) {
-          hv[tq] -= s;
-          q2 += hv[tq] * hv[tq];
+        for (int tq = 0; tq < 8; ++tq) q2 += hv[tq] * hv[tq];
+        f4 sg, aw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sg[r] = sqrtf(row16_sum(q2[r]) * (1.f / 128.f) + 1e-5f);
+          aw[r] = lg[tile][r] / sg[r];                                    // alpha * rstd of the row
         }
-        f4 rs;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rs[r] = 1.0f / sqrtf(row16_sum(q2[r]) * (1.f / 128.f) + 1e-5f);
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq) {
-          const float gm = gv[16 * tq + m], bt = bv[16 * tq + m];
+          const float bt = bv[16 * tq + m];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[tq][r] = fmaxf(fmaf(hv[tq][r] * rs[r], gm, bt), 0.f);
+          for (int r = 0; r < 4; ++r) hv[tq][r] = fmaxf(fmaf(bt, sg[r], hv[tq][r]), 0.f);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)            // r outer: 8 independent accumulator chains
 #pragma unroll
-          for (int tq = 0; tq < 8; ++tq) sT[tq] = mfma16(hv[tq][r], lg[tile][r], sT[tq]);
+          for (int tq = 0; tq < 8; ++tq) sT[tq] = mfma16(hv[tq][r], aw[r], sT[tq]);
       }
     }
 
     // =============================== epilogue: out = resid + W2v_h . S[:,h] / l + b2v ===============================
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ablate & 4) {
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) part[tq] = sT[tq][0] + sT[tq][1] + sT[tq][2] + sT[tq][3];
+    } else
 #pragma unroll
     for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
@@ -330,6 +327,8 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
   }
 }
 
+static int g_ablate = 0;   // PG_TRI_ABLATE bit mask: timing-only ablations (results are wrong when non-zero)
+
 template <int THREADS, int MAXT>
 static int launch_tri(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   const size_t lds = (512 + 2 * 1536 + 2 * 16384 + 128 + (THREADS / 64) * 256) * sizeof(float);
@@ -340,7 +339,7 @@ static int launch_tri(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
     if (e != hipSuccess) { set_error("triplet: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((triplet_kernel<THREADS, MAXT>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p);
+  hipLaunchKernelGGL((triplet_kernel<THREADS, MAXT>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p, g_ablate);
   return check_launch("pg_seg_attn(triplet)");
 }
 
@@ -350,6 +349,8 @@ int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   if (!threads) {
     const char* e = getenv("PG_TRI_THREADS");      // tuning knob: 512 / 768 / 1024 threads = 2 / 3 / 4 waves per SIMD (256 / 168 / 128 VGPRs)
     threads = e ? atoi(e) : 768;
+    const char* a = getenv("PG_TRI_ABLATE");
+    g_ablate = a ? atoi(a) : 0;
   }
   const int tiles = (t->max_nlig + 15) / 16;
   if (threads == 768) {

@@ -57,6 +57,25 @@ def _mlp(sd, p):
                 b=sd[p + '.net.1.bias'].contiguous(), W2=sd[p + '.net.3.weight'], b2=sd[p + '.net.3.bias'])
 
 
+def _kv_mlp(sd, p):
+    """Key/value MLP rewritten so that the kernels' LayerNorm+ReLU costs 3 VALU ops per element instead of 6
+    (exact in real arithmetic):
+      * first layer centred over its 128 outputs (W1 - mean_rows, b1 - mean)  =>  hidden has zero mean, the
+        LayerNorm mean pass disappears (the mean of a linear map is the map with averaged weights);
+      * ReLU(g*x_hat + b) = |g| * ReLU(s*x_hat + b/|g|), s = sign(g): s goes into the first layer (row signs),
+        |g| into the COLUMNS of the second Linear, and with sigma = 1/rstd
+        ReLU(s*x_hat + b') = rstd * ReLU(s*x + b'*sigma), the per-row rstd is applied to the 16 logits /
+        attention weights of the row instead of its 128 channels.
+    Returns W1', b1' (centred, sign-normalised), bp = b/|g|, W2' = W2 * |g| (columns), b2."""
+    m = _mlp(sd, p)
+    W1c = m['W1'] - m['W1'].mean(0, keepdim=True)
+    b1c = m['b1'] - m['b1'].mean()
+    sgn = torch.where(m['g'] < 0, -torch.ones_like(m['g']), torch.ones_like(m['g']))
+    ag = m['g'].abs().clamp(min=1e-20)
+    return dict(W1=(sgn[:, None] * W1c).contiguous(), b1=(sgn * b1c).contiguous(), bp=(m['b'] / ag).contiguous(),
+                W2=(m['W2'] * ag[None, :]).contiguous(), b2=m['b2'])
+
+
 def _knn_feat(W1, W_dd, dst_is_lig):
     """48 feature rows of a knn first layer for one target kind (csrc/seg_attn.hip KNN features):
     [smear if src lig (20) | smear if src phore (20) | 3 direction dots | src-lig flag | src-phore flag | 0 0 0].
@@ -85,7 +104,7 @@ class AttnPack:
 def pack_knn(sd, p, names, Wd, bd, pos):
     """names = (k, v, q) MLP names. Returns (AttnPack, node GEMM blocks [(W [128,128], bias or None)] x 5:
     k_dst, v_dst, k_src, v_src, q_hid)."""
-    k, v, q = (_mlp(sd, f'{p}.{n}') for n in names)
+    k, v, q = _kv_mlp(sd, f'{p}.{names[0]}'), _kv_mlp(sd, f'{p}.{names[1]}'), _mlp(sd, f'{p}.{names[2]}')
     a = AttnPack()
     blocks = []
     feats = {}
@@ -106,7 +125,7 @@ def pack_knn(sd, p, names, Wd, bd, pos):
 
 def pack_bond(sd, p, names, pos):
     """Node GEMM blocks: k_dst, v_dst, k_src, v_src, q_hid; bond GEMM weight [256,128] (k | v halves of h_bond)."""
-    k, v, q = (_mlp(sd, f'{p}.{n}') for n in names)
+    k, v, q = _kv_mlp(sd, f'{p}.{names[0]}'), _kv_mlp(sd, f'{p}.{names[1]}'), _mlp(sd, f'{p}.{names[2]}')
     a = AttnPack()
     blocks = [(k['W1'][:, 128:256], k['b1']), (v['W1'][:, 128:256], v['b1']),
               (k['W1'][:, 256:384], None), (v['W1'][:, 256:384], None), (q['W1'], q['b1'])]
@@ -117,7 +136,7 @@ def pack_bond(sd, p, names, pos):
 
 def pack_triplet(sd, p):
     """Node GEMM blocks: k_hk, v_hk (gathered at src), k_hj(+b1), v_hj(+b1) (gathered at dst), q_hi(+b1q) (dst)."""
-    k, v, q = (_mlp(sd, f'{p}.{n}') for n in ('hk_func', 'hv_func', 'hq_func'))
+    k, v, q = _kv_mlp(sd, p + '.hk_func'), _kv_mlp(sd, p + '.hv_func'), _mlp(sd, p + '.hq_func')
     a = AttnPack()
     blocks = [(k['W1'][:, 181:309], None), (v['W1'][:, 181:309], None),
               (k['W1'][:, 309:437], k['b1']), (v['W1'][:, 309:437], v['b1']), (q['W1'][:, 128:256], q['b1'])]
@@ -132,7 +151,7 @@ def pack_triplet(sd, p):
 
 
 def pack_phore(sd, p='phore_encoder'):
-    k, v, q = (_mlp(sd, f'{p}.{n}') for n in ('hk_func', 'hv_func', 'hq_func'))
+    k, v, q = _kv_mlp(sd, p + '.hk_func'), _kv_mlp(sd, p + '.hv_func'), _mlp(sd, p + '.hq_func')
     a = AttnPack()
     blocks = [(k['W1'][:, 1:129], k['b1']), (v['W1'][:, 1:129], v['b1']),
               (k['W1'][:, 129:257], None), (v['W1'][:, 129:257], None), (q['W1'], q['b1'])]
@@ -144,7 +163,7 @@ def pack_phore(sd, p='phore_encoder'):
 
 
 def _common(a, k, v, q, pos):
-    a.ln_gk, a.ln_bk, a.ln_gv, a.ln_bv = k['g'], k['b'], v['g'], v['b']
+    a.ln_gk, a.ln_bk, a.ln_gv, a.ln_bv = k['bp'], k['bp'], v['bp'], v['bp']      # kernels read only b' = beta/|gamma|
     a.W2k_l = lane_fixed_w2(k['W2'])                     # key bias cancels inside the segment softmax
     a.q_ln_g, a.q_ln_b, a.W2q, a.b2q = q['g'], q['b'], q['W2'].contiguous(), q['b2'].contiguous()
     if pos:

@@ -72,7 +72,10 @@ class BatchPlan:
         t.max_nlig = int(nlig.max()) if B else 0
         # cost-balanced chunks of consecutive bond edges for the 256 persistent triplet workgroups:
         # cost(edge) ~ row tiles of its ligand + a fixed per-segment part (query fold / value unfold)
-        cost = ((nlig[be] + 15) // 16).double() + 1.0
+        # triplet segments are visited in source-atom order (edge j->i reads the rows P[k->j], shared by all i)
+        order = torch.argsort(ei[0], stable=True) if self.n_bond else torch.zeros(0, dtype=torch.long)
+        self.tri_order = i32(order)
+        cost = ((nlig[be[order]] + 15) // 16).double() + 1.0
         csum = torch.cat([torch.zeros(1, dtype=torch.double), cost.cumsum(0)])
         targets = torch.linspace(0, float(csum[-1]), 257, dtype=torch.double)
         self.tri_chunks = i32(torch.searchsorted(csum, targets).clamp(max=self.n_bond))
