@@ -67,6 +67,7 @@ typedef struct {
   const int* lig2ctx;       /* [n_lig] ctx index of ligand atom a (= l_index_in_ctx, common.py:166-177) */
   const int* bond_src;      /* [n_bond] ctx index of edge source (edge_index[0], diffusion.py:201) */
   const int* bond_dst;      /* [n_bond] ctx index of edge target                                  */
+  const int* bond_desc;     /* [n_bond][4] {ctx j, local_i | local_j << 16, n_lig of the graph, eid offset of the graph} */
 } PgTopo;
 
 /* ---- embeddings (models/diffusion.py:180-183,205; models/common.py:34-55) -------------------- */

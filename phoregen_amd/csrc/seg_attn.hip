@@ -83,14 +83,16 @@ __device__ __forceinline__ float ln_relu_kpath(f4 (&hid)[8], const float* bp, in
     for (int r = 0; r < 4; ++r) q = fmaf(hid[tq][r], hid[tq][r], q);
   q += __shfl_xor(q, 16);
   q += __shfl_xor(q, 32);
-  const float sigma = sqrtf(q * (1.f / 128.f) + 1e-5f);
+  const float var = q * (1.f / 128.f) + 1e-5f;
+  const float rs = __builtin_amdgcn_rsqf(var);
+  const float sigma = var * rs;
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq) {
     const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
     for (int r = 0; r < 4; ++r) hid[tq][r] = fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f);
   }
-  return 1.0f / sigma;
+  return rs;
 }
 
 // V-path tile: hid[tau][r] = hidden[row = 4g + r][c = 16 tau + m]; returns 1/sigma per row r
@@ -105,8 +107,9 @@ __device__ __forceinline__ f4 ln_relu_vpath(f4 (&hid)[8], const float* bp, int m
   f4 sg, rs;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    sg[r] = sqrtf(q[r] * (1.f / 128.f) + 1e-5f);
-    rs[r] = 1.0f / sg[r];
+    const float var = q[r] * (1.f / 128.f) + 1e-5f;
+    rs[r] = __builtin_amdgcn_rsqf(var);
+    sg[r] = var * rs[r];
   }
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq) {
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run, tmax);
-      const float scale = expf(m_run - m_new);
+      const float scale = __builtin_amdgcn_exp2f(m_run - m_new);      // base-2 softmax: queries carry log2(e)/sqrt(8)
       m_run = m_new;
       f4 pw;
       float psum = 0.f, wsum = 0.f;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr = rv[r].valid ? expf(lg[r] - m_new) : 0.f;
+        const float pr = rv[r].valid ? __builtin_amdgcn_exp2f(lg[r] - m_new) : 0.f;
         psum += pr;
         pw[r] = pr * gate[r];
         wsum += pw[r];
@@ -628,7 +631,7 @@ static int launch_seg(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   else {
     const int per = threads / 64;
     blocks = (p->n_seg + per - 1) / per;
-    const int cap = kNumCU * (lds > 40 * 1024 ? 2 : 4);
+    const int cap = lds > 16 * 1024 ? kNumCU * 3 : (1 << 20);   // LDS-light modes: exactly one segment per wave
     if (blocks > cap) blocks = cap;
   }
   if (blocks < 1) blocks = 1;

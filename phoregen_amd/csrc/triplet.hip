@@ -94,14 +94,25 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     s_end = min(p.n_seg, s_begin + per);
   }
 
+  // segment = bond edge j->i, visited in source-atom order (neighbours in time share the rows P[.->j]); its 16-byte
+  // descriptor is fetched one segment ahead so that no dependent index chain sits in front of a segment
+  const int4* desc = reinterpret_cast<const int4*>(t.bond_desc);
+  int seg_next = 0;
+  int4 d_next = {0, 0, 0, 0};
+  if (s_begin + wave < s_end) {
+    seg_next = p.seg_ids ? p.seg_ids[s_begin + wave] : s_begin + wave;
+    d_next = desc[seg_next];
+  }
   for (int si = s_begin + wave; si < s_end; si += TRI_WAVES) {
-    const int seg = p.seg_ids ? p.seg_ids[si] : si;   // edges ordered by source atom j: neighbours in time share P[.->j]
-    const int cj = t.bond_src[seg], ci = t.bond_dst[seg];
-    const int gi = t.ctx_graph[cj];
-    const int n = t.g_nlig[gi];
-    const int lig0 = t.g_ctx_off[gi] + t.g_nph[gi];
-    const int li = ci - lig0, lj = cj - lig0;
-    const int* eid_g = t.eid + t.g_eid_off[gi];
+    const int seg = seg_next;
+    const int4 d = d_next;
+    if (si + TRI_WAVES < s_end) {
+      seg_next = p.seg_ids ? p.seg_ids[si + TRI_WAVES] : si + TRI_WAVES;
+      d_next = desc[seg_next];
+    }
+    const int cj = d.x, li = d.y & 0xffff, lj = d.y >> 16, n = d.z;
+    const int lig0 = cj - lj, ci = lig0 + li;
+    const int* eid_g = t.eid + d.w;
     const int n_tiles = (n + 15) >> 4;
 
     // ---- Q = Wg2 . smear(d_ji) into the wave's scratch: [0:128] key MLP, [128:256] value MLP ----
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
             const int f = 4 * st + g;
             float v = (ablate & 8) ? 0.5f : sincos_sel(theta * kTriFreq[f], f >= 6);
             v = f == 0 ? theta : v;
-            feat[tile][st] = (valid && f != 11) ? v : 0.f;
+            feat[tile][st] = f == 11 ? 1.0f : (valid ? v : 0.f);   // f = 11 carries the per-segment constant Q
           }
           // hidden^T[c, row] = P_k[e_kj][c] + Q_k[c] + Wf_k . feat
           f4 hid[8];
@@ -179,12 +190,16 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
           for (int tq = 0; tq < 8; ++tq) {
             f4 c = {0.f, 0.f, 0.f, 0.f};
             if (valid && !(ablate & 1)) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
-            hid[tq] = c + *reinterpret_cast<const f4*>(sc + 16 * tq + 4 * g);
+            hid[tq] = c;
           }
 #pragma unroll
           for (int st = 0; st < 3; ++st)
 #pragma unroll
-            for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf_k[(st * 8 + tq) * 64 + lane], feat[tile][st], hid[tq]);
+            for (int tq = 0; tq < 8; ++tq) {
+              float w = wf_k[(st * 8 + tq) * 64 + lane];
+              if (st == 2) w = g == 3 ? sc[16 * tq + m] : w;          // feature row 11 = Q_k of this segment
+              hid[tq] = mfma16(w, feat[tile][st], hid[tq]);
+            }
           // LayerNorm + ReLU over c in the folded form (packing._kv_mlp): hidden is centred and sign-normalised,
           // z = ReLU(hidden + b' * sigma); the row's 1/sigma multiplies its 16 logits below
           float q2 = 0.f;
@@ -194,8 +209,9 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
             for (int r = 0; r < 4; ++r) q2 = fmaf(hid[tq][r], hid[tq][r], q2);
           q2 += __shfl_xor(q2, 16);
           q2 += __shfl_xor(q2, 32);
-          const float sigma = sqrtf(q2 * (1.f / 128.f) + 1e-5f);
-          const float rs = 1.0f / sigma;
+          const float var = q2 * (1.f / 128.f) + 1e-5f;
+          const float rs = __builtin_amdgcn_rsqf(var);
+          const float sigma = var * rs;
           f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: 40-cycle dependent latency
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) {
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     for (int tile = 0; tile < TRI_MAX_TILES; ++tile)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = lg[tile][r] > 0.5f * TRI_NEG ? expf(lg[tile][r] - mx) : 0.f;
+        const float e = lg[tile][r] > 0.5f * TRI_NEG ? __builtin_amdgcn_exp2f(lg[tile][r] - mx) : 0.f;
         lg[tile][r] = e;
         l += e;
       }
@@ -250,9 +266,6 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     for (int tile = 0; tile < TRI_MAX_TILES; ++tile) {
       if (tile < n_tiles && !(ablate & 32)) {
         f4 hv[8];
-        float qv[8];
-#pragma unroll
-        for (int tq = 0; tq < 8; ++tq) qv[tq] = sc[128 + 16 * tq + m];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kr = tile * 16 + 4 * g + r;
@@ -260,12 +273,16 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
           const int e_kj = valid ? eid_g[kr * n + lj] : 0;
           const float* pv = p.Csrc_v + (size_t)e_kj * p.ld_csrc + m;
 #pragma unroll
-          for (int tq = 0; tq < 8; ++tq) hv[tq][r] = ((valid && !(ablate & 1)) ? pv[16 * tq] : 0.f) + qv[tq];
+          for (int tq = 0; tq < 8; ++tq) hv[tq][r] = (valid && !(ablate & 1)) ? pv[16 * tq] : 0.f;
         }
 #pragma unroll
         for (int st = 0; st < 3; ++st)
 #pragma unroll
-          for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(feat[tile][st], wf_v[(st * 8 + tq) * 64 + lane], hv[tq]);
+          for (int tq = 0; tq < 8; ++tq) {
+            float w = wf_v[(st * 8 + tq) * 64 + lane];
+            if (st == 2) w = g == 3 ? sc[128 + 16 * tq + m] : w;      // feature row 11 = Q_v of this segment
+            hv[tq] = mfma16(feat[tile][st], w, hv[tq]);
+          }
         // folded LayerNorm + ReLU per row r over c = (tau in-lane, m across the DPP row)
         f4 q2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -273,8 +290,10 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
         f4 sg, aw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sg[r] = sqrtf(row16_sum(q2[r]) * (1.f / 128.f) + 1e-5f);
-          aw[r] = lg[tile][r] / sg[r];                                    // alpha * rstd of the row
+          const float var = row16_sum(q2[r]) * (1.f / 128.f) + 1e-5f;
+          const float rsq = __builtin_amdgcn_rsqf(var);
+          sg[r] = var * rsq;
+          aw[r] = lg[tile][r] * rsq;                                      // alpha * rstd of the row
         }
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq) {

@@ -11,7 +11,9 @@ import math
 
 import torch
 
-HEAD_SCALE = 1.0 / math.sqrt(8.0)   # np.sqrt(k.shape[-1]) with head_dim 8 (uni_denoiser.py:62,158,204)
+# queries are pre-scaled by 1/sqrt(head_dim) (np.sqrt(k.shape[-1]) = sqrt(8), uni_denoiser.py:62,158,204) and by
+# log2(e): the kernels' segment softmax runs in base 2 (one v_exp_f32 per weight), which is the same softmax
+HEAD_SCALE = math.log2(math.e) / math.sqrt(8.0)
 
 
 def _lane():

@@ -64,6 +64,9 @@ class BatchPlan:
         self.phore2ctx_long = phore2ctx.to(device)
         self.bond_src, self.bond_dst = i32(lig2ctx[ei[0]]), i32(lig2ctx[ei[1]])
         self.bond_graph, self.lig_graph, self.phore_graph = i32(be), i32(bn), i32(bp)
+        # one 16-byte descriptor per bond edge j->i (triplet kernel): no dependent index chain per segment
+        self.bond_desc = i32(torch.stack([lig2ctx[ei[0]], ld + (ls << 16), nlig[be], g_eid_off[be]], 1).contiguous()) \
+            if self.n_bond else torch.zeros(0, 4, dtype=torch.int32, device=device)
         self.g_lig_off = i32(lig_off)
         self.batch_node, self.batch_edge, self.edge_index = bn.to(device), be.to(device), ei.to(device)
 
@@ -81,7 +84,7 @@ class BatchPlan:
         self.tri_chunks = i32(torch.searchsorted(csum, targets).clamp(max=self.n_bond))
         self.tri_chunks[0], self.tri_chunks[-1] = 0, self.n_bond
         for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
-                     'bond_src', 'bond_dst'):
+                     'bond_src', 'bond_dst', 'bond_desc'):
             setattr(t, name, getattr(self, name).data_ptr())
         self.topo = t
         self.topo_ref = C.byref(t)
