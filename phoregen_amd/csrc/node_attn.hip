@@ -1,0 +1,382 @@
+// Node-target attention sub-layers (knn edges / bond edges, node update / position update) in the two-pass,
+// low-register form of triplet.hip: one wave per target node,
+//   pass A  K path for every row tile -> logits (and, for the position update, the per-head value scalars);
+//   exact softmax over the stored logits (base 2; queries carry log2(e)/sqrt(8));
+//   pass B  V path -> S^T[c,h] (node update) or the weighted sum of relative positions (position update).
+// U (query-folded keys) is read from HBM (pg_attn_fold_query), S goes back for pg_attn_unfold_value, so no
+// second-layer weights sit in LDS and several workgroups share a CU.  fp32 MFMA and VALU share the SIMD pipe on
+// gfx950 (profiles/r01_micro_mfma_valu_coexec.md): the kernel is written for low instruction count, occupancy only
+// hides the row-gather latency.
+// Lane l = (g = l>>4, m = l&15); 16x16x4 maps as in seg_attn.hip.
+#include "common.h"
+#include "../../include/phoregen_hip.h"
+
+namespace pg {
+
+constexpr float NA_NEG = -1.0e30f;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_na(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum_na(float v) {
+  v += dpp_na<0xB1>(v);
+  v += dpp_na<0x4E>(v);
+  v += dpp_na<0x141>(v);
+  v += dpp_na<0x140>(v);
+  return v;
+}
+
+// folded LayerNorm + ReLU on a K-path tile (hid[tau][r] = hidden[c = 16 tau + 4g + r][row = m]); returns rstd of row m
+__device__ __forceinline__ float ln_fold_k(f4 (&hid)[8], const float* bp, int g) {
+  float q = 0.f;
+#pragma unroll
+  for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q = fmaf(hid[tq][r], hid[tq][r], q);
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  const float var = q * (1.f / 128.f) + 1e-5f;
+  const float rs = __builtin_amdgcn_rsqf(var);
+  const float sigma = var * rs;
+#pragma unroll
+  for (int tq = 0; tq < 8; ++tq) {
+    const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hid[tq][r] = fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f);
+  }
+  return rs;
+}
+
+template <bool KNN, bool POS, int MAXT, int THREADS>
+__global__ __launch_bounds__(THREADS, 3) void node_attn_kernel(PgTopo t, PgSegAttn p) {
+  constexpr int NSTEP = KNN ? 12 : 0;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const bpk = lds;                   // [128] b' of the key MLP
+  float* const bpv = lds + 128;             // [128] b' of the value MLP
+  float* const wf_k = lds + 256;            // [NSTEP][8][64]
+  float* const wf_v = wf_k + NSTEP * 512;
+  float* const w2xv = wf_v + NSTEP * 512;   // POS: [32][64]
+  float* const b2xv = w2xv + (POS ? 2048 : 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, m = lane & 15;
+  for (int i = tid; i < 128; i += THREADS) { bpk[i] = p.ln_bk[i]; bpv[i] = p.ln_bv[i]; }
+  for (int i = tid; i < NSTEP * 512; i += THREADS) { wf_k[i] = p.Wf_k[i]; wf_v[i] = p.Wf_v[i]; }
+  if constexpr (POS) {
+    for (int i = tid; i < 2048; i += THREADS) w2xv[i] = p.W2xv_l[i];
+    for (int i = tid; i < 16; i += THREADS) b2xv[i] = p.b2xv[i];
+  }
+  __syncthreads();
+
+  const int n_waves = gridDim.x * (THREADS / 64);
+  for (int si = blockIdx.x * (THREADS / 64) + wave; si < p.n_seg; si += n_waves) {
+    const int seg = p.seg_ids ? p.seg_ids[si] : si;        // target ctx node
+    int n_rows, lig0 = 0, n = 0, li = 0;
+    const int* eid_g = nullptr;
+    if constexpr (KNN) {
+      n_rows = p.deg[seg];
+    } else {
+      const int gi = t.ctx_graph[seg];
+      n = t.g_nlig[gi];
+      lig0 = t.g_ctx_off[gi] + t.g_nph[gi];
+      li = seg - lig0;
+      eid_g = t.eid + t.g_eid_off[gi];
+      n_rows = n;
+    }
+    const int n_tiles = (n_rows + 15) >> 4;
+    const float* ckp = p.Cdst_k + (size_t)seg * p.ld_cdst;
+    const float* cvp = p.Cdst_v + (size_t)seg * p.ld_cdst;
+    float xd[3] = {0.f, 0.f, 0.f}, nd[3] = {0.f, 0.f, 0.f};
+    if constexpr (KNN || POS) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xd[c] = p.x[seg * 3 + c];
+    }
+    if constexpr (KNN) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nd[c] = p.nrm[seg * 3 + c];
+    }
+
+    float feat[MAXT][NSTEP > 0 ? NSTEP : 1];
+    f4 lg[MAXT];
+    f4 vv[POS ? MAXT : 1];
+
+    // ======================= pass A =======================
+    {
+      f4 U[8];
+      {
+        const float* up = p.U + (size_t)seg * 2048 + lane;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) U[tq][r] = up[(tq * 4 + r) * 64];
+      }
+#pragma unroll
+      for (int tile = 0; tile < MAXT; ++tile) {
+        lg[tile] = (f4){NA_NEG, NA_NEG, NA_NEG, NA_NEG};
+        if constexpr (POS) vv[tile] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (tile < n_tiles) {
+          const int k = tile * 16 + m;
+          bool valid = k < n_rows;
+          int src = 0, crow = 0;
+          if constexpr (KNN) {
+            if (valid) { src = p.nbr[(size_t)seg * p.knn_k + k]; crow = src; }
+          } else {
+            valid = valid && k != li;
+            if (valid) { src = lig0 + k; crow = eid_g[k * n + li]; }
+          }
+          if constexpr (KNN) {
+            // 48 features of row k for f = 4 step + g (packing._knn_feat); f = 47 carries the target's constant Cdst
+            float d = 0.f, dots[3] = {0.f, 0.f, 0.f};
+            bool src_lig = false;
+            if (valid) {
+              float xs[3], ns[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { xs[c] = p.x[src * 3 + c]; ns[c] = p.nrm[src * 3 + c]; }
+              const float r0 = xd[0] - xs[0], r1 = xd[1] - xs[1], r2 = xd[2] - xs[2];
+              d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+              dots[0] = ns[0] * nd[0] + ns[1] * nd[1] + ns[2] * nd[2];
+              dots[1] = -(ns[0] * r0 + ns[1] * r1 + ns[2] * r2);
+              dots[2] = -(nd[0] * r0 + nd[1] * r1 + nd[2] * r2);
+              src_lig = t.ctx_is_lig[src] != 0;
+            }
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+              const float sv = valid ? smear(d, 4 * st + g) : 0.f;
+              feat[tile][st] = src_lig ? sv : 0.f;
+              feat[tile][5 + st] = src_lig ? 0.f : sv;
+            }
+            feat[tile][10] = g == 0 ? dots[0] : (g == 1 ? dots[1] : (g == 2 ? dots[2] : ((valid && src_lig) ? 1.f : 0.f)));
+            feat[tile][11] = g == 0 ? ((valid && !src_lig) ? 1.f : 0.f) : (g == 3 ? 1.f : 0.f);
+          }
+          // ---- key MLP: hidden^T[c,row] ----
+          f4 hid[8];
+          {
+            const float* pk = p.Csrc_k + (size_t)crow * p.ld_csrc + 4 * g;
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              f4 c = {0.f, 0.f, 0.f, 0.f};
+              if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+              if constexpr (!KNN) c += *reinterpret_cast<const f4*>(ckp + 16 * tq + 4 * g);
+              hid[tq] = c;
+            }
+          }
+#pragma unroll
+          for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              float w = wf_k[(st * 8 + tq) * 64 + lane];
+              if (st == 11) w = g == 3 ? ckp[16 * tq + m] : w;
+              hid[tq] = mfma16(w, feat[tile][st], hid[tq]);
+            }
+          const float rs = ln_fold_k(hid, bpk, g);
+          f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              acc = mfma16(hid[tq][r], U[tq][r], acc);
+              acc2 = mfma16(hid[tq][r + 1], U[tq][r + 1], acc2);
+            }
+          acc += acc2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kr = tile * 16 + 4 * g + r;
+            const bool vr = kr < n_rows && (KNN || kr != li);
+            const float sc_ = acc[r] * __shfl(rs, 4 * g + r);      // shuffle outside the select: every source lane must be live
+            lg[tile][r] = vr ? sc_ : NA_NEG;
+          }
+          if constexpr (POS) {
+            // ---- value MLP of the position update (K-path form): v[row,h] = z . W2xv[h,:] + b ----
+            f4 hx[8];
+            const float* pk = p.Csrc_v + (size_t)crow * p.ld_csrc + 4 * g;
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              f4 c = {0.f, 0.f, 0.f, 0.f};
+              if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+              if constexpr (!KNN) c += *reinterpret_cast<const f4*>(cvp + 16 * tq + 4 * g);
+              hx[tq] = c;
+            }
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+              for (int tq = 0; tq < 8; ++tq) {
+                float w = wf_v[(st * 8 + tq) * 64 + lane];
+                if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
+                hx[tq] = mfma16(w, feat[tile][st], hx[tq]);
+              }
+            const float rsx = ln_fold_k(hx, bpv, g);
+            f4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+              for (int r = 0; r < 4; r += 2) {
+                a1 = mfma16(hx[tq][r], w2xv[(tq * 4 + r) * 64 + lane], a1);
+                a2 = mfma16(hx[tq][r + 1], w2xv[(tq * 4 + r + 1) * 64 + lane], a2);
+              }
+            a1 += a2;
+            const float bx = b2xv[m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[tile][r] = a1[r] * __shfl(rsx, 4 * g + r) + bx;
+          }
+        }
+      }
+    }
+
+    // ======================= softmax over all rows, head m =======================
+    float mx = NA_NEG;
+#pragma unroll
+    for (int tile = 0; tile < MAXT; ++tile)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, lg[tile][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f, sw = 0.f;
+#pragma unroll
+    for (int tile = 0; tile < MAXT; ++tile) {
+      f4 gate = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (KNN) {
+        if (tile < n_tiles) gate = *reinterpret_cast<const f4*>(p.ew + (size_t)seg * p.knn_k + tile * 16 + 4 * g);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = lg[tile][r] > 0.5f * NA_NEG ? __builtin_amdgcn_exp2f(lg[tile][r] - mx) : 0.f;
+        l += e;
+        lg[tile][r] = e * gate[r];           // attention weight x edge gate (v = MLP(...) * e_w, uni_denoiser.py:52-54)
+        sw += lg[tile][r];
+      }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+
+    if constexpr (POS) {
+      // dx = mean_h sum_rows alpha * gate * v * (x_dst - x_src)   (uni_denoiser.py:200-209)
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int tile = 0; tile < MAXT; ++tile)
+        if (tile < n_tiles) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kr = tile * 16 + 4 * g + r;
+            const bool vr = kr < n_rows && (KNN || kr != li);
+            if (vr) {
+              const int src = KNN ? p.nbr[(size_t)seg * p.knn_k + kr] : lig0 + kr;
+              const float w = lg[tile][r] * vv[tile][r];
+              a0 = fmaf(w, xd[0] - p.x[src * 3], a0);
+              a1 = fmaf(w, xd[1] - p.x[src * 3 + 1], a1);
+              a2 = fmaf(w, xd[2] - p.x[src * 3 + 2], a2);
+            }
+          }
+        }
+      a0 = wave_sum(a0 * inv) * (1.f / 16.f);
+      a1 = wave_sum(a1 * inv) * (1.f / 16.f);
+      a2 = wave_sum(a2 * inv) * (1.f / 16.f);
+      if (lane == 0) {
+        if (p.accumulate_dx) { p.dx[seg * 3] += a0; p.dx[seg * 3 + 1] += a1; p.dx[seg * 3 + 2] += a2; }
+        else { p.dx[seg * 3] = a0; p.dx[seg * 3 + 1] = a1; p.dx[seg * 3 + 2] = a2; }
+      }
+    } else {
+      // ======================= pass B: S^T[c,h] = sum_rows z_v[row,c] * alpha[row,h] =======================
+      sw += __shfl_xor(sw, 16);
+      sw += __shfl_xor(sw, 32);
+      f4 sT[8];
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) sT[tq] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tile = 0; tile < MAXT; ++tile) {
+        if (tile < n_tiles) {
+          f4 hv[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kr = tile * 16 + 4 * g + r;
+            const bool vr = kr < n_rows && (KNN || kr != li);
+            int crow = 0;
+            if (vr) crow = KNN ? p.nbr[(size_t)seg * p.knn_k + kr] : eid_g[kr * n + li];
+            const float* pv = p.Csrc_v + (size_t)crow * p.ld_csrc + m;
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) hv[tq][r] = vr ? pv[16 * tq] : 0.f;
+          }
+          if constexpr (!KNN) {
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) hv[tq] += cvp[16 * tq + m];
+          }
+#pragma unroll
+          for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              float w = wf_v[(st * 8 + tq) * 64 + lane];
+              if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
+              hv[tq] = mfma16(feat[tile][st], w, hv[tq]);
+            }
+          f4 q2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) q2 += hv[tq] * hv[tq];
+          f4 sg, aw;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float var = row16_sum_na(q2[r]) * (1.f / 128.f) + 1e-5f;
+            const float rsq = __builtin_amdgcn_rsqf(var);
+            sg[r] = var * rsq;
+            aw[r] = lg[tile][r] * rsq;
+          }
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) {
+            const float bt = bpv[16 * tq + m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[tq][r] = fmaxf(fmaf(bt, sg[r], hv[tq][r]), 0.f);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) sT[tq] = mfma16(hv[tq][r], aw[r], sT[tq]);
+        }
+      }
+      float* sp = p.S + (size_t)seg * 2048 + lane;
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sp[(tq * 4 + r) * 64] = sT[tq][r] * inv;
+      if (g == 0) p.swn[(size_t)seg * 16 + m] = sw * inv;
+    }
+  }
+}
+
+template <bool KNN, bool POS, int MAXT, int THREADS>
+static int launch_na(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  constexpr int NSTEP = KNN ? 12 : 0;
+  const size_t lds = (256 + 2 * NSTEP * 512 + (POS ? 2048 + 16 : 0)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("node_attn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
+    attr_set = true;
+  }
+  const int per = THREADS / 64;
+  int blocks = (p->n_seg + per - 1) / per;
+  if (KNN && blocks > 3 * kNumCU) blocks = 3 * kNumCU;     // LDS-heavy: persistent-ish, the weights are loaded per block
+  hipLaunchKernelGGL((node_attn_kernel<KNN, POS, MAXT, THREADS>), dim3(blocks), dim3(THREADS), lds, st, *t, *p);
+  return check_launch("pg_seg_attn(node)");
+}
+
+// returns -1 when the shape is outside what the two-pass kernels hold in registers (caller falls back to seg_attn.hip)
+int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  const bool knn = p->mode == PG_SEG_KNN_NODE || p->mode == PG_SEG_KNN_POS;
+  const bool pos = p->mode == PG_SEG_KNN_POS || p->mode == PG_SEG_BOND_POS;
+  if (knn) {
+    if (p->knn_k > 32) return -1;
+    return pos ? launch_na<true, true, 2, 256>(t, p, st) : launch_na<true, false, 2, 256>(t, p, st);
+  }
+  const int tiles = (t->max_nlig + 15) / 16;
+  if (tiles > 5) return -1;
+  if (pos) {
+    if (tiles <= 3) return launch_na<false, true, 3, 256>(t, p, st);
+    if (tiles == 4) return launch_na<false, true, 4, 256>(t, p, st);
+    return launch_na<false, true, 5, 256>(t, p, st);
+  }
+  if (tiles <= 3) return launch_na<false, false, 3, 256>(t, p, st);
+  if (tiles == 4) return launch_na<false, false, 4, 256>(t, p, st);
+  return launch_na<false, false, 5, 256>(t, p, st);
+}
+
+}  // namespace pg

@@ -9,12 +9,15 @@
 //   VALU   online softmax over rows per head
 //   MFMA3  S^T[c,h] += z_v[row,c] * p[row,h]            (accumulator of MFMA1 is the A operand as it stands)
 // Lane l = (g = l>>4, m = l&15).  16x16x4 maps: A[row=m][k=g], B[k=g][col=m], D reg r = D[row=4g+r][col=m].
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/phoregen_hip.h"
 
 namespace pg {
 
-int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // triplet.hip
+int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st);     // triplet.hip
+int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // node_attn.hip (-1: shape not covered)
 
 constexpr float NEG_BIG = -1.0e30f;
 
@@ -647,6 +650,10 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
   if (!t || !p) { set_error("pg_seg_attn: null argument"); return PG_ERR_ARG; }
   if (p->n_seg == 0) return PG_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (p->mode <= PG_SEG_BOND_POS && !getenv("PG_GENERIC_SEG")) {   // two-pass kernels; env knob keeps the one-pass kernel testable
+    const int rc = launch_node_attn(t, p, st);
+    if (rc >= 0) return rc;
+  }
   switch (p->mode) {
     case PG_SEG_KNN_NODE: return launch_seg<PG_SEG_KNN_NODE>(t, p, st);
     case PG_SEG_KNN_POS: return launch_seg<PG_SEG_KNN_POS>(t, p, st);
