@@ -2,6 +2,8 @@
 // 128x128 block tile, 4 waves x (64x64) of v_mfma_f32_32x32x2_f32, K streamed through LDS in 32-wide
 // chunks (row stride 33 floats: conflict-free ds_read_b32 for both operands).  Optional
 // LayerNorm(128)+ReLU folded into the A-tile load (second half of models/common.py:99-119 MLPs).
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/phoregen_hip.h"
 
@@ -186,6 +188,167 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// W-stationary persistent variant for the tall bond-row GEMMs (M ~ 2e5, K <= 148, 128 output columns per block):
+// the 128 x K weight block stays in LDS for the whole kernel, 64-row A tiles stream through a double buffer
+// (next tile prefetched into registers during the MFMAs), the finished tile is staged through the consumed A buffer
+// for float4 bias / gathered-row / activation epilogues.  8 waves: 2 row blocks x 4 column blocks of 32x32.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WS_THREADS = 512, WS_BM = 64, WS_LDC = 132;
+
+template <int KP /* LDS row stride of the K dimension, odd */>
+__global__ __launch_bounds__(WS_THREADS) void gemm_ws_kernel(PgGemm p, int tiles_per_col) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int ABUF = WS_BM * (KP > WS_LDC ? KP : WS_LDC);
+  float* const Ws = sm;                      // [128][KP]
+  float* const Ab = sm + 128 * KP;           // [2][ABUF]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = p.K1 + p.K2;
+  const int col0 = blockIdx.y * BN;
+  const int rb = wave >> 2, cb = wave & 3;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const bool ln = p.ln_gamma != nullptr;
+
+  for (int i = tid; i < 128 * (K >> 2); i += WS_THREADS) {          // W rows, float4 pieces (K % 4 == 0)
+    const int r = i / (K >> 2), kq = (i % (K >> 2)) * 4;
+    f4 w = {0.f, 0.f, 0.f, 0.f};
+    if (col0 + r < p.N) w = *reinterpret_cast<const f4*>(p.W + (size_t)(col0 + r) * p.ldw + kq);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Ws[r * KP + kq + j] = w[j];
+  }
+
+  // fetch mapping: 8 threads per row, thread `sub` owns float4 pieces sub, sub+8, ... of the row
+  const int fr = tid >> 3, sub = tid & 7;
+  f4 ra[5];
+  auto fetch = [&](int tile) {
+    const int grow = tile * WS_BM + fr;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      ra[j] = (f4){0.f, 0.f, 0.f, 0.f};
+      const int kq = (j * 8 + sub) * 4;
+      if (grow < p.M) {
+        if (kq < p.K1) ra[j] = *reinterpret_cast<const f4*>(p.X + (size_t)grow * p.ldx + kq);
+        else if (kq < K) ra[j] = *reinterpret_cast<const f4*>(p.X2 + (size_t)grow * p.ldx2 + (kq - p.K1));
+      }
+    }
+  };
+  auto stage = [&](float* dst) {
+    if (ln) {     // LayerNorm(128)+ReLU of the fetched row (K1 == 128, K2 == 0): 8 lanes hold one row
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
+      s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+      const float mu = s * (1.f / 128.f);
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ra[j][e] -= mu; q = fmaf(ra[j][e], ra[j][e], q); }
+      q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+      const float rs = 1.0f / sqrtf(q * (1.f / 128.f) + 1e-5f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kq = (j * 8 + sub) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf(ra[j][e] * rs * p.ln_gamma[kq + e] + p.ln_beta[kq + e], 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int kq = (j * 8 + sub) * 4;
+      if (kq < K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[fr * KP + kq + e] = ra[j][e];
+      }
+    }
+  };
+
+  const int n_tiles = (p.M + WS_BM - 1) / WS_BM;
+  const int t_begin = blockIdx.x * tiles_per_col, t_end = min(n_tiles, t_begin + tiles_per_col);
+  const bool vec_ok = (p.ldy & 3) == 0 && ((size_t)p.Y & 15) == 0 && (p.N & 3) == 0 &&
+                      (!p.add1 || ((p.ld_add1 & 3) == 0 && ((size_t)p.add1 & 15) == 0)) &&
+                      (!p.add2 || ((p.ld_add2 & 3) == 0 && ((size_t)p.add2 & 15) == 0));
+  if (t_begin < t_end) {
+    fetch(t_begin);
+    stage(Ab);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    float* const A = Ab + cur * ABUF;
+    if (tile + 1 < t_end) fetch(tile + 1);
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = A + (rb * 32 + l31) * KP + kh;
+    const float* wp = Ws + (cb * 32 + l31) * KP + kh;
+#pragma unroll 8
+    for (int ks = 0; ks < (K >> 1); ++ks) acc = mfma32(ap[2 * ks], wp[2 * ks], acc);
+    __syncthreads();                                   // all waves are done reading A
+#pragma unroll
+    for (int r = 0; r < 16; ++r)                        // finished 64 x 128 tile -> the consumed A buffer
+      A[(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * WS_LDC + cb * 32 + l31] = acc[r];
+    if (tile + 1 < t_end) stage(Ab + (1 - cur) * ABUF);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                    // 64 rows x 32 float4 pieces over 512 threads
+      const int piece = it * WS_THREADS + tid;
+      const int r = piece >> 5, c4 = (piece & 31) * 4;
+      const int grow = tile * WS_BM + r, gcol = col0 + c4;
+      if (grow >= p.M || gcol >= p.N) continue;
+      f4 v = *reinterpret_cast<const f4*>(A + r * WS_LDC + c4);
+      const int a1 = p.add1 ? (p.idx1 ? p.idx1[grow] : grow) : 0;
+      const int a2 = p.add2 ? (p.idx2 ? p.idx2[grow] : grow) : 0;
+      if (vec_ok) {
+        if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + gcol);
+        if (p.add1) v += *reinterpret_cast<const f4*>(p.add1 + (size_t)a1 * p.ld_add1 + gcol);
+        if (p.add2) v += *reinterpret_cast<const f4*>(p.add2 + (size_t)a2 * p.ld_add2 + gcol);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p.act == 1) v[j] = ssp(v[j]);
+          else if (p.act == 2) v[j] = fmaxf(v[j], 0.f);
+          v[j] *= p.out_scale;
+        }
+        *reinterpret_cast<f4*>(p.Y + (size_t)grow * p.ldy + gcol) = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (gcol + j >= p.N) break;
+          float x = v[j];
+          if (p.bias) x += p.bias[gcol + j];
+          if (p.add1) x += p.add1[(size_t)a1 * p.ld_add1 + gcol + j];
+          if (p.add2) x += p.add2[(size_t)a2 * p.ld_add2 + gcol + j];
+          if (p.act == 1) x = ssp(x);
+          else if (p.act == 2) x = fmaxf(x, 0.f);
+          p.Y[(size_t)grow * p.ldy + gcol + j] = x * p.out_scale;
+        }
+      }
+    }
+    __syncthreads();                                   // epilogue reads of A are done before it is restaged
+    cur = 1 - cur;
+  }
+}
+
+template <int KP>
+static int launch_ws(const PgGemm* p, hipStream_t st) {
+  constexpr int ABUF = WS_BM * (KP > WS_LDC ? KP : WS_LDC);
+  const size_t lds = (128 * KP + 2 * ABUF) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("pg_gemm(ws): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
+    attr_set = true;
+  }
+  const int n_tiles = (p->M + WS_BM - 1) / WS_BM, n_col = (p->N + BN - 1) / BN;
+  int row_groups = kNumCU / n_col;
+  if (row_groups < 1) row_groups = 1;
+  const int tiles_per = (n_tiles + row_groups - 1) / row_groups;
+  row_groups = (n_tiles + tiles_per - 1) / tiles_per;
+  hipLaunchKernelGGL(gemm_ws_kernel<KP>, dim3(row_groups, n_col), dim3(WS_THREADS), lds, st, *p, tiles_per);
+  return check_launch("pg_gemm(ws)");
+}
+
 // ---- small per-row linear (n_out <= 16): one wave per row ----------------------------------------
 __global__ __launch_bounds__(256) void rows_linear_kernel(const float* X, int ldx, int K, const float* W, const float* b,
                                                           int n_out, int M, const int* rows, float* Y, int ldy) {
@@ -213,6 +376,15 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   if (p->M == 0) return PG_OK;
   if (p->K2 > 0 && !p->X2) { pg::set_error("pg_gemm: K2 > 0 without X2"); return PG_ERR_ARG; }
   if (p->ln_gamma && (p->K2 != 0 || p->K1 != 128 || (p->ldx & 3) || ((size_t)p->X & 15))) { pg::set_error("pg_gemm: LayerNorm-on-load needs K1 == 128, K2 == 0, 16-byte aligned rows"); return PG_ERR_ARG; }
+  // tall, thin-K problems: W-stationary persistent kernel (needs float4-able operands)
+  const int K = p->K1 + p->K2;
+  const bool al = (p->ldx & 3) == 0 && ((size_t)p->X & 15) == 0 && (p->ldw & 3) == 0 && ((size_t)p->W & 15) == 0 &&
+                  (p->K1 & 3) == 0 && (p->K2 & 3) == 0 && (!p->K2 || ((p->ldx2 & 3) == 0 && ((size_t)p->X2 & 15) == 0));
+  // (measured, tools/bench_gemm.py: a clear win for the LayerNorm-on-load form, a wash or slightly worse otherwise)
+  if (p->M >= 32768 && al && p->N <= 256 && p->ln_gamma && !getenv("PG_GEMM_TILED")) {
+    if (K == 128) return pg::launch_ws<129>(p, (hipStream_t)stream);
+    if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
+  }
   dim3 grid((p->M + pg::BM - 1) / pg::BM, (p->N + pg::BN - 1) / pg::BN);
   hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
   return pg::check_launch("pg_gemm");
