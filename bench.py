@@ -123,7 +123,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        dist.init_process_group(os.environ.get('PG_DIST_BACKEND', 'nccl'))    # nccl == RCCL on ROCm
+    local = local % max(torch.cuda.device_count(), 1)     # (a 2-rank gloo dry run can share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -141,6 +142,7 @@ def main():
     T = model.num_timesteps
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -167,7 +169,7 @@ def main():
         gather_predictions(res['pred'], work['num_atoms'], gids)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
-    tmax = torch.tensor([dt], device=dev)
+    tmax = torch.tensor([dt], device=dev if (world == 1 or dist.get_backend() != 'gloo') else 'cpu')
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -16,7 +16,7 @@ __device__ __forceinline__ float ssp(float v) {  // softplus(v) - ln 2, torch th
   return sp - 0.69314718055994530942f;
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
+__global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];   // staging tiles; reused by the epilogue
   float* const As = smem;
   float* const Bs = smem + BM * LDT;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
       const int r = (tid >> 3) + 32 * i, kq = (tid & 7) * 4, kk = k0 + kq;
       const int grow = row0 + r;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (grow < p.M) {
+      if (grow < p.M && !(ablate & 1)) {
         if (fastX && kk + 3 < p.K1) {
           const float4 t = *reinterpret_cast<const float4*>(p.X + (size_t)grow * p.ldx + kk);
           v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
 
       const int gcol = col0 + r;
       float w[4] = {0.f, 0.f, 0.f, 0.f};
-      if (gcol < p.N) {
+      if (gcol < p.N && !(ablate & 1)) {
         if (fastW && kk + 3 < K) {
           const float4 t = *reinterpret_cast<const float4*>(p.W + (size_t)gcol * p.ldw + kk);
           w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
     // ---- 16 k-steps of 2 ----
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll 4
-    for (int ks = 0; ks < BK / 2; ++ks) {
+    for (int ks = 0; ks < ((ablate & 2) ? 1 : BK / 2); ++ks) {
       const int k = ks * 2 + kh;
       const float a0 = As[(wr + l31) * LDT + k], a1 = As[(wr + 32 + l31) * LDT + k];
       const float b0 = Bs[(wc + l31) * LDT + k], b1 = Bs[(wc + 32 + l31) * LDT + k];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p) {
       const int piece = it * 256 + tid;
       const int r = piece >> 5, c4 = (piece & 31) * 4;
       const int grow = row0 + half * 64 + r, gcol = col0 + c4;
-      if (grow >= p.M || gcol >= p.N) continue;
+      if (grow >= p.M || gcol >= p.N || ((ablate & 4) && r != 0)) continue;
       f4 v = *reinterpret_cast<const f4*>(Cs + r * LDC + c4);
       const int a1 = p.add1 ? (p.idx1 ? p.idx1[grow] : grow) : 0;
       const int a2 = p.add2 ? (p.idx2 ? p.idx2[grow] : grow) : 0;
@@ -386,7 +386,9 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
     if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
   }
   dim3 grid((p->M + pg::BM - 1) / pg::BM, (p->N + pg::BN - 1) / pg::BN);
-  hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p);
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("PG_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }   // timing-only knob
+  hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p, ablate);
   return pg::check_launch("pg_gemm");
 }
 

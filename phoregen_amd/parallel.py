@@ -26,6 +26,9 @@ def gather_variable(t, group=None):
     """all_gather of a [n_r, ...] tensor whose first dimension differs per rank: counts first, then one padded
     all_gather (two collectives per tensor, ~50 KB per graph)."""
     world = dist.get_world_size(group)
+    dev = t.device
+    if dist.get_backend(group) == 'gloo' and t.is_cuda:      # gloo moves host memory; RCCL works on device memory
+        t = t.cpu()
     n = torch.tensor([t.size(0)], device=t.device, dtype=torch.long)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -35,7 +38,7 @@ def gather_variable(t, group=None):
     pad[:t.size(0)] = t
     out = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
-    return [o[:c] for o, c in zip(out, counts)]
+    return [o[:c].to(dev) for o, c in zip(out, counts)]
 
 
 def gather_predictions(pred, num_atoms_local, graph_ids_local, group=None):

@@ -129,6 +129,26 @@ def test_forward_against_oracle_larger_graphs(model, oracle):
     assert max(errs.values()) <= TOL, errs
 
 
+def test_forward_max_size_ligand_and_generic_kernel_fallback(model, oracle):
+    """78-atom ligand (the reference's max_atom: 5 row tiles in the triplet / bond kernels) next to a 4-atom one, and the
+    one-pass generic segment kernel (PG_GENERIC_SEG=1, the fallback for shapes the two-pass kernels do not hold)."""
+    import os
+    from oracle.make_inputs import synthetic_batch
+    inp = synthetic_batch(11, [78, 4], [35, 23], [321, 77])
+    dev_inp = {k: v.to(DEV) for k, v in inp.items()}
+    with torch.no_grad():
+        ref = oracle.forward(**inp)
+        out = model(**dev_inp)
+        os.environ['PG_GENERIC_SEG'] = '1'
+        try:
+            out_g = model(**dev_inp)
+        finally:
+            del os.environ['PG_GENERIC_SEG']
+    for o in (out, out_g):
+        errs = dict(v=rel_err(o[0].cpu(), ref[0]), x0=rel_err(o[1].cpu(), ref[1]), bond=rel_err(o[2].cpu(), ref[2]))
+        assert max(errs.values()) <= TOL, errs
+
+
 def test_posterior_kats(model):
     from phoregen_amd import hip
     lib, pk = hip.lib(), model.packed()
