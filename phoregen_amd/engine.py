@@ -13,6 +13,7 @@ Data flow of one layer (reference: AttentionLayerO2TwoUpdateNodeGeneral.forward,
   Y2   = h' @ W_node2^T; same for the two position sub-layers;  x' = x + mask * (dx_knn + dx_bond)
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -33,6 +34,11 @@ class Engine:
         self.debug = None
         self.timers = None
         self.tri_calls = []      # indices of the triplet launches in the forward program (profiling)
+        # independent sub-layer chains of a layer run on side streams ("lanes" 1, 2) next to the triplet chain (lane 0):
+        # kernels of different chains interleave on the CUs, so one chain's load/store phases meet another's MFMA phases
+        self.multi_stream = os.environ.get('PG_STREAMS', '1') != '0'
+        self._lane = 0
+        self._side = None
         self._alloc()
         if full:
             self.prog_phore = self._build_phore_program()
@@ -62,8 +68,9 @@ class Engine:
         w.deg = torch.zeros(n, dtype=torch.int32, device=d)
         w.ew, w.nrm, w.G = _f(n, k, device=d), _f(n, 3, device=d), _f(E, 20, device=d)
         w.Y1, w.Y2 = _f(n, 1920, device=d), _f(n, 1280, device=d)
-        w.q = _f(n, 128, device=d)
-        w.U, w.S, w.swn = _f(n, 2048, device=d), _f(n, 2048, device=d), _f(n, 16, device=d)
+        w.q = [_f(n, 128, device=d) for _ in range(2)]                 # per concurrent chain (knn / bond)
+        w.U, w.S = [_f(n, 2048, device=d) for _ in range(2)], [_f(n, 2048, device=d) for _ in range(2)]
+        w.swn = [_f(n, 16, device=d) for _ in range(2)]
         w.aggE, w.aggB = _f(n, 128, device=d, zero=True), _f(n, 128, device=d, zero=True)
         w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)
         w.qhid, w.qT = _f(E, 128, device=d), _f(E, 128, device=d)
@@ -75,7 +82,33 @@ class Engine:
     # ------------------------------------------------------------------ call builders
     def _call(self, prog, fn, *args):
         assert len(args) + 1 == len(fn.argtypes), (fn.__name__, len(args) + 1, len(fn.argtypes))
-        prog.append((fn, args))
+        prog.append((fn, args, self._lane if self.multi_stream else 0))
+
+    def _fork(self, prog, lanes):
+        """Side lanes start after everything enqueued so far on lane 0."""
+        if not self.multi_stream:
+            return
+        def tap(streams):
+            ev = torch.cuda.Event()
+            ev.record(streams[0])
+            for l in lanes:
+                streams[l].wait_event(ev)
+            return 0
+        tap.__name__ = 'fork'
+        prog.append((tap, None, -1))
+
+    def _join(self, prog, lanes):
+        """Lane 0 continues after the side lanes have drained."""
+        if not self.multi_stream:
+            return
+        def tap(streams):
+            for l in lanes:
+                ev = torch.cuda.Event()
+                ev.record(streams[l])
+                streams[0].wait_event(ev)
+            return 0
+        tap.__name__ = 'join'
+        prog.append((tap, None, -1))
 
     def _event(self, prog, name, start):
         """Timing tap: when `self.timers` is a dict, record a HIP event on the launch stream around a kernel."""
@@ -86,7 +119,7 @@ class Engine:
                 self.timers.setdefault(name, []).append((start, ev))
             return 0
         tap.__name__ = 'event_' + name
-        prog.append((tap, ()))
+        prog.append((tap, None, -1))
 
     def kernel_ms(self, name):
         """Per-launch durations (ms) collected since `self.timers = {}`; call after a device synchronize."""
@@ -100,7 +133,7 @@ class Engine:
                 self.debug[name] = tuple(t.clone() for t in tensors)
             return 0
         tap.__name__ = 'tap_' + name
-        prog.append((tap, ()))
+        prog.append((tap, None, -1))
 
     def _gemm(self, prog, X, K1, W, Y, M, N, bias=None, X2=None, K2=0, ln=None, add1=None, idx1=None, add2=None,
               idx2=None, scale=1.0, act=hip.ACT_NONE):
@@ -128,18 +161,19 @@ class Engine:
         self._keep += [s, seg_ids, a]
         self._call(prog, self.lib.pg_seg_attn, self.plan.topo_ref, C.byref(s))
 
-    def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None):
+    def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None, buf=0):
         """Shared tail of the four node-target sub-layers.  Y[:, col0 + 128*b] blocks: k_dst, v_dst, k_src, v_src, q_hid."""
         w, p, n = self.ws, self.plan, self.plan.n_ctx
+        wq, wU, wS, wsw = w.q[buf], w.U[buf], w.S[buf], w.swn[buf]
         blk = lambda b: Y[:, col0 + 128 * b: col0 + 128 * (b + 1)]
         # q = W2q . ReLU(LN(q_hid)) + b2q, scaled by 1/sqrt(head_dim)
-        self._gemm(prog, blk(4), 128, a.W2q, w.q, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
+        self._gemm(prog, blk(4), 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
         knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
         pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
         for seg_ids, n_seg, is_lig in h_dst_lists:
-            self._call(prog, self.lib.pg_attn_fold_query, w.q.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
-                       seg_ids.data_ptr(), w.U.data_ptr())
-            kw = dict(x=x, Cdst_k=blk(0), Cdst_v=blk(1), ld_cdst=Y.stride(0), U=w.U)
+            self._call(prog, self.lib.pg_attn_fold_query, wq.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
+                       seg_ids.data_ptr(), wU.data_ptr())
+            kw = dict(x=x, Cdst_k=blk(0), Cdst_v=blk(1), ld_cdst=Y.stride(0), U=wU)
             if knn:
                 kw.update(nrm=w.nrm, nbr=w.nbr, deg=w.deg, ew=w.ew, Csrc_k=blk(2), Csrc_v=blk(3), ld_csrc=Y.stride(0),
                           Wf_k=a.Wf_k[is_lig], Wf_v=a.Wf_v[is_lig])
@@ -150,10 +184,10 @@ class Engine:
             if pos:
                 kw.update(W2xv_l=a.W2xv_l, b2xv=a.b2xv, dx=dx, accumulate_dx=0)
             else:
-                kw.update(S=w.S, swn=w.swn)
+                kw.update(S=wS, swn=wsw)
             self._seg(prog, mode, n_seg, seg_ids, a, **kw)
             if not pos:
-                self._call(prog, self.lib.pg_attn_unfold_value, w.S.data_ptr(), w.swn.data_ptr(), a.W2v_l.data_ptr(),
+                self._call(prog, self.lib.pg_attn_unfold_value, wS.data_ptr(), wsw.data_ptr(), a.W2v_l.data_ptr(),
                            a.b2v.data_ptr(), n_seg, seg_ids.data_ptr(), out.data_ptr(), out.stride(0))
 
     # ------------------------------------------------------------------ phore encoder + count heads (per plan)
@@ -229,12 +263,16 @@ class Engine:
                        w.nrm.data_ptr())
             self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
             self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
-            # ---- node update over knn edges (:281)
-            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE)
-            # ---- node update over bond edges (:284)
+            self._fork(prog, (1, 2))
+            # ---- node update over knn edges (:281)                                    [lane 1]
+            self._lane = 1
+            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0)
+            # ---- node update over bond edges (:284)                                   [lane 2]
+            self._lane = 2
             self._gemm(prog, hbc, 128, L.NB.W_hb, w.CsB, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
-            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB)
-            # ---- bond update over triplets (:285)
+            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB, buf=1)
+            # ---- bond update over triplets (:285)                                     [lane 0]
+            self._lane = 0
             self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
                        add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
                        add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)
@@ -248,22 +286,31 @@ class Engine:
                       ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
                       W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks)
             self._event(prog, 'triplet', False)
+            self._join(prog, (1, 2))
             # ---- h' = h + lin_node(aggE + aggB) (:288)
             self._gemm(prog, w.aggE, 128, L.W_lin2, hn, n, 128, bias=L.b_lin, X2=w.aggB, K2=128, add1=hc)
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
             self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
-            self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe)
+            self._fork(prog, (1,))
+            self._lane = 1
+            self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
+            self._lane = 0
             self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
-            self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB)
+            self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1)
+            self._join(prog, (1,))
             self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
             self._mark(prog, f'L{li}', hn, hbn, xn, w.aggE, w.aggB, w.dxe, w.dxb, w.nrm, hbc)
             cur = nxt
         self.final_idx = cur
 
     def _run(self, prog):
-        s = hip.stream_ptr()
-        for fn, args in prog:
-            rc = fn(*args, s)
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = [torch.cuda.Stream(), torch.cuda.Stream()]
+        streams = [cur] + self._side
+        sp = [st.cuda_stream for st in streams]
+        for fn, args, lane in prog:
+            rc = fn(streams) if lane < 0 else fn(*args, sp[lane])
             if rc:
                 hip.check(rc, fn.__name__)
 

@@ -18,7 +18,7 @@ st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm']
                           torch.zeros(graphs, 3), rng='device', seed=0, return_traj=False, num_steps=2)
 model.reverse_step(st, 0, 999)
 eng = st.eng
-fn, args = eng.prog_fwd[eng.tri_calls[0]]
+fn, args, _lane = eng.prog_fwd[eng.tri_calls[0]]
 s = hip.stream_ptr()
 torch.cuda.synchronize()
 for _ in range(3):
