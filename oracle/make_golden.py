@@ -101,41 +101,7 @@ def build_model(seed=0):
     return m, cfg
 
 
-def synthetic_phore(gen, p, frac_ex=0.6):
-    """Feature layout of datasets/get_phore_data.py:55-69: 13 type one-hot | alpha | has_norm(2) | EX(2)."""
-    n_ex = int(round(p * frac_ex))
-    types = torch.cat([torch.randint(0, 12, (p - n_ex,), generator=gen), torch.full((n_ex,), 12)])
-    t1 = torch.nn.functional.one_hot(types, 13).float()
-    ex = torch.nn.functional.one_hot((types == 12).long(), 2).float()
-    alpha = 0.5 + torch.rand(p, 1, generator=gen)
-    has_norm = ((torch.rand(p, generator=gen) < 0.4) & (types != 12)).long()
-    hn = torch.nn.functional.one_hot(has_norm, 2).float()
-    norm = torch.randn(p, 3, generator=gen)
-    norm = norm / norm.norm(dim=-1, keepdim=True) * has_norm[:, None].float()
-    pos = 3.0 * torch.randn(p, 3, generator=gen)
-    pos = pos - pos.mean(0, keepdim=True)
-    return torch.cat([t1, alpha, hn, ex], -1), pos, norm
-
-
-def synthetic_batch(seed, n_atoms, n_phore, t_values):
-    """A synthetic PhoreDiff.forward input set (diffusion.py:175-178) for B=len(n_atoms) graphs."""
-    gen = torch.Generator().manual_seed(seed)
-    na = torch.tensor(n_atoms)
-    B = len(n_atoms)
-    batch_node = torch.repeat_interleave(torch.arange(B), na)
-    edge_index, batch_edge = make_edge_data(na)
-    N, E = int(na.sum()), edge_index.size(1)
-    h_node = torch.nn.functional.one_hot(torch.randint(0, 12, (N,), generator=gen), 12).float()
-    h_edge = torch.nn.functional.one_hot(torch.randint(0, 6, (E,), generator=gen), 6).float()
-    pos = 2.5 * torch.randn(N, 3, generator=gen)
-    hp, pp, pn, bp = [], [], [], []
-    for gi, p in enumerate(n_phore):
-        x, ps, nr = synthetic_phore(gen, p)
-        hp.append(x), pp.append(ps), pn.append(nr), bp.append(torch.full((p,), gi))
-    return dict(h_node_pert=h_node, pos_pert=pos, batch_node=batch_node, h_edge_pert=h_edge,
-                edge_index=edge_index, batch_edge=batch_edge, time_step=torch.tensor(t_values),
-                h_phore=torch.cat(hp), pos_phore=torch.cat(pp), phore_norm=torch.cat(pn),
-                batch_phore=torch.cat(bp))
+from oracle.make_inputs import synthetic_batch, synthetic_phore  # noqa: E402  (shared with tests / bench)
 
 
 # --------------------------------------------------------------------------------------------
@@ -331,8 +297,17 @@ def g_posterior(model):
     save('g_posterior', **arrays)
 
 
+def g8_phore_parse():
+    """datasets/get_phore_data.py:24-105 on a shipped pharmacophore file, no transform: the input side of `sample`."""
+    path = os.path.join(ref_import.REFERENCE, 'data/phores_for_sampling/P03211_merge.phore')
+    d = PhoreData_New([path])[0]
+    save('g8_phore_parse', file_text=np.frombuffer(open(path, 'rb').read(), dtype=np.uint8), x=d['phore'].x,
+         pos=d['phore'].pos, norm=d['phore'].norm, center=d.center)
+
+
 if __name__ == '__main__':
     g1_ops()
+    g8_phore_parse()
     model, cfg = build_model(seed=0)
     g7_manifest(model)
     g4_tables(model)

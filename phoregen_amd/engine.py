@@ -263,7 +263,7 @@ class Engine:
                        w.nrm.data_ptr())
             self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
             self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
-            self._fork(prog, (1, 2))
+            self._fork(prog, (1, 2, 3))
             # ---- node update over knn edges (:281)                                    [lane 1]
             self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0)
@@ -276,9 +276,12 @@ class Engine:
             self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
                        add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
                        add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)
+            self._lane = 3                                                              # triplet queries [lane 3]
             self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
             self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
                        scale=HEAD_SCALE)
+            self._lane = 0
+            self._join(prog, (3,))
             a = L.TB
             self._event(prog, 'triplet', True)
             self.tri_calls.append(len(prog))
@@ -306,7 +309,7 @@ class Engine:
     def _run(self, prog):
         cur = torch.cuda.current_stream()
         if self._side is None:
-            self._side = [torch.cuda.Stream(), torch.cuda.Stream()]
+            self._side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
         streams = [cur] + self._side
         sp = [st.cuda_stream for st in streams]
         for fn, args, lane in prog:

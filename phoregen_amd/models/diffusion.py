@@ -133,15 +133,18 @@ class PhoreDiff(nn.Module):
     # ------------------------------------------------------------------ sampler (diffusion.py:390-525)
     @torch.no_grad()
     def sample(self, data, n_graphs, device, pos_guidance_opt=None, sample_mode='uniform', normal_scale=4.0,
-               rng='cpu', seed=0, num_atoms=None, return_traj=True, **kwargs):
+               rng='device', seed=None, num_atoms=None, return_traj=True, **kwargs):
         """Reference contract: returns {'pred': [logits_node, x0 + center, logits_edge],
         'traj': [node, pos, edge], 'lig_info': [num_atoms, batch, edge_index, edge_batch]}.
 
+        rng='device': (default, like the reference on a GPU) counter-based Philox inside the transition kernels, no host
+                      traffic in the loop; `seed` defaults to torch.initial_seed(), so `seed_all(seed)` still controls it.
         rng='cpu'   : noise is drawn from torch's default CPU generator in the reference's order, shape and dtype
                        and uploaded -> same seeds give the reference CPU path's draws.
-        rng='device': counter-based Philox inside the transition kernels (no host traffic in the loop).
         num_atoms   : optional LongTensor [n_graphs] overriding the atom-count draw (tests / benchmarks)."""
         ph = data['phore']
+        if seed is None:
+            seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
         if num_atoms is None:
             num_atoms = self.sample_nodes(data, n_graphs, device, sample_mode, normal_scale)
         p = ph.x.size(0)

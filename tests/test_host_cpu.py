@@ -156,3 +156,15 @@ def test_factored_first_layer_algebra(model):
     feat = torch.cat([torch.zeros(20, dtype=torch.float64), sm, dots, torch.tensor([0., 1., 0., 0., 0.], dtype=torch.float64)])
     mine = Wfe @ feat + W1[:, 93:221] @ hd + b1 + W1[:, 84:93] @ bd + W1[:, 221:349] @ hs
     assert torch.allclose(mine, ref, atol=1e-10)
+
+
+def test_phore_parser_matches_reference(tmp_path):
+    """phoregen_amd.data.parse_phore_file against datasets/get_phore_data.py run on a shipped .phore file."""
+    from phoregen_amd.data import parse_phore_file
+    g = golden('g8_phore_parse')
+    f = tmp_path / 'P03211_merge.phore'
+    f.write_bytes(g['file_text'].tobytes())
+    d = parse_phore_file(str(f))
+    assert np.array_equal(d['phore'].x.numpy(), g['x']) and np.array_equal(d['phore'].norm.numpy(), g['norm'])
+    assert np.allclose(d['phore'].pos.numpy(), g['pos'], rtol=0, atol=1e-6) and np.allclose(d.center.numpy(), g['center'], atol=1e-6)
+    assert d.name == 'P03211_merge'

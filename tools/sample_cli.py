@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Thin sampling driver with sample_all.py's flags (the reference's script cannot travel to the GPU box and its
+RDKit/OpenBabel post-processing is out of scope): .phore files -> PhoreDiff.sample -> per-molecule tensors (.pt).
+
+  python tools/sample_cli.py --phore_file_list files.json --num_samples 100 --batch_size 30 --outdir results/x
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phoregen_amd.config import default_model_config, load_config  # noqa: E402
+from phoregen_amd.data import parse_phore_file  # noqa: E402
+from phoregen_amd.models.diffusion import PhoreDiff  # noqa: E402
+from phoregen_amd.weights import init_deterministic_  # noqa: E402
+
+
+def unbatch(results, n_graphs):
+    """Per-graph views of `pred` (+ final trajectory frame), the contract of utils/sample_utils.py:57-93."""
+    bn, ei, be = results['lig_info'][1], results['lig_info'][2], results['lig_info'][3]
+    out = []
+    for g in range(n_graphs):
+        mn, me = bn == g, be == g
+        first = int(mn.nonzero()[0])
+        out.append({'pred': [results['pred'][0][mn], results['pred'][1][mn], results['pred'][2][me]],
+                    'edge_index': ei[:, me] - first})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', type=str, default=None, help='reference YAML (model: block); default = shipped values')
+    ap.add_argument('--num_samples', type=int, default=100)
+    ap.add_argument('--batch_size', type=int, default=30)
+    ap.add_argument('--outdir', type=str, default='./results/test')
+    ap.add_argument('--check_point', type=str, default=None, help="torch checkpoint with a 'model' state_dict")
+    ap.add_argument('--phore_file_list', type=str, required=True, help='json list of .phore files')
+    ap.add_argument('--pos_guidance_opt', type=json.loads, default=None)
+    ap.add_argument('--sample_nodes_mode', type=str, default='uniform')
+    ap.add_argument('--normal_scale', type=float, default=4.0)
+    ap.add_argument('--seed', type=int, default=2032)
+    ap.add_argument('--rng', type=str, default='device', choices=['device', 'cpu'])
+    args = ap.parse_args()
+    torch.manual_seed(args.seed)
+    cfg = default_model_config()
+    if args.config:
+        full = load_config(args.config)
+        cfg = full.model
+        if full.dataset.data_name in ('zinc_300', 'pdbbind'):
+            cfg.phore_feat_dim += 2
+    model = PhoreDiff(cfg, 'zinc_300')
+    if args.check_point:
+        model.load_state_dict(torch.load(args.check_point, map_location='cpu')['model'])
+    else:
+        print('[W] no --check_point: deterministic synthetic weights (molecules will be noise)')
+        init_deterministic_(model, 0)
+    model = model.eval().to('cuda')
+    os.makedirs(args.outdir, exist_ok=True)
+    files = json.load(open(args.phore_file_list))
+    for f in files:
+        data = parse_phore_file(f).to('cuda')
+        done, t0 = [], time.time()
+        while len(done) < args.num_samples:
+            n = min(args.batch_size, args.num_samples - len(done))
+            res = model.sample(data, n, 'cuda', pos_guidance_opt=args.pos_guidance_opt, sample_mode=args.sample_nodes_mode,
+                               normal_scale=args.normal_scale, rng=args.rng, return_traj=False)
+            res = {k: [v.cpu() if torch.is_tensor(v) else v for v in vals] for k, vals in res.items()}
+            done += unbatch(res, n)
+        torch.save(done, os.path.join(args.outdir, data.name + '.pt'))
+        print(f'{data.name}: {len(done)} samples in {time.time() - t0:.1f} s')
+
+
+if __name__ == '__main__':
+    main()
