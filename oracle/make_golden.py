@@ -305,9 +305,34 @@ def g8_phore_parse():
          pos=d['phore'].pos, norm=d['phore'].norm, center=d.center)
 
 
+def g9_unbatch_decode():
+    """utils/sample_utils.py:57-132 (unbatch_data / decode_data) on a seeded synthetic result dict with two masked atoms."""
+    from utils.sample_utils import decode_data, unbatch_data
+    g = torch.Generator().manual_seed(9)
+    na = torch.tensor([5, 3, 6])
+    N = int(na.sum())
+    ei, eb = make_edge_data(na)
+    E = ei.size(1)
+    bn = torch.repeat_interleave(torch.arange(3), na)
+    pred = [torch.randn(N, 12, generator=g), torch.randn(N, 3, generator=g), torch.randn(E, 6, generator=g)]
+    pred[0][2, 11] = 9.0
+    pred[0][9, 11] = 9.0
+    traj = [torch.randn(4, N, 12, generator=g), torch.randn(4, N, 3, generator=g), torch.randn(4, E, 6, generator=g)]
+    outs = unbatch_data({'pred': pred, 'traj': traj, 'lig_info': [na, bn, ei, eb]}, 3, include_bond=True)
+    arr = dict(na=na, ei=ei, eb=eb, bn=bn)
+    arr.update({f'pred{i}': t for i, t in enumerate(pred)})
+    arr.update({f'traj{i}': t for i, t in enumerate(traj)})
+    for gi, o in enumerate(outs):
+        d = decode_data(o['pred'], o['edge_index'], include_bond=True)
+        arr.update({f'g{gi}_edge_index': o['edge_index'], f'g{gi}_traj1': o['traj'][1], f'g{gi}_element': np.array(d['element']),
+                    f'g{gi}_atom_pos': d['atom_pos'], f'g{gi}_bond_type': d['bond_type'], f'g{gi}_bond_index': d['bond_index']})
+    save('g9_unbatch_decode', **arr)
+
+
 if __name__ == '__main__':
     g1_ops()
     g8_phore_parse()
+    g9_unbatch_decode()
     model, cfg = build_model(seed=0)
     g7_manifest(model)
     g4_tables(model)

@@ -18,3 +18,44 @@ def get_fully_connected_edge(num_nodes):
     """utils/sample_utils.py:20-25 (self pairs kept)."""
     a = torch.arange(num_nodes)
     return torch.stack([torch.repeat_interleave(a, num_nodes), a.repeat(num_nodes)], 0)
+
+
+# ---- device -> host hand-off (reference: utils/sample_utils.py:57-132, sample_all.py:104-116) ----------------------
+ATOM_TYPES = [5, 6, 7, 8, 9, 14, 15, 16, 17, 35, 53]      # class 11 = masked atom (sample_utils.py:17)
+
+
+def unbatch_data(results, n_graphs, include_bond=True):
+    """Same contract as utils/sample_utils.py:57-93: per graph {'pred': [...], 'traj': [...], 'edge_index': local ids}.
+    Graphs are contiguous in the sampler's output, so this slices by offsets (one pass) instead of building
+    n_graphs boolean masks over every tensor; `traj` entries are views of the [T+1, N, .] trajectory tensors."""
+    pred, traj = results['pred'], results['traj']
+    num_atoms, edge_index = results['lig_info'][0], results['lig_info'][2]
+    na = [int(v) for v in num_atoms.tolist()]
+    out, n0, e0 = [], 0, 0
+    for n in na[:n_graphs]:
+        e = n * (n - 1)
+        p = [pred[0][n0:n0 + n], pred[1][n0:n0 + n]]
+        t = [traj[0][:, n0:n0 + n], traj[1][:, n0:n0 + n]] if traj[0] is not None else [None, None]
+        if include_bond:
+            p.append(pred[2][e0:e0 + e])
+            t.append(traj[2][:, e0:e0 + e] if traj[2] is not None else None)
+        out.append({'pred': p, 'traj': t, 'edge_index': edge_index[:, e0:e0 + e] - n0})
+        n0, e0 = n0 + n, e0 + e
+    return out
+
+
+def decode_data(pred_info, edge_index, include_bond=True, num_bond_types=5):
+    """Same contract as utils/sample_utils.py:96-132: argmax types, masked atoms (class 11) and their bonds dropped."""
+    atom_type = pred_info[0].argmax(dim=-1)                       # softmax is monotone: argmax(logits)
+    keep = atom_type < len(ATOM_TYPES)
+    remap = torch.full((keep.numel(),), -1, dtype=torch.long, device=keep.device)
+    remap[keep] = torch.arange(int(keep.sum()), device=keep.device)
+    out = {'element': [ATOM_TYPES[i] for i in atom_type[keep].tolist()], 'atom_pos': pred_info[1][keep],
+           'bond_type': None, 'bond_index': None}
+    if include_bond:
+        edge_type = pred_info[2].argmax(dim=-1)
+        is_bond = (edge_type > 0) & (edge_type < num_bond_types)
+        bond_index = remap[edge_index[:, is_bond]]
+        ok = (bond_index >= 0).all(dim=0)
+        out['bond_type'], out['bond_index'] = edge_type[is_bond][ok], bond_index[:, ok]
+    return out

@@ -168,3 +168,20 @@ def test_phore_parser_matches_reference(tmp_path):
     assert np.array_equal(d['phore'].x.numpy(), g['x']) and np.array_equal(d['phore'].norm.numpy(), g['norm'])
     assert np.allclose(d['phore'].pos.numpy(), g['pos'], rtol=0, atol=1e-6) and np.allclose(d.center.numpy(), g['center'], atol=1e-6)
     assert d.name == 'P03211_merge'
+
+
+def test_unbatch_and_decode_match_reference():
+    from phoregen_amd.utils.sample_utils import decode_data, unbatch_data
+    g = golden('g9_unbatch_decode')
+    res = {'pred': [torch.as_tensor(g[f'pred{i}']) for i in range(3)],
+           'traj': [torch.as_tensor(g[f'traj{i}']) for i in range(3)],
+           'lig_info': [torch.as_tensor(g['na']), torch.as_tensor(g['bn']), torch.as_tensor(g['ei']), torch.as_tensor(g['eb'])]}
+    outs = unbatch_data(res, 3)
+    for gi, o in enumerate(outs):
+        assert np.array_equal(o['edge_index'].numpy(), g[f'g{gi}_edge_index'])
+        assert np.array_equal(o['traj'][1].numpy(), g[f'g{gi}_traj1'])
+        d = decode_data(o['pred'], o['edge_index'])
+        assert d['element'] == g[f'g{gi}_element'].tolist()
+        assert np.array_equal(d['atom_pos'].numpy(), g[f'g{gi}_atom_pos'])
+        assert np.array_equal(d['bond_type'].numpy(), g[f'g{gi}_bond_type'])
+        assert np.array_equal(d['bond_index'].numpy(), g[f'g{gi}_bond_index'])
