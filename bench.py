@@ -125,12 +125,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(os.environ.get('PG_DIST_BACKEND', 'nccl'))    # nccl == RCCL on ROCm
     local = local % max(torch.cuda.device_count(), 1)     # (a 2-rank gloo dry run can share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(os.environ.get('PG_DIST_BACKEND', 'nccl'))    # nccl == RCCL on ROCm
 
     from phoregen_amd.config import default_model_config
     from phoregen_amd.models.diffusion import PhoreDiff
