@@ -90,10 +90,12 @@ int pg_knn_ctx(const PgTopo* t, const float* x_ctx, int k, int* nbr, int* deg, v
 int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* phore_norm, const int* phore2ctx,
                    float* nrm, void* stream);
 
-/* global edge gate e_w = sigmoid(MLP(smear(dist)))  (uni_denoiser.py:410-415) */
+/* global edge gate e_w = sigmoid(MLP(smear(dist)))  (uni_denoiser.py:410-415); weights in kernel layout
+ * (phoregen_amd/packing.py pack_gate): W0 = lane-fixed centred/sign-normalised first layer [5][8][64], b0 = its bias
+ * [128], gamma unused, beta = beta/|gamma| [128], W3 = last-layer row times |gamma| [128] */
 int pg_edge_gate(const PgTopo* t, const float* x_ctx, const int* nbr, const int* deg, int k,
-                 const float* W0 /*[128,20]*/, const float* b0, const float* gamma, const float* beta,
-                 const float* W3 /*[128]*/, float b3, float* ew /*[n_ctx,k]*/, void* stream);
+                 const float* W0, const float* b0, const float* gamma, const float* beta,
+                 const float* W3, float b3, float* ew /*[n_ctx,k]*/, void* stream);
 
 /* per-bond Gaussian smearing of the bond length: G[e, 0:20] (uni_denoiser.py:128,137) */
 int pg_bond_smear(const PgTopo* t, const float* x_ctx, float* G /*[n_bond,20]*/, void* stream);

@@ -155,43 +155,64 @@ __global__ __launch_bounds__(256) void lig_normals_kernel(PgTopo t, const float*
 
 // ------------------------------------------------------------------------------------------------
 // global edge gate  e_w = sigmoid(W3 . ReLU(LN(W0 . smear(d) + b0)) + b3)   (uni_denoiser.py:410-415)
-// one wave per (node, slot); lane owns hidden units lane and lane+64
+// one wave per node, its k neighbour slots in tiles of 16 rows; hidden^T[c,row] by 5 K-steps of 16x16x4 MFMA
+// (A = lane-fixed first-layer weights, B = the 20 Gaussians of the row), LayerNorm folded as in packing._kv_mlp.
+// Arguments are in kernel layout (packing.pack_gate): Wl [5][8][64], b1c [128] centred+signed bias, bp = beta/|gamma|,
+// w3g = W3 * |gamma|.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void edge_gate_kernel(int n_ctx, const float* x, const int* nbr, const int* deg,
-                                                        int k, const float* W0, const float* b0, const float* gamma,
-                                                        const float* beta, const float* W3, float b3, float* ew) {
-  const int lane = threadIdx.x & 63;
-  float w0[2][20];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int i = 0; i < 20; ++i) w0[u][i] = W0[(lane + 64 * u) * 20 + i];
-  const float bb[2] = {b0[lane], b0[lane + 64]}, gg[2] = {gamma[lane], gamma[lane + 64]},
-              be[2] = {beta[lane], beta[lane + 64]}, w3[2] = {W3[lane], W3[lane + 64]};
-  const long total = (long)n_ctx * k;
-  for (long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (long)gridDim.x * 4) {
-    const int node = (int)(e / k), slot = (int)(e % k);
-    if (slot >= deg[node]) {
-      if (lane == 0) ew[e] = 0.f;
-      continue;
+                                                        int k, const float* Wl, const float* b1c, const float* bp,
+                                                        const float* w3g, float b3, float* ew) {
+  __shared__ __attribute__((aligned(16))) float wl[5 * 512];
+  __shared__ __attribute__((aligned(16))) float cst[3 * 128];
+  for (int i = threadIdx.x; i < 5 * 512; i += 256) wl[i] = Wl[i];
+  for (int i = threadIdx.x; i < 128; i += 256) { cst[i] = b1c[i]; cst[128 + i] = bp[i]; cst[256 + i] = w3g[i]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= n_ctx) return;
+  const int dg = deg[node];
+  const float x0 = x[node * 3], x1 = x[node * 3 + 1], x2 = x[node * 3 + 2];
+  for (int tile = 0; tile * 16 < k; ++tile) {
+    const int row = tile * 16 + m;
+    float d = 0.f;
+    const bool valid = row < dg;
+    if (valid) {
+      const int src = nbr[(size_t)node * k + row];
+      const float r0 = x0 - x[src * 3], r1 = x1 - x[src * 3 + 1], r2 = x2 - x[src * 3 + 2];
+      d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
     }
-    const int src = nbr[e];
-    const float dx = x[node * 3] - x[src * 3], dy = x[node * 3 + 1] - x[src * 3 + 1], dz = x[node * 3 + 2] - x[src * 3 + 2];
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-    float h[2] = {bb[0], bb[1]};
+    f4 hid[8];
 #pragma unroll
-    for (int i = 0; i < 20; ++i) {
-      const float s = smear(d, i);
-      h[0] += w0[0][i] * s;
-      h[1] += w0[1][i] * s;
+    for (int tq = 0; tq < 8; ++tq) hid[tq] = *reinterpret_cast<const f4*>(cst + 16 * tq + 4 * g);
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const float f = smear(d, 4 * st + g);
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wl[(st * 8 + tq) * 64 + lane], f, hid[tq]);
     }
-    const float mu = wave_sum(h[0] + h[1]) * (1.f / 128.f);
-    const float d0 = h[0] - mu, d1 = h[1] - mu;
-    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
-    const float rs = 1.0f / sqrtf(var + 1e-5f);
-    const float z0 = fmaxf(d0 * rs * gg[0] + be[0], 0.f), z1 = fmaxf(d1 * rs * gg[1] + be[1], 0.f);
-    const float o = wave_sum(z0 * w3[0] + z1 * w3[1]) + b3;
-    if (lane == 0) ew[e] = 1.f / (1.f + expf(-o));
+    float q = 0.f;
+#pragma unroll
+    for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q = fmaf(hid[tq][r], hid[tq][r], q);
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    const float var = q * (1.f / 128.f) + 1e-5f;
+    const float rs = 1.0f / sqrtf(var);
+    const float sigma = var * rs;
+    float dot = 0.f;
+#pragma unroll
+    for (int tq = 0; tq < 8; ++tq) {
+      const f4 bt = *reinterpret_cast<const f4*>(cst + 128 + 16 * tq + 4 * g);
+      const f4 w3 = *reinterpret_cast<const f4*>(cst + 256 + 16 * tq + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dot = fmaf(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), w3[r], dot);
+    }
+    dot += __shfl_xor(dot, 16);
+    dot += __shfl_xor(dot, 32);
+    const float o = dot * rs + b3;
+    if (g == 0 && row < k) ew[(size_t)node * k + row] = valid ? 1.f / (1.f + expf(-o)) : 0.f;
   }
 }
 
@@ -276,10 +297,9 @@ extern "C" int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* 
 extern "C" int pg_edge_gate(const PgTopo* t, const float* x_ctx, const int* nbr, const int* deg, int k, const float* W0,
                             const float* b0, const float* gamma, const float* beta, const float* W3, float b3,
                             float* ew, void* stream) {
-  const long total = (long)t->n_ctx * k;
-  const int blocks = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
-  hipLaunchKernelGGL(edge_gate_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t->n_ctx, x_ctx, nbr, deg, k,
-                     W0, b0, gamma, beta, W3, b3, ew);
+  (void)gamma;
+  hipLaunchKernelGGL(edge_gate_kernel, dim3((t->n_ctx + 3) / 4), dim3(256), 0, (hipStream_t)stream, t->n_ctx, x_ctx, nbr,
+                     deg, k, W0, b0, beta, W3, b3, ew);
   return check_launch("pg_edge_gate");
 }
 

@@ -369,9 +369,7 @@ def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, b
 
 class _DenoiserOnlyPack(ModelPack):
     def __init__(self, sd, num_layers):
-        from .packing import LayerPack, _mlp
+        from .packing import LayerPack, pack_gate
         sd = {k: v.detach() for k, v in sd.items()}
         self.layers = [LayerPack(sd, f'denoiser.base_block.{l}') for l in range(num_layers)]
-        g = _mlp(sd, 'denoiser.edge_pred_layer')
-        self.gate = dict(W0=g['W1'].contiguous(), b0=g['b1'].contiguous(), g=g['g'], b=g['b'],
-                         W3=g['W2'].reshape(-1).contiguous(), b3=float(g['b2'].reshape(-1)[0]))
+        self.gate = pack_gate(sd)

@@ -199,6 +199,13 @@ class LayerPack:
         self.b_lin = sd[p + '.lin_node.bias'].contiguous()
 
 
+def pack_gate(sd, p='denoiser.edge_pred_layer'):
+    """Global edge gate MLP (20 -> 128 -> LN -> ReLU -> 1) in the folded form of _kv_mlp, kernel layout of pg_edge_gate."""
+    m = _kv_mlp(sd, p)
+    return dict(W0=lane_fixed_feat(m['W1']), b0=m['b1'], g=m['bp'], b=m['bp'], W3=m['W2'].reshape(-1).contiguous(),
+                b3=float(m['b2'].reshape(-1)[0]))
+
+
 class ModelPack:
     """All kernel-layout weights of a PhoreDiff state_dict (tensors must already be on the GPU)."""
 
@@ -207,9 +214,7 @@ class ModelPack:
         self.layers = [LayerPack(sd, f'denoiser.base_block.{l}') for l in range(num_layers)]
         self.PH, b_ph = pack_phore(sd)
         self.W_ph, self.b_ph = fuse_blocks(b_ph)                           # [640,128]
-        g = _mlp(sd, 'denoiser.edge_pred_layer')
-        self.gate = dict(W0=g['W1'].contiguous(), b0=g['b1'].contiguous(), g=g['g'], b=g['b'],
-                         W3=g['W2'].reshape(-1).contiguous(), b3=float(g['b2'].reshape(-1)[0]))
+        self.gate = pack_gate(sd)
         c = lambda k: sd[k].contiguous()
         self.W_node_emb, self.W_edge_emb = c('node_embedder.weight'), c('edge_embedder.weight')
         self.t_off, self.t_coeff = c('time_emb.0.offset'), c('time_emb.0.coeff')
