@@ -316,3 +316,72 @@ def test_device_rng_sampler_runs_and_is_reproducible(model):
     assert torch.equal(a['traj'][0], b['traj'][0]) and torch.equal(a['traj'][1], b['traj'][1])
     assert not torch.equal(a['traj'][1], c['traj'][1])
     assert torch.isfinite(a['pred'][1]).all() and a['traj'][0].sum(-1).eq(1).all()
+
+
+def _headline_inputs(n_graphs=128, seed=1234):
+    """PhoreDiff.forward inputs of the benchmark workload (BASELINE.json config 3) at an early reverse step."""
+    import torch.nn.functional as F
+    from bench import ligphore_workload
+    from phoregen_amd.plan import make_edge_data
+    w = ligphore_workload(n_graphs, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    na = w['num_atoms']
+    N = int(na.sum())
+    ei, be = make_edge_data(na)
+    return dict(h_node_pert=F.one_hot(torch.randint(0, 12, (N,), generator=g), 12).float(),
+                pos_pert=3.0 * torch.randn(N, 3, generator=g), batch_node=torch.repeat_interleave(torch.arange(n_graphs), na),
+                h_edge_pert=F.one_hot(torch.randint(0, 6, (ei.size(1),), generator=g), 6).float(), edge_index=ei,
+                batch_edge=be, time_step=torch.randint(0, 1000, (n_graphs,), generator=g), h_phore=w['h_phore'],
+                pos_phore=w['pos_phore'], phore_norm=w['phore_norm'], batch_phore=w['batch_phore']), na, w['n_phore']
+
+
+def _slice_graph(inp, na, nph, gi):
+    n0, p0 = int(na[:gi].sum()), int(nph[:gi].sum())
+    n, p = int(na[gi]), int(nph[gi])
+    e0 = int((na[:gi] * (na[:gi] - 1)).sum())
+    e = n * (n - 1)
+    return dict(h_node_pert=inp['h_node_pert'][n0:n0 + n], pos_pert=inp['pos_pert'][n0:n0 + n],
+                batch_node=torch.zeros(n, dtype=torch.long), h_edge_pert=inp['h_edge_pert'][e0:e0 + e],
+                edge_index=inp['edge_index'][:, e0:e0 + e] - n0, batch_edge=torch.zeros(e, dtype=torch.long),
+                time_step=inp['time_step'][gi:gi + 1], h_phore=inp['h_phore'][p0:p0 + p], pos_phore=inp['pos_phore'][p0:p0 + p],
+                phore_norm=inp['phore_norm'][p0:p0 + p], batch_phore=torch.zeros(p, dtype=torch.long)), (n0, n, e0, e)
+
+
+def test_full_size_batch_equals_single_graph_runs(model, oracle):
+    """Size-independent property at BASELINE's full size (128 graphs): graphs are independent, so every graph's slice of
+    the batched result must equal the result of running that graph alone (this is also why per-graph sharding over GPUs
+    is exact), and a single-graph run is small enough to check against the oracle."""
+    inp, na, nph = _headline_inputs()
+    with torch.no_grad():
+        out = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in inp.items()})[:3]]
+        for gi in (0, 57, 127):
+            one, (n0, n, e0, e) = _slice_graph(inp, na, nph, gi)
+            alone = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in one.items()})[:3]]
+            assert rel_err(out[0][n0:n0 + n], alone[0]) <= 1e-6
+            assert rel_err(out[1][n0:n0 + n], alone[1]) <= 1e-6
+            assert rel_err(out[2][e0:e0 + e], alone[2]) <= 1e-6
+            if gi == 57:
+                ref = oracle.forward(**one)
+                errs = [rel_err(alone[i], ref[i]) for i in range(3)]
+                assert max(errs) <= TOL, errs
+    assert all(torch.isfinite(o).all() for o in out)
+
+
+def test_full_size_e3_equivariance(model):
+    """Rigid motion of ligand + pharmacophore (positions and direction vectors) at full size: type logits invariant,
+    predicted coordinates co-rotate (the denoiser is E(3)-equivariant by construction, uni_denoiser.py:260-298)."""
+    inp, na, nph = _headline_inputs(32, seed=77)
+    g = torch.Generator().manual_seed(3)
+    Q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    if torch.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    tvec = torch.tensor([1.5, -2.0, 0.7])
+    moved = dict(inp)
+    moved['pos_pert'] = inp['pos_pert'] @ Q.t() + tvec
+    moved['pos_phore'] = inp['pos_phore'] @ Q.t() + tvec
+    moved['phore_norm'] = inp['phore_norm'] @ Q.t()
+    with torch.no_grad():
+        a = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in inp.items()})[:3]]
+        b = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in moved.items()})[:3]]
+    assert rel_err(b[0], a[0]) <= 1e-4 and rel_err(b[2], a[2]) <= 1e-4
+    assert rel_err(b[1], a[1] @ Q.t() + tvec) <= 1e-4
