@@ -32,7 +32,7 @@ int pg_abi_version(void);
 int pg_selftest_mfma(int* d_result, void* stream);
 
 /* ---- dense linear layers -------------------------------------------------------------------
- * Y[r, n] = out_scale * act( sum_k Xcat[r,k] * W[n,k] + bias[n] + add1[i1(r), n] + add2[i2(r), n] )
+ * Y[R, n] = out_scale * act( sum_k Xcat[R,k] * W[n,k] + bias[n] + add1[i1(r), n] + add2[i2(r), n] ),  R = rows ? rows[r] : r
  * Xcat = [X | X2] along k; if ln_gamma != NULL, X rows first go through LayerNorm(K1, eps 1e-5)+ReLU.
  * Replaces nn.Linear / MLP second halves (models/common.py:99-119), the per-node / per-edge halves
  * of the first MLP layer that the reference computes on concatenated gathers
@@ -49,6 +49,7 @@ typedef struct {
   float out_scale;
   int   act;                 /* 0 none, 1 shifted softplus (models/common.py:58-64), 2 ReLU */
   float* Y; int ldy; int M; int N;
+  const int* rows;           /* optional [M]: logical row r reads X/X2 row rows[r] and writes Y row rows[r] (row subset) */
 } PgGemm;
 int pg_gemm(const PgGemm* p, void* stream);
 

@@ -32,11 +32,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
     const int sub = tid & 7;
     for (int r = tid >> 3; r < BM; r += 32) {
       const int grow = row0 + r;
+      const int prow = (p.rows && grow < p.M) ? p.rows[grow] : grow;
       f4 v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         v[i] = (f4){0.f, 0.f, 0.f, 0.f};
-        if (grow < p.M) v[i] = *reinterpret_cast<const f4*>(p.X + (size_t)grow * p.ldx + (i * 8 + sub) * 4);
+        if (grow < p.M) v[i] = *reinterpret_cast<const f4*>(p.X + (size_t)prow * p.ldx + (i * 8 + sub) * 4);
       }
       float s = 0.f;
 #pragma unroll
@@ -74,17 +75,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
     for (int i = 0; i < 4; ++i) {
       const int r = (tid >> 3) + 32 * i, kq = (tid & 7) * 4, kk = k0 + kq;
       const int grow = row0 + r;
+      const int prow = (p.rows && grow < p.M) ? p.rows[grow] : grow;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (grow < p.M && !(ablate & 1)) {
         if (fastX && kk + 3 < p.K1) {
-          const float4 t = *reinterpret_cast<const float4*>(p.X + (size_t)grow * p.ldx + kk);
+          const float4 t = *reinterpret_cast<const float4*>(p.X + (size_t)prow * p.ldx + kk);
           v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int k = kk + j;
-            if (k < p.K1) v[j] = p.X[(size_t)grow * p.ldx + k];
-            else if (k < K) v[j] = p.X2[(size_t)grow * p.ldx2 + (k - p.K1)];
+            if (k < p.K1) v[j] = p.X[(size_t)prow * p.ldx + k];
+            else if (k < K) v[j] = p.X2[(size_t)prow * p.ldx2 + (k - p.K1)];
           }
         }
         if (ln) {
@@ -158,8 +160,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
       const int grow = row0 + half * 64 + r, gcol = col0 + c4;
       if (grow >= p.M || gcol >= p.N || ((ablate & 4) && r != 0)) continue;
       f4 v = *reinterpret_cast<const f4*>(Cs + r * LDC + c4);
-      const int a1 = p.add1 ? (p.idx1 ? p.idx1[grow] : grow) : 0;
-      const int a2 = p.add2 ? (p.idx2 ? p.idx2[grow] : grow) : 0;
+      const int prow = p.rows ? p.rows[grow] : grow;
+      const int a1 = p.add1 ? (p.idx1 ? p.idx1[grow] : prow) : 0;
+      const int a2 = p.add2 ? (p.idx2 ? p.idx2[grow] : prow) : 0;
       if (vec_ok) {
         if (p.bias) v += *reinterpret_cast<const f4*>(p.bias + gcol);
         if (p.add1) v += *reinterpret_cast<const f4*>(p.add1 + (size_t)a1 * p.ld_add1 + gcol);
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
           else if (p.act == 2) v[j] = fmaxf(v[j], 0.f);
           v[j] *= p.out_scale;
         }
-        *reinterpret_cast<f4*>(p.Y + (size_t)grow * p.ldy + gcol) = v;
+        *reinterpret_cast<f4*>(p.Y + (size_t)prow * p.ldy + gcol) = v;
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
           if (p.add2) x += p.add2[(size_t)a2 * p.ld_add2 + gcol + j];
           if (p.act == 1) x = ssp(x);
           else if (p.act == 2) x = fmaxf(x, 0.f);
-          p.Y[(size_t)grow * p.ldy + gcol + j] = x * p.out_scale;
+          p.Y[(size_t)prow * p.ldy + gcol + j] = x * p.out_scale;
         }
       }
     }
@@ -381,7 +384,7 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   const bool al = (p->ldx & 3) == 0 && ((size_t)p->X & 15) == 0 && (p->ldw & 3) == 0 && ((size_t)p->W & 15) == 0 &&
                   (p->K1 & 3) == 0 && (p->K2 & 3) == 0 && (!p->K2 || ((p->ldx2 & 3) == 0 && ((size_t)p->X2 & 15) == 0));
   // (measured, tools/bench_gemm.py: a clear win for the LayerNorm-on-load form, a wash or slightly worse otherwise)
-  if (p->M >= 32768 && al && p->N <= 256 && p->ln_gamma && !getenv("PG_GEMM_TILED")) {
+  if (p->M >= 32768 && al && p->N <= 256 && p->ln_gamma && !p->rows && !getenv("PG_GEMM_TILED")) {
     if (K == 128) return pg::launch_ws<129>(p, (hipStream_t)stream);
     if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
   }

@@ -37,6 +37,7 @@ class Engine:
         # independent sub-layer chains of a layer run on side streams ("lanes" 1, 2) next to the triplet chain (lane 0):
         # kernels of different chains interleave on the CUs, so one chain's load/store phases meet another's MFMA phases
         self.multi_stream = os.environ.get('PG_STREAMS', '1') != '0'
+        self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
         self._lane = 0
         self._side = None
         self._alloc()
@@ -136,7 +137,7 @@ class Engine:
         prog.append((tap, None, -1))
 
     def _gemm(self, prog, X, K1, W, Y, M, N, bias=None, X2=None, K2=0, ln=None, add1=None, idx1=None, add2=None,
-              idx2=None, scale=1.0, act=hip.ACT_NONE):
+              idx2=None, scale=1.0, act=hip.ACT_NONE, rows=None):
         g = hip.PgGemm()
         g.X, g.ldx, g.K1 = X.data_ptr(), X.stride(0), K1
         g.X2, g.ldx2, g.K2 = (X2.data_ptr(), X2.stride(0), K2) if X2 is not None else (None, 0, 0)
@@ -147,7 +148,8 @@ class Engine:
         g.add2, g.ld_add2, g.idx2 = (add2.data_ptr(), add2.stride(0), hip.ptr(idx2)) if add2 is not None else (None, 0, None)
         g.out_scale, g.act = scale, act
         g.Y, g.ldy, g.M, g.N = Y.data_ptr(), Y.stride(0), M, N
-        self._keep += [g, X, W, Y, bias, X2, ln, add1, idx1, add2, idx2]
+        g.rows = hip.ptr(rows)
+        self._keep += [g, X, W, Y, bias, X2, ln, add1, idx1, add2, idx2, rows]
         self._call(prog, self.lib.pg_gemm, C.byref(g))
 
     def _seg(self, prog, mode, n_seg, seg_ids, a, **kw):
@@ -167,7 +169,11 @@ class Engine:
         wq, wU, wS, wsw = w.q[buf], w.U[buf], w.S[buf], w.swn[buf]
         blk = lambda b: Y[:, col0 + 128 * b: col0 + 128 * (b + 1)]
         # q = W2q . ReLU(LN(q_hid)) + b2q, scaled by 1/sqrt(head_dim)
-        self._gemm(prog, blk(4), 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
+        if len(h_dst_lists) == 1 and self.row_subsets:      # queries are only needed at the target rows
+            ids, cnt, _ = h_dst_lists[0]
+            self._gemm(prog, blk(4), 128, a.W2q, wq, cnt, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE, rows=ids)
+        else:
+            self._gemm(prog, blk(4), 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
         knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
         pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
         for seg_ids, n_seg, is_lig in h_dst_lists:
@@ -262,7 +268,13 @@ class Engine:
             self._call(prog, lib.pg_lig_normals, t, xc.data_ptr(), w.phore_norm.data_ptr(), p.phore2ctx.data_ptr(),
                        w.nrm.data_ptr())
             self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
-            self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
+            # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
+            # (ligand atoms: targets and sources of bond edges)
+            if self.row_subsets:
+                self._gemm(prog, hc, 128, L.W_node1[:640], w.Y1[:, :640], n, 640, bias=L.b_node1[:640])
+                self._gemm(prog, hc, 128, L.W_node1[640:], w.Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
+            else:
+                self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
             self._fork(prog, (1, 2, 3))
             # ---- node update over knn edges (:281)                                    [lane 1]
             self._lane = 1
@@ -293,7 +305,14 @@ class Engine:
             # ---- h' = h + lin_node(aggE + aggB) (:288)
             self._gemm(prog, w.aggE, 128, L.W_lin2, hn, n, 128, bias=L.b_lin, X2=w.aggB, K2=128, add1=hc)
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
-            self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
+            # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
+            # only for ligand atoms
+            if self.row_subsets:
+                self._gemm(prog, hn, 128, L.W_node2[256:512], w.Y2[:, 256:512], n, 256, bias=L.b_node2[256:512])
+                self._gemm(prog, hn, 128, L.W_node2[:256], w.Y2[:, :256], p.n_lig, 256, bias=L.b_node2[:256], rows=p.lig2ctx)
+                self._gemm(prog, hn, 128, L.W_node2[512:], w.Y2[:, 512:], p.n_lig, 768, bias=L.b_node2[512:], rows=p.lig2ctx)
+            else:
+                self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
             self._fork(prog, (1,))
             self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
