@@ -91,6 +91,9 @@ int pg_knn_ctx(const PgTopo* t, const float* x_ctx, int k, int* nbr, int* deg, v
 int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* phore_norm, const int* phore2ctx,
                    float* nrm, void* stream);
 
+/* nn3[n_lig,3]: ctx ids of the neighbours pg_lig_normals averages (-1 = fewer than 3 other atoms); training path */
+int pg_lig_nn3(const PgTopo* t, const float* x_ctx, int* nn3, void* stream);
+
 /* global edge gate e_w = sigmoid(MLP(smear(dist)))  (uni_denoiser.py:410-415); weights in kernel layout
  * (phoregen_amd/packing.py pack_gate): W0 = lane-fixed centred/sign-normalised first layer [5][8][64], b0 = its bias
  * [128], gamma unused, beta = beta/|gamma| [128], W3 = last-layer row times |gamma| [128] */
@@ -151,7 +154,7 @@ int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 /* U[s][c][h] = sum_d q[s,8h+d] * W2k[8h+d,c]  in lane-fixed layout (key second layer folded into the query) */
 int pg_attn_fold_query(const float* q /*[n,128] pre-scaled*/, int ldq, const float* W2k_l, int n,
                        const int* ids, float* U, void* stream);
-/* out[s, 8h+d] = sum_c W2v[8h+d,c] * S[s][c][h] + b2v[8h+d] * swn[s][h] */
+/* out[s, 8h+d] = sum_c W2v[8h+d,c] * S[s][c][h] + b2v[8h+d] * swn[s][h]   (swn / b2v NULL: no bias term) */
 int pg_attn_unfold_value(const float* S, const float* swn, const float* W2v_l, const float* b2v, int n,
                          const int* ids, float* out, int ldo, void* stream);
 
@@ -186,6 +189,45 @@ int pg_guidance_grad(const PgTopo* t, const float* x_lig /*[n_lig,3]*/, const fl
                      const int* lig_graph, const int* g_lig_off, int use_atom_prox, float min_d, float max_d,
                      int use_center_prox, const float* phore_center /*[3]*/, float* cnt_ws /*[B]*/,
                      float* mean_ws /*[B,3]*/, float* grad /*[n_lig,3]*/, void* stream);
+
+/* ---- training path: backward kernels (PhoreDiff.compute_loss, models/diffusion.py:249-352) -------------------
+ * The forward of a training step runs the same kernels as sampling; these entry points are their adjoints.
+ * Gradient buffers marked (+=) are accumulated with atomics into caller-zeroed memory, (=) are overwritten. */
+
+/* gW[n,k] (+=) sum_r dY[r,n] * X[r,k];  gb[n] (+=) sum_r dY[r,n] (gb may be NULL).  Adjoint of pg_gemm w.r.t. W / bias
+ * (nn.Linear weight gradients). */
+int pg_gemm_wgrad(const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* gW, int ldgw,
+                  float* gb, void* stream);
+
+/* Y = ReLU(LayerNorm_128(X) * gamma + beta) and its adjoint (the LayerNorm+ReLU between the two Linear layers of
+ * models/common.py:99-119 MLPs, used where the forward keeps it fused into pg_gemm's operand load).
+ * gX (=), ggamma / gbeta (+=). */
+int pg_ln_relu(const float* X, int ldx, const float* gamma, const float* beta, int M, float* Y, int ldy, void* stream);
+int pg_ln_relu_bwd(const float* X, int ldx, const float* gamma, const float* beta, const float* gY, int ldgy, int M,
+                   float* gX, int ldgx, float* ggamma, float* gbeta, void* stream);
+
+/* adjoint of pg_seg_attn (same PgSegAttn inputs as the forward call, with U and Cdst_k/v given explicitly in every
+ * mode; triplet: Cdst = smear(d_ji) . Wg2 computed by the caller, S/swn form) */
+typedef struct {
+  const float* gS; const float* gswn;     /* non-pos modes: gradient of S [..][32][64] and swn [..][16]            */
+  const float* gdx;                        /* pos modes: gradient of dx [n_ctx,3]                                    */
+  float* gU;                               /* (=) [..][32][64] lane-fixed, rows = segments                           */
+  float* gCdst_k; float* gCdst_v; int ld_gcdst;   /* (=) rows = segments                                            */
+  float* gCsrc_k; float* gCsrc_v; int ld_gcsrc;   /* (+=) rows as Csrc                                              */
+  float* gWf_k; float* gWf_v;              /* (+=) lane-fixed [F/4][8][64]                                           */
+  float* gbk; float* gbv;                  /* (+=) [128] gradient of b' = beta/|gamma| (PgSegAttn.ln_bk / ln_bv)     */
+  float* gW2xv_l; float* gb2xv;            /* (+=) pos modes                                                         */
+  float* gx; float* gnrm;                  /* (+=) [n_ctx,3]; NULL = not needed (pharmacophore encoder)              */
+  float* gew;                              /* (=) knn modes [n_ctx,k]                                                */
+  float* rowbuf; int rowbuf_rows; int grid;/* scratch: grid * pg_seg_attn_bwd_waves(mode) * rowbuf_rows * 48 floats,
+                                              rowbuf_rows >= rows of the largest segment; grid = workgroups to launch */
+} PgSegAttnGrad;
+int pg_seg_attn_bwd_waves(int mode);
+int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* g, void* stream);
+
+/* gW2_l (+=) in the lane-fixed layout of W2k_l / W2v_l:  gW2[8h+d, c] += sum_s X[s, 8h+d] * T[s][c][h]
+ * (adjoint of pg_attn_fold_query w.r.t. the weights with X = q, T = dU; of pg_attn_unfold_value with X = dout, T = S) */
+int pg_attn_fold_wgrad(const float* X, int ldx, const float* T, int n, const int* ids, float* gW2_l, void* stream);
 
 #ifdef __cplusplus
 }

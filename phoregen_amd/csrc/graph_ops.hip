@@ -153,6 +153,21 @@ __global__ __launch_bounds__(256) void lig_normals_kernel(PgTopo t, const float*
   }
 }
 
+// indices of the (up to) 3 nearest ligand atoms of every ligand atom, in the order lig_normals_kernel sums them
+// (training path: the mean itself is composed on the host so that autograd sees it); nn3[a][i] = -1 beyond the count
+__global__ __launch_bounds__(256) void lig_nn3_kernel(PgTopo t, const float* x, int* nn3) {
+  __shared__ int slots[4][4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + w;
+  if (item >= t.n_lig) return;
+  const int ctx = t.lig2ctx[item], g = t.ctx_graph[ctx];
+  const int first = t.g_ctx_off[g] + t.g_nph[g], count = t.g_nlig[g];
+  int d;
+  wave_knn(x, first, count, ctx, 3, slots[w], &d);
+  d = min(3, count - 1);
+  if (lane < 3) nn3[item * 3 + lane] = lane < d ? slots[w][lane] : -1;
+}
+
 // ------------------------------------------------------------------------------------------------
 // global edge gate  e_w = sigmoid(W3 . ReLU(LN(W0 . smear(d) + b0)) + b3)   (uni_denoiser.py:410-415)
 // one wave per node, its k neighbour slots in tiles of 16 rows; hidden^T[c,row] by 5 K-steps of 16x16x4 MFMA
@@ -292,6 +307,12 @@ extern "C" int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* 
   hipLaunchKernelGGL(lig_normals_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, phore_norm,
                      phore2ctx, nrm);
   return check_launch("pg_lig_normals");
+}
+
+extern "C" int pg_lig_nn3(const PgTopo* t, const float* x_ctx, int* nn3, void* stream) {
+  if (t->n_lig == 0) return PG_OK;
+  hipLaunchKernelGGL(lig_nn3_kernel, dim3((t->n_lig + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, nn3);
+  return check_launch("pg_lig_nn3");
 }
 
 extern "C" int pg_edge_gate(const PgTopo* t, const float* x_ctx, const int* nbr, const int* deg, int k, const float* W0,

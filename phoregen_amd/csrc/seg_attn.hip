@@ -13,67 +13,12 @@
 
 #include "common.h"
 #include "../../include/phoregen_hip.h"
+#include "seg_common.h"
 
 namespace pg {
 
 int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st);     // triplet.hip
 int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // node_attn.hip (-1: shape not covered)
-
-constexpr float NEG_BIG = -1.0e30f;
-
-template <int MODE> struct ModeTraits;
-template <> struct ModeTraits<PG_SEG_KNN_NODE>  { static constexpr int NSTEP = 12; static constexpr bool POS = false, KNN = true,  BOND = false, TRI = false, PH = false; };
-template <> struct ModeTraits<PG_SEG_KNN_POS>   { static constexpr int NSTEP = 12; static constexpr bool POS = true,  KNN = true,  BOND = false, TRI = false, PH = false; };
-template <> struct ModeTraits<PG_SEG_BOND_NODE> { static constexpr int NSTEP = 0;  static constexpr bool POS = false, KNN = false, BOND = true,  TRI = false, PH = false; };
-template <> struct ModeTraits<PG_SEG_BOND_POS>  { static constexpr int NSTEP = 0;  static constexpr bool POS = true,  KNN = false, BOND = true,  TRI = false, PH = false; };
-template <> struct ModeTraits<PG_SEG_TRIPLET>   { static constexpr int NSTEP = 3;  static constexpr bool POS = false, KNN = false, BOND = false, TRI = true,  PH = false; };
-template <> struct ModeTraits<PG_SEG_PHORE>     { static constexpr int NSTEP = 1;  static constexpr bool POS = false, KNN = false, BOND = false, TRI = false, PH = true;  };
-
-// angular features of the triplet update (models/common.py:67-87 with duplicated sin/cos(theta) columns merged)
-__device__ __constant__ const float kAngFreq[12] = {0.f, 1.f, 2.f, 3.f, 0.5f, (float)(1.0 / 3.0), 1.f, 2.f, 3.f, 0.5f,
-                                                    (float)(1.0 / 3.0), 0.f};
-
-struct RowInfo {
-  bool valid;
-  int csrc;  // row of Csrc_{k,v}
-  int src;   // ctx node the row comes from (geometry)
-};
-
-template <int MODE>
-struct Seg {
-  int seg;          // ctx node (node modes) / bond edge j->i (triplet)
-  int n_rows;
-  int lig0, n, li, lj;  // bond / triplet
-  int first;            // phore
-  int ci, cj;           // triplet: ctx ids of i, j
-  const int* eid_g;
-};
-
-template <int MODE>
-__device__ __forceinline__ RowInfo row_info(const PgTopo& t, const PgSegAttn& p, const Seg<MODE>& s, int k) {
-  using T = ModeTraits<MODE>;
-  RowInfo r;
-  r.valid = k < s.n_rows;
-  r.csrc = 0;
-  r.src = 0;
-  if (!r.valid) return r;
-  if constexpr (T::KNN) {
-    r.src = p.nbr[(size_t)s.seg * p.knn_k + k];
-    r.csrc = r.src;
-  } else if constexpr (T::BOND) {
-    r.src = s.lig0 + k;
-    r.valid = k != s.li;
-    r.csrc = r.valid ? s.eid_g[k * s.n + s.li] : 0;
-  } else if constexpr (T::TRI) {
-    r.src = s.lig0 + k;
-    r.valid = (k != s.li) && (k != s.lj);
-    r.csrc = r.valid ? s.eid_g[k * s.n + s.lj] : 0;
-  } else {
-    r.src = s.first + k;
-    r.csrc = r.src;
-  }
-  return r;
-}
 
 // Folded LayerNorm + ReLU (packing._kv_mlp: hidden is centred and sign-normalised, |gamma| lives in the next Linear):
 // z = ReLU(hidden + b' * sigma); returns 1/sigma, which the caller applies to the row's logits / attention weights.
@@ -170,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
     L.ln[i] = p.ln_gk[i]; L.ln[128 + i] = p.ln_bk[i]; L.ln[256 + i] = p.ln_gv[i]; L.ln[384 + i] = p.ln_bv[i];
   }
   for (int i = tid; i < NSTEP * 512; i += blockDim.x) { L.wf_k[i] = p.Wf_k[i]; L.wf_v[i] = p.Wf_v[i]; }
-  if constexpr (T::TRI) {
+  if (T::TRI && p.S == nullptr) {
     for (int i = tid; i < 16384 / 4; i += blockDim.x) {
       reinterpret_cast<f4*>(L.w2k_l)[i] = reinterpret_cast<const f4*>(p.W2k_l)[i];
       reinterpret_cast<f4*>(L.w2v_l)[i] = reinterpret_cast<const f4*>(p.W2v_l)[i];
@@ -190,41 +135,16 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
   const int s_end = min(p.n_seg, s_begin + per_blk);
 
   for (int si = s_begin + wave; si < s_end; si += nwaves) {
-    Seg<MODE> s;
-    s.seg = p.seg_ids ? p.seg_ids[si] : si;
-    s.lig0 = s.n = s.li = s.lj = s.first = s.ci = s.cj = 0;
-    s.eid_g = nullptr;
-    if constexpr (T::KNN) {
-      s.n_rows = p.deg[s.seg];
-    } else if constexpr (T::BOND) {
-      const int gi = t.ctx_graph[s.seg];
-      s.n = t.g_nlig[gi];
-      s.lig0 = t.g_ctx_off[gi] + t.g_nph[gi];
-      s.li = s.seg - s.lig0;
-      s.eid_g = t.eid + t.g_eid_off[gi];
-      s.n_rows = s.n;
-    } else if constexpr (T::TRI) {
-      s.cj = t.bond_src[s.seg];
-      s.ci = t.bond_dst[s.seg];
-      const int gi = t.ctx_graph[s.cj];
-      s.n = t.g_nlig[gi];
-      s.lig0 = t.g_ctx_off[gi] + t.g_nph[gi];
-      s.li = s.ci - s.lig0;
-      s.lj = s.cj - s.lig0;
-      s.eid_g = t.eid + t.g_eid_off[gi];
-      s.n_rows = s.n;
-    } else {
-      const int gi = t.ctx_graph[s.seg];
-      s.first = t.g_ctx_off[gi];
-      s.n_rows = t.g_nph[gi];
-    }
+    const Seg<MODE> s = setup_seg<MODE>(t, p, si);
     const int dst_ctx = T::TRI ? s.ci : s.seg;
 
     // ---- per-segment constants: Cdst (K path: c = 16 tau + 4g + r ; V path: c = 16 tau + m) ----
     f4 cdk[8];
     float cdv[8];
     f4 cdk2[8];  // pos modes: second K-path MLP (xv)
-    if constexpr (T::TRI) {
+    // triplet, training form (p.S set): Q, U come precomputed (Cdst_*, U) and S / swn are written like the node modes
+    const bool tri_ext = T::TRI && p.S != nullptr;
+    if (T::TRI && !tri_ext) {
       // Q[c] = sum_i Wg2[i][c] * smear(d_ji)[i]   (first-layer columns 148:168, uni_denoiser.py:146)
       float* sc = L.scratch + wave * 256;
       float qk0 = 0.f, qk1 = 0.f, qv0 = 0.f, qv1 = 0.f;
@@ -259,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
 
     // ---- U[tau][r] = U[c = 16 tau + 4g + r][h = m] ----
     f4 U[8];
-    if constexpr (T::TRI) {
+    if (T::TRI && !tri_ext) {
       const float* qp = p.q + (size_t)s.seg * 128 + 8 * m;
       const f4 qa = *reinterpret_cast<const f4*>(qp), qb = *reinterpret_cast<const f4*>(qp + 4);
 #pragma unroll
@@ -493,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
           else p.dx[dst_ctx * 3 + c] = v;
         }
       }
-    } else if constexpr (T::TRI) {
+    } else if (T::TRI && !tri_ext) {
       // out[8h + d] = sum_c W2v[8h+d][c] * S[c][h] + b2v[8h+d]  (alpha sums to 1; empty segment -> 0)
       float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -576,12 +496,12 @@ __global__ __launch_bounds__(256) void unfold_value_kernel(const float* S, const
       part[d] += __shfl_xor(part[d], 16);
       part[d] += __shfl_xor(part[d], 32);
     }
-    const float sw = swn[(size_t)s * 16 + m];
+    const float sw = swn ? swn[(size_t)s * 16 + m] : 0.f;
     const int o0 = 8 * m + 2 * g;
     const float p0 = g == 0 ? part[0] : (g == 1 ? part[2] : (g == 2 ? part[4] : part[6]));
     const float p1 = g == 0 ? part[1] : (g == 1 ? part[3] : (g == 2 ? part[5] : part[7]));
-    out[(size_t)s * ldo + o0] = p0 + b2v[o0] * sw;
-    out[(size_t)s * ldo + o0 + 1] = p1 + b2v[o0 + 1] * sw;
+    out[(size_t)s * ldo + o0] = p0 + (b2v ? b2v[o0] * sw : 0.f);
+    out[(size_t)s * ldo + o0 + 1] = p1 + (b2v ? b2v[o0 + 1] * sw : 0.f);
   }
 }
 
@@ -661,7 +581,7 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
     case PG_SEG_BOND_POS: return launch_seg<PG_SEG_BOND_POS>(t, p, st);
     case PG_SEG_TRIPLET:
       // the occupancy-tuned kernel holds the logits of <= 5 row tiles in registers (ligands of <= 80 atoms)
-      return t->max_nlig <= 80 ? launch_triplet(t, p, st) : launch_seg<PG_SEG_TRIPLET>(t, p, st);
+      return (t->max_nlig <= 80 && !p->S) ? launch_triplet(t, p, st) : launch_seg<PG_SEG_TRIPLET>(t, p, st);
     case PG_SEG_PHORE: return launch_seg<PG_SEG_PHORE>(t, p, st);
   }
   set_error("pg_seg_attn: unknown mode %d", p->mode);

@@ -1,0 +1,689 @@
+// Backward of the segment attention sub-layers (training path, PhoreDiff.compute_loss -> models/diffusion.py:249-352;
+// the forward these gradients belong to is seg_attn.hip / node_attn.hip, reference: models/uni_denoiser.py:40-72,
+// 101-165, 187-209).
+//
+// One wave owns one segment and recomputes the forward from the same inputs (nothing but the layer inputs is kept
+// from the forward pass):
+//   pass 1  per 16-row tile: both MLP paths in the transposed layout hidden^T[c,row] (seg_attn.hip "K path"),
+//           logits[row,h] and tv[row,h] = rstd_v * z_v . M[:,h]  (M = dS of the segment, or W2xv in the pos modes)
+//           go to a per-wave row buffer; then the exact softmax, D[h] = sum_r alpha * dalpha and dlogits per row;
+//   pass 2  per tile: recompute z_k, z_v, then
+//             dU[c,h]  += z_k[c,row] * dy[row,h]               dz_k[c,row] = U[c,h] * dy[row,h]
+//             dz_v[c,row] = M[c,h] * cw[row,h]                 (pos: dW2xv[c,h] += z_v[c,row] * rstd * dvx[row,h])
+//           folded-LayerNorm backward per row, then from dhidden: dCdst (row sum), dCsrc (scatter), dWf (x feat),
+//           dfeat -> geometry (positions / direction vectors), gate gradient.
+// Matrix products whose operands are not in the register layout the MFMA wants go through a per-wave LDS tile
+// (stride 17), so every product is a plain 16x16x4 MFMA chain with operands read where they lie.
+// Weight gradients accumulate in LDS (dWf, lane-fixed layout of the forward weights) or registers (db', dW2xv) and
+// are flushed with one atomic per element per workgroup.
+#include <stdlib.h>
+
+#include "seg_common.h"
+
+namespace pg {
+
+namespace {
+
+constexpr float LN2 = 0.69314718055994530942f;
+constexpr int ROWBUF = 48;   // floats per row: alpha[16] | tv[16] | dlogit[16]
+
+template <int MODE>
+struct RowGeo {
+  float rel[3];   // x_dst - x_src
+  float d;
+  float ns[3];    // direction vector of the source (knn)
+  float v[3];     // triplet: x_k - x_i
+  float theta;
+  bool src_lig;
+};
+
+// features of row rk for f = 4 step + g (identical arithmetic to seg_attn.hip), plus what the backward needs
+template <int MODE, int NS>
+__device__ __forceinline__ void row_features(const PgTopo& t, const PgSegAttn& p, const RowInfo& rk, const float (&xd)[3],
+                                             const float (&nd)[3], const float (&xj)[3], int g, float (&feat)[NS],
+                                             RowGeo<MODE>& geo) {
+  using T = ModeTraits<MODE>;
+  geo.d = 0.f; geo.theta = 0.f; geo.src_lig = false;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { geo.rel[c] = 0.f; geo.ns[c] = 0.f; geo.v[c] = 0.f; }
+  if constexpr (T::KNN || T::PH || T::POS) {
+    if (rk.valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) geo.rel[c] = xd[c] - p.x[rk.src * 3 + c];
+      geo.d = sqrtf(geo.rel[0] * geo.rel[0] + geo.rel[1] * geo.rel[1] + geo.rel[2] * geo.rel[2]);
+    }
+  }
+  if constexpr (T::KNN) {
+    float dots[3] = {0.f, 0.f, 0.f};
+    if (rk.valid) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) geo.ns[c] = p.nrm[rk.src * 3 + c];
+      dots[0] = geo.ns[0] * nd[0] + geo.ns[1] * nd[1] + geo.ns[2] * nd[2];
+      dots[1] = -(geo.ns[0] * geo.rel[0] + geo.ns[1] * geo.rel[1] + geo.ns[2] * geo.rel[2]);
+      dots[2] = -(nd[0] * geo.rel[0] + nd[1] * geo.rel[1] + nd[2] * geo.rel[2]);
+      geo.src_lig = t.ctx_is_lig[rk.src] != 0;
+    }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+      const float sv = rk.valid ? smear(geo.d, 4 * st + g) : 0.f;
+      feat[st] = geo.src_lig ? sv : 0.f;
+      feat[5 + st] = geo.src_lig ? 0.f : sv;
+    }
+    feat[10] = g == 0 ? dots[0] : (g == 1 ? dots[1] : (g == 2 ? dots[2] : ((rk.valid && geo.src_lig) ? 1.f : 0.f)));
+    feat[11] = (g == 0 && rk.valid && !geo.src_lig) ? 1.f : 0.f;
+  } else if constexpr (T::TRI) {
+    if (rk.valid) {
+      float u[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { u[c] = xj[c] - xd[c]; geo.v[c] = p.x[rk.src * 3 + c] - xd[c]; }
+      const float a = u[0] * geo.v[0] + u[1] * geo.v[1] + u[2] * geo.v[2];
+      const float c0 = u[1] * geo.v[2] - u[2] * geo.v[1], c1 = u[2] * geo.v[0] - u[0] * geo.v[2],
+                  c2 = u[0] * geo.v[1] - u[1] * geo.v[0];
+      geo.theta = atan2f(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), a);
+    }
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      const int f = 4 * st + g;
+      float sn, cs;
+      sincosf(geo.theta * kAngFreq[f], &sn, &cs);
+      float v = f >= 6 ? cs : sn;
+      v = f == 0 ? geo.theta : v;
+      feat[st] = (rk.valid && f != 11) ? v : 0.f;
+    }
+  } else if constexpr (T::PH) {
+    feat[0] = g == 0 ? geo.d : 0.f;
+  }
+}
+
+// folded LayerNorm statistics of a transposed tile hid[tau][r] = hidden[c = 16 tau + 4g + r][row = m]
+__device__ __forceinline__ void ln_stats(const f4 (&hid)[8], float& rs, float& sigma) {
+  float q = 0.f;
+#pragma unroll
+  for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q = fmaf(hid[tq][r], hid[tq][r], q);
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  const float var = q * (1.f / 128.f) + 1e-5f;
+  rs = 1.0f / sqrtf(var);
+  sigma = var * rs;
+}
+
+struct BwdLds {
+  float *wf_k, *wf_v, *acc_k, *acc_v, *bk, *bv;
+  float *sT, *sF, *sGF, *sR;
+  int* sI;
+};
+
+}  // namespace
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAttn p, PgSegAttnGrad gr) {
+  using T = ModeTraits<MODE>;
+  constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
+  constexpr int FS = 16 * NF + 1;
+  constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32;       // per-wave floats
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, m = lane & 15;
+
+  BwdLds L;
+  {
+    float* q = lds_raw;
+    L.wf_k = q; q += NSTEP * 512;
+    L.wf_v = q; q += NSTEP * 512;
+    L.acc_k = q; q += NSTEP * 512;
+    L.acc_v = q; q += NSTEP * 512;
+    L.bk = q; q += 128;
+    L.bv = q; q += 128;
+    q += wave * PW;
+    L.sT = q; q += 128 * 17;
+    L.sF = q; q += 16 * FS;
+    L.sGF = q; q += 16 * FS;
+    L.sR = q; q += 64;
+    L.sI = reinterpret_cast<int*>(q);
+  }
+  for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
+    L.wf_k[i] = p.Wf_k[i]; L.wf_v[i] = p.Wf_v[i]; L.acc_k[i] = 0.f; L.acc_v[i] = 0.f;
+  }
+  for (int i = tid; i < 128; i += blockDim.x) { L.bk[i] = p.ln_bk[i]; L.bv[i] = p.ln_bv[i]; }
+  for (int i = lane; i < 16 * FS; i += 64) { L.sF[i] = 0.f; L.sGF[i] = 0.f; }
+  __syncthreads();
+
+  // first-layer feature weight W[c][f] out of the lane-fixed copy ([step][tau][lane=(f&3, c&15)])
+  auto wf_plain = [&](const float* wf, int c, int f) -> float {
+    return f < F ? wf[((f >> 2) * 8 + (c >> 4)) * 64 + (f & 3) * 16 + (c & 15)] : 0.f;
+  };
+
+  f4 gbk_acc[8], gbv_acc[8], gw2_acc[8];
+#pragma unroll
+  for (int tq = 0; tq < 8; ++tq) {
+    gbk_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f}; gbv_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f}; gw2_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f};
+  }
+  float gbx_acc = 0.f;
+  float* const rb = gr.rowbuf + (size_t)(blockIdx.x * NW + wave) * gr.rowbuf_rows * ROWBUF;
+  const float bx = T::POS ? p.b2xv[m] : 0.f;
+
+  for (int si = blockIdx.x * NW + wave; si < p.n_seg; si += gridDim.x * NW) {
+    const Seg<MODE> s = setup_seg<MODE>(t, p, si);
+    const int dst_ctx = T::TRI ? s.ci : s.seg;
+    const int n_rows = s.n_rows;
+    const int n_tiles = (n_rows + 15) >> 4;
+
+    // ---- per-segment constants in the transposed layout (c = 16 tau + 4g + r) ----
+    f4 cdk[8], cdv[8];
+    {
+      const float* ck = p.Cdst_k + (size_t)s.seg * p.ld_cdst;
+      const float* cv = p.Cdst_v + (size_t)s.seg * p.ld_cdst;
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) {
+        cdk[tq] = *reinterpret_cast<const f4*>(ck + 16 * tq + 4 * g);
+        cdv[tq] = *reinterpret_cast<const f4*>(cv + 16 * tq + 4 * g);
+      }
+    }
+    const float* Uk = p.U + (size_t)s.seg * 2048;                                     // [c][h] lane-fixed
+    const float* Mv = T::POS ? p.W2xv_l : gr.gS + (size_t)s.seg * 2048;              // [c][h] lane-fixed
+    auto m_plain = [&](const float* M, int c, int h) -> float {                       // M[c][h] out of the lane-fixed layout
+      return M[((c >> 4) * 4 + (c & 3)) * 64 + ((c >> 2) & 3) * 16 + h];
+    };
+    float xd[3] = {0.f, 0.f, 0.f}, nd[3] = {0.f, 0.f, 0.f}, xj[3] = {0.f, 0.f, 0.f}, gdx[3] = {0.f, 0.f, 0.f};
+    if constexpr (T::KNN || T::PH || T::POS || T::TRI) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xd[c] = p.x[dst_ctx * 3 + c];
+    }
+    if constexpr (T::KNN) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nd[c] = p.nrm[dst_ctx * 3 + c];
+    }
+    if constexpr (T::TRI) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xj[c] = p.x[s.cj * 3 + c];
+    }
+    if constexpr (T::POS) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gdx[c] = gr.gdx[dst_ctx * 3 + c];
+    }
+    const float gswn_m = T::POS ? 0.f : gr.gswn[(size_t)s.seg * 16 + m];
+
+    // hidden^T tile of one path: gather + per-segment constant + feature product
+    auto hidden_tile = [&](const float* Csrc, const f4* cd, const float* wf, const RowInfo& rk, const float (&feat)[NS],
+                           f4 (&hid)[8]) {
+      const float* pk = Csrc + (size_t)rk.csrc * p.ld_csrc + 4 * g;
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) {
+        f4 c = {0.f, 0.f, 0.f, 0.f};
+        if (rk.valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+        hid[tq] = c + cd[tq];
+      }
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf[(st * 8 + tq) * 64 + lane], feat[st], hid[tq]);
+    };
+    // z = ReLU(hidden + b' sigma) in place, then y[row = 4g+r][h = m] = z . M[:,h]   (unscaled by rstd)
+    auto relu_project = [&](f4 (&hid)[8], const float* bp, float sigma, const float* M) -> f4 {
+      f4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) {
+        const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          hid[tq][r] = fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f);
+          y = mfma16(hid[tq][r], M[(tq * 4 + r) * 64 + lane], y);
+        }
+      }
+      return y;
+    };
+
+    // =============================== pass 1: logits and tv of every row ===============================
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const RowInfo rk = row_info<MODE>(t, p, s, tile * 16 + m);
+      float feat[NS];
+      RowGeo<MODE> geo;
+      row_features<MODE, NS>(t, p, rk, xd, nd, xj, g, feat, geo);
+      f4 hid[8];
+      float rs, sg;
+      hidden_tile(p.Csrc_k, cdk, L.wf_k, rk, feat, hid);
+      ln_stats(hid, rs, sg);
+      f4 y = relu_project(hid, L.bk, sg, Uk);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] *= __shfl(rs, 4 * g + r);
+      hidden_tile(p.Csrc_v, cdv, L.wf_v, rk, feat, hid);
+      ln_stats(hid, rs, sg);
+      f4 tv = relu_project(hid, L.bv, sg, Mv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tv[r] = tv[r] * __shfl(rs, 4 * g + r) + bx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = tile * 16 + 4 * g + r;
+        if (row < n_rows) {
+          const RowInfo rv = row_info<MODE>(t, p, s, row);
+          rb[row * ROWBUF + m] = rv.valid ? y[r] : NEG_BIG;
+          rb[row * ROWBUF + 16 + m] = tv[r];
+        }
+      }
+    }
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+
+    // =============================== softmax backward per head m (rows r = g, g+4, ...) ===============================
+    {
+      float mx = NEG_BIG;
+      for (int r = g; r < n_rows; r += 4) mx = fmaxf(mx, rb[r * ROWBUF + m]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float l = 0.f;
+      for (int r = g; r < n_rows; r += 4) {
+        const float lg = rb[r * ROWBUF + m];
+        l += lg > 0.5f * NEG_BIG ? exp2f(lg - mx) : 0.f;
+      }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      float D = 0.f;
+      for (int r = g; r < n_rows; r += 4) {
+        const float lg = rb[r * ROWBUF + m];
+        const float a = lg > 0.5f * NEG_BIG ? exp2f(lg - mx) * inv : 0.f;
+        const float tvv = rb[r * ROWBUF + 16 + m];
+        float w = 1.f;
+        if constexpr (T::KNN) w = p.ew[(size_t)s.seg * p.knn_k + r];
+        float ga;
+        if constexpr (T::POS) {
+          const RowInfo rv = row_info<MODE>(t, p, s, r);
+          float e = 0.f;
+          if (rv.valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) e += gdx[c] * (xd[c] - p.x[rv.src * 3 + c]);
+          }
+          ga = w * e * (1.f / 16.f) * tvv;
+        } else {
+          ga = w * (tvv + gswn_m);
+        }
+        D += a * ga;
+        rb[r * ROWBUF + m] = a;
+        rb[r * ROWBUF + 32 + m] = ga;
+      }
+      D += __shfl_xor(D, 16);
+      D += __shfl_xor(D, 32);
+      for (int r = g; r < n_rows; r += 4) {
+        const float a = rb[r * ROWBUF + m];
+        rb[r * ROWBUF + 32 + m] = LN2 * a * (rb[r * ROWBUF + 32 + m] - D);
+      }
+    }
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+
+    // =============================== pass 2: gradients ===============================
+    f4 gU[8];
+#pragma unroll
+    for (int tq = 0; tq < 8; ++tq) gU[tq] = (f4){0.f, 0.f, 0.f, 0.f};
+    float gcd_k0 = 0.f, gcd_k1 = 0.f, gcd_v0 = 0.f, gcd_v1 = 0.f;
+
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const int row_m = tile * 16 + m;
+      const RowInfo rk = row_info<MODE>(t, p, s, row_m);
+      float feat[NS];
+      RowGeo<MODE> geo;
+      row_features<MODE, NS>(t, p, rk, xd, nd, xj, g, feat, geo);
+      if constexpr (NSTEP > 0) {
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) L.sF[m * FS + 4 * st + g] = feat[st];
+      }
+      if (g == 0) L.sI[m] = rk.valid ? rk.csrc : -1;
+      // per-row weight of the value path: cw = gate (non-pos) or gate * <ddx, rel_x> / 16 (pos)
+      float w_m = 1.f;
+      if constexpr (T::KNN) w_m = (rk.valid && row_m < p.knn_k) ? p.ew[(size_t)s.seg * p.knn_k + row_m] : 0.f;
+      float e_m = 0.f;
+      if constexpr (T::POS) e_m = (gdx[0] * geo.rel[0] + gdx[1] * geo.rel[1] + gdx[2] * geo.rel[2]) * (1.f / 16.f);
+      const float cw_m = rk.valid ? (T::POS ? w_m * e_m : w_m) : 0.f;
+      if (g == 0) L.sR[32 + m] = cw_m;
+
+      f4 gfeat[NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) gfeat[ft] = (f4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+      for (int path = 0; path < 2; ++path) {
+        const bool kp = path == 0;
+        const float* bp = kp ? L.bk : L.bv;
+        const float* wf = kp ? L.wf_k : L.wf_v;
+        float* acc = kp ? L.acc_k : L.acc_v;
+        const float* M = kp ? Uk : Mv;
+        f4 hid[8], z[8];
+        float rs, sg;
+        hidden_tile(kp ? p.Csrc_k : p.Csrc_v, kp ? cdk : cdv, wf, rk, feat, hid);
+        ln_stats(hid, rs, sg);
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) z[tq] = hid[tq];
+        const f4 y = relu_project(z, bp, sg, M);                    // z = ReLU(..) now; y unscaled, rows 4g+r, head m
+        // coefficient of y in the loss, rows 4g+r: k path dlogit ; v path cw * alpha
+        f4 coefD;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = tile * 16 + 4 * g + r;
+          float c = 0.f;
+          if (row < n_rows) c = kp ? rb[row * ROWBUF + 32 + m] : rb[row * ROWBUF + m] * L.sR[32 + 4 * g + r];
+          coefD[r] = c;
+        }
+        wave_lds_sync();   // sR[32..] written above is read here by other lanes only after this point on later paths
+        if (!kp) {
+          // gate gradient, d(rel_x) weight and the bias of the pos value head
+          f4 av;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tile * 16 + 4 * g + r;
+            const float a = row < n_rows ? rb[row * ROWBUF + m] : 0.f;
+            const float vfull = y[r] * __shfl(rs, 4 * g + r);          // rstd_v * z_v . M
+            av[r] = row16_total(a * (T::POS ? vfull + bx : vfull + gswn_m));
+          }
+          if constexpr (T::KNN) {
+            // d gate[row] = sum_h alpha * (rstd t + dswn)    (pos: e * sum_h alpha * vx)
+            if (m < 4) {
+              const int row = tile * 16 + 4 * g + m;
+              const float a4 = m == 0 ? av[0] : (m == 1 ? av[1] : (m == 2 ? av[2] : av[3]));
+              if (row < p.knn_k && gr.gew) {
+                float e_r = 1.f;
+                if constexpr (T::POS) {
+                  const RowInfo rv = row_info<MODE>(t, p, s, row);
+                  e_r = 0.f;
+                  if (rv.valid) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) e_r += gdx[c] * (xd[c] - p.x[rv.src * 3 + c]);
+                  }
+                  e_r *= (1.f / 16.f);
+                }
+                gr.gew[(size_t)s.seg * p.knn_k + row] = row < n_rows ? a4 * e_r : 0.f;
+              }
+            }
+          }
+          if constexpr (T::POS) {
+            // A[row] = (1/16) * gate * sum_h alpha vx  -> d rel_x = A * ddx
+            if (m < 4) {
+              const float a4 = m == 0 ? av[0] : (m == 1 ? av[1] : (m == 2 ? av[2] : av[3]));
+              L.sR[48 + 4 * g + m] = a4;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gbx_acc += coefD[r];
+          }
+        }
+        // d rstd of the row = sum_h coef * y
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = row16_total(coefD[r] * y[r]);
+          if (m == r) L.sR[4 * g + r] = v;
+        }
+        if (g == 0) L.sR[16 + m] = rs;
+        // z^T tile to LDS for the products contracted over rows
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = z[tq][r];
+        wave_lds_sync();
+        const float grs = L.sR[m];
+        // dM[c,h] += sum_row z[c,row] * rstd[row] * coef[row,h]      (k path: dU; pos v path: dW2xv)
+        if (kp || T::POS) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int rowk = tile * 16 + 4 * ks + g;
+            float b = 0.f;
+            if (rowk < n_rows) b = (kp ? rb[rowk * ROWBUF + 32 + m] : rb[rowk * ROWBUF + m] * L.sR[32 + 4 * ks + g]) * L.sR[16 + 4 * ks + g];
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              const float a = L.sT[(16 * tq + m) * 17 + 4 * ks + g];
+              if (kp) gU[tq] = mfma16(a, b, gU[tq]);
+              else gw2_acc[tq] = mfma16(a, b, gw2_acc[tq]);
+            }
+          }
+        }
+        // dz^T[c,row] = sum_h M[c,h] * coef[row,h] * rstd[row]
+        f4 gz[8];
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) gz[tq] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          float b = 0.f;
+          if (row_m < n_rows) b = (kp ? rb[row_m * ROWBUF + 32 + 4 * ks + g] : rb[row_m * ROWBUF + 4 * ks + g] * cw_m) * rs;
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) gz[tq] = mfma16(m_plain(M, 16 * tq + m, 4 * ks + g), b, gz[tq]);
+        }
+        // folded LayerNorm backward: z = ReLU(h + b' sigma), sigma = sqrt(var), rstd = 1/sigma, var = mean(h^2) + eps
+        float s1 = 0.f;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) {
+          const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gz[tq][r] = z[tq][r] > 0.f ? gz[tq][r] : 0.f;
+            s1 = fmaf(gz[tq][r], bt[r], s1);
+          }
+        }
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        const float gvar = 0.5f * rs * s1 - 0.5f * grs * rs * rs * rs;
+        f4* gb_acc = kp ? gbk_acc : gbv_acc;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gb_acc[tq][r] = fmaf(gz[tq][r], sg, gb_acc[tq][r]);
+            gz[tq][r] = fmaf(gvar * (1.f / 64.f), hid[tq][r], gz[tq][r]);       // d hidden
+          }
+        wave_lds_sync();   // products over sT (z) are done
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = gz[tq][r];
+        wave_lds_sync();
+        if constexpr (NSTEP > 0) {
+          // d feat[row, f] += sum_c dhidden[c,row] * Wf[c,f]
+          if constexpr (!T::PH) {
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+              for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  gfeat[ft] = mfma16(gz[tq][r], wf_plain(wf, 16 * tq + 4 * g + r, 16 * ft + m), gfeat[ft]);
+          }
+          // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]   (LDS accumulator in the lane-fixed layout)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft) {
+            const int f = 16 * ft + m;
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              f4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks)
+                a4 = mfma16(L.sT[(16 * tq + m) * 17 + 4 * ks + g], L.sF[(4 * ks + g) * FS + f], a4);
+              if (f < F) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&acc[((f >> 2) * 8 + tq) * 64 + (f & 3) * 16 + 4 * g + r], a4[r]);
+              }
+            }
+          }
+        }
+        // d Csrc (scatter) and d Cdst (row sum): lane owns channels lane and lane + 64
+        {
+          float* gsrc = kp ? gr.gCsrc_k : gr.gCsrc_v;
+          float a0 = 0.f, a1 = 0.f;
+          for (int rr = 0; rr < 16; ++rr) {
+            const int ci = L.sI[rr];
+            if (ci >= 0) {
+              const float v0 = L.sT[lane * 17 + rr], v1 = L.sT[(64 + lane) * 17 + rr];
+              atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + lane, v0);
+              atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + 64 + lane, v1);
+              a0 += v0; a1 += v1;
+            }
+          }
+          if (kp) { gcd_k0 += a0; gcd_k1 += a1; } else { gcd_v0 += a0; gcd_v1 += a1; }
+        }
+        wave_lds_sync();   // sT is rewritten by the next path / tile
+      }  // paths
+
+      // ---------------- geometry: d feat -> positions / direction vectors; pos modes: d rel_x ----------------
+      if constexpr ((T::KNN || T::TRI) && NSTEP > 0) {
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L.sGF[(4 * g + r) * FS + 16 * ft + m] = gfeat[ft][r];
+        wave_lds_sync();
+      }
+      if (g == 0 && rk.valid && gr.gx) {
+        const float* gf = L.sGF + m * FS;
+        float grel[3] = {0.f, 0.f, 0.f};
+        if constexpr (T::KNN) {
+          const int base = geo.src_lig ? 0 : 20;
+          float gd = 0.f;
+          for (int i = 0; i < 20; ++i) {
+            const float tt = geo.d - kSmearOff[i];
+            gd += gf[base + i] * expf(-0.5f * tt * tt) * (-tt);
+          }
+          const float sc = geo.d > 0.f ? gd / geo.d : 0.f;
+          const float g0 = gf[40], g1 = gf[41], g2 = gf[42];
+          float gns[3], gnd[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            grel[c] = sc * geo.rel[c] - g1 * geo.ns[c] - g2 * nd[c];
+            gns[c] = g0 * nd[c] - g1 * geo.rel[c];
+            gnd[c] = g0 * geo.ns[c] - g2 * geo.rel[c];
+          }
+          if (gr.gnrm) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              atomicAdd(gr.gnrm + rk.src * 3 + c, gns[c]);
+              atomicAdd(gr.gnrm + dst_ctx * 3 + c, gnd[c]);
+            }
+          }
+        }
+        if constexpr (T::POS) {
+          const float A = L.sR[48 + m] * w_m * (1.f / 16.f);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) grel[c] += A * gdx[c];
+        }
+        if constexpr (T::KNN || T::POS) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            atomicAdd(gr.gx + dst_ctx * 3 + c, grel[c]);
+            atomicAdd(gr.gx + rk.src * 3 + c, -grel[c]);
+          }
+        }
+        if constexpr (T::TRI) {
+          // theta = atan2(|u x v|, u.v), u = x_j - x_i, v = x_k - x_i
+          float gth = gf[0];
+          for (int f = 1; f < 11; ++f) {
+            float sn, cs;
+            sincosf(geo.theta * kAngFreq[f], &sn, &cs);
+            gth += gf[f] * kAngFreq[f] * (f >= 6 ? -sn : cs);
+          }
+          float u[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) u[c] = xj[c] - xd[c];
+          const float* v = geo.v;
+          const float a = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+          const float cr[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+          const float b = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+          const float den = a * a + b * b;
+          if (den > 0.f) {
+            const float ka = -b / den * gth;                          // d theta / d a
+            const float kb = b > 0.f ? a / den * gth / b : 0.f;       // d theta / d b, times 1/b of d b = c . dc / b
+            // db/du = v x c, db/dv = c x u
+            const float vxc[3] = {v[1] * cr[2] - v[2] * cr[1], v[2] * cr[0] - v[0] * cr[2], v[0] * cr[1] - v[1] * cr[0]};
+            const float cxu[3] = {cr[1] * u[2] - cr[2] * u[1], cr[2] * u[0] - cr[0] * u[2], cr[0] * u[1] - cr[1] * u[0]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float gu = ka * v[c] + kb * vxc[c];
+              const float gv = ka * u[c] + kb * cxu[c];
+              atomicAdd(gr.gx + s.cj * 3 + c, gu);
+              atomicAdd(gr.gx + rk.src * 3 + c, gv);
+              atomicAdd(gr.gx + dst_ctx * 3 + c, -(gu + gv));
+            }
+          }
+        }
+      }
+      wave_lds_sync();
+    }  // tiles
+
+    // ---------------- per-segment outputs ----------------
+    {
+      float* up = gr.gU + (size_t)s.seg * 2048 + lane;
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) up[(tq * 4 + r) * 64] = gU[tq][r];
+      float* ck = gr.gCdst_k + (size_t)s.seg * gr.ld_gcdst;
+      float* cv = gr.gCdst_v + (size_t)s.seg * gr.ld_gcdst;
+      ck[lane] = gcd_k0; ck[64 + lane] = gcd_k1;
+      cv[lane] = gcd_v0; cv[64 + lane] = gcd_v1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }  // segments
+
+  // ---------------- flush the weight-gradient accumulators ----------------
+  __syncthreads();
+  for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
+    if (L.acc_k[i] != 0.f) atomicAdd(gr.gWf_k + i, L.acc_k[i]);
+    if (L.acc_v[i] != 0.f) atomicAdd(gr.gWf_v + i, L.acc_v[i]);
+  }
+#pragma unroll
+  for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = row16_total(gbk_acc[tq][r]), b = row16_total(gbv_acc[tq][r]);
+      if (m == 0) {
+        atomicAdd(gr.gbk + 16 * tq + 4 * g + r, a);
+        atomicAdd(gr.gbv + 16 * tq + 4 * g + r, b);
+      }
+      if constexpr (T::POS) atomicAdd(gr.gW2xv_l + (tq * 4 + r) * 64 + lane, gw2_acc[tq][r]);
+    }
+  if constexpr (T::POS) {
+    gbx_acc += __shfl_xor(gbx_acc, 16);
+    gbx_acc += __shfl_xor(gbx_acc, 32);
+    if (g == 0) atomicAdd(gr.gb2xv + m, gbx_acc);
+  }
+}
+
+template <int MODE, int NW>
+static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st) {
+  using T = ModeTraits<MODE>;
+  constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
+  constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32;
+  const size_t lds = ((size_t)4 * NSTEP * 512 + 256 + (size_t)NW * PW) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { set_error("pg_seg_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
+    attr_set = true;
+  }
+  int blocks = (p->n_seg + NW - 1) / NW;
+  if (blocks > gr->grid) blocks = gr->grid;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr);
+  return check_launch("pg_seg_attn_bwd");
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_seg_attn_bwd_waves(int mode) { return (mode == PG_SEG_KNN_NODE || mode == PG_SEG_KNN_POS) ? 2 : 4; }
+
+extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, void* stream) {
+  if (!t || !p || !gr) { set_error("pg_seg_attn_bwd: null argument"); return PG_ERR_ARG; }
+  if (p->n_seg == 0) return PG_OK;
+  if (!p->U || !p->Cdst_k || !p->Cdst_v || !gr->rowbuf || gr->grid < 1) {
+    set_error("pg_seg_attn_bwd: U, Cdst_k/v and the row buffer are required");
+    return PG_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (p->mode) {
+    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 2>(t, p, gr, st);
+    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 2>(t, p, gr, st);
+    case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
+    case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
+    case PG_SEG_TRIPLET: return launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
+    case PG_SEG_PHORE: return launch_bwd<PG_SEG_PHORE, 4>(t, p, gr, st);
+  }
+  set_error("pg_seg_attn_bwd: unknown mode %d", p->mode);
+  return PG_ERR_ARG;
+}

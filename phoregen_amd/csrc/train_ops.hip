@@ -1,0 +1,186 @@
+// Training-path kernels that are not attention: weight gradients of the dense layers, the stand-alone
+// LayerNorm+ReLU of the query MLPs with its adjoint, and the weight gradient of the folded second key/value layers.
+// (PhoreDiff.compute_loss, models/diffusion.py:249-352; MLP = models/common.py:99-119.)
+#include "common.h"
+#include "../../include/phoregen_hip.h"
+
+namespace pg {
+
+// ------------------------------------------------------------------------------------------------
+// gW[n,k] += sum_r dY[r,n] * X[r,k]       (rows are the contraction index; M is huge, N and K are small)
+// Workgroup = 4 waves in 2x2, output tile 64(n) x 64(k), one 32x32x2 accumulator per wave; blockIdx.z strides over
+// row chunks of 32 and the partial tile is added with atomics.  Both operands are read from LDS with the lane
+// running along the row-major fast dimension: A[i=n][kk=row] = sdY[row][n], B[kk=row][j=k] = sX[row][k].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* dY, int ldy, const float* X, int ldx, int M, int N,
+                                                         int K, float* gW, int ldgw, float* gb) {
+  __shared__ float sdY[32][64 + 1];
+  __shared__ float sX[32][64 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int wn = (wave & 1) * 32, wk = (wave >> 1) * 32;
+  f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum = 0.f;
+  const int lr = tid >> 3, lc = (tid & 7) * 8;     // loader: row lr, 8 consecutive columns from lc
+  for (int row0 = blockIdx.z * 32; row0 < M; row0 += gridDim.z * 32) {
+    const int row = row0 + lr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int n = n0 + lc + j, k = k0 + lc + j;
+      sdY[lr][lc + j] = (row < M && n < N) ? dY[(size_t)row * ldy + n] : 0.f;
+      sX[lr][lc + j] = (row < M && k < K) ? X[(size_t)row * ldx + k] : 0.f;
+    }
+    __syncthreads();
+    if (gb && blockIdx.y == 0 && tid < 64) {
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) colsum += sdY[r][tid];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const int rr = kk + (lane >> 5);
+      acc = mfma32(sdY[rr][wn + (lane & 31)], sX[rr][wk + (lane & 31)], acc);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), k = k0 + wk + (lane & 31);
+    if (n < N && k < K && acc[r] != 0.f) atomicAdd(gW + (size_t)n * ldgw + k, acc[r]);
+  }
+  if (gb && blockIdx.y == 0 && tid < 64 && n0 + tid < N) atomicAdd(gb + n0 + tid, colsum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Y = ReLU(LN(X) * gamma + beta) over 128 channels, one wave per row (2 channels per lane), and its adjoint
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_relu_kernel(const float* X, int ldx, const float* gamma, const float* beta, int M,
+                                                      float* Y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const float g0 = gamma[lane], g1 = gamma[64 + lane], b0 = beta[lane], b1 = beta[64 + lane];
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const float x0 = X[(size_t)row * ldx + lane], x1 = X[(size_t)row * ldx + 64 + lane];
+    const float mu = wave_sum(x0 + x1) * (1.f / 128.f);
+    const float d0 = x0 - mu, d1 = x1 - mu;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    Y[(size_t)row * ldy + lane] = fmaxf(d0 * rs * g0 + b0, 0.f);
+    Y[(size_t)row * ldy + 64 + lane] = fmaxf(d1 * rs * g1 + b1, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_relu_bwd_kernel(const float* X, int ldx, const float* gamma, const float* beta,
+                                                          const float* gY, int ldgy, int M, float* gX, int ldgx,
+                                                          float* ggamma, float* gbeta) {
+  const int lane = threadIdx.x & 63;
+  const float g0 = gamma[lane], g1 = gamma[64 + lane], b0 = beta[lane], b1 = beta[64 + lane];
+  float gg0 = 0.f, gg1 = 0.f, gb0 = 0.f, gb1 = 0.f;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const float x0 = X[(size_t)row * ldx + lane], x1 = X[(size_t)row * ldx + 64 + lane];
+    const float mu = wave_sum(x0 + x1) * (1.f / 128.f);
+    const float d0 = x0 - mu, d1 = x1 - mu;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    const float h0 = d0 * rs, h1 = d1 * rs;
+    float y0 = gY[(size_t)row * ldgy + lane], y1 = gY[(size_t)row * ldgy + 64 + lane];
+    y0 = (h0 * g0 + b0) > 0.f ? y0 : 0.f;
+    y1 = (h1 * g1 + b1) > 0.f ? y1 : 0.f;
+    gg0 += y0 * h0; gg1 += y1 * h1; gb0 += y0; gb1 += y1;
+    const float a0 = y0 * g0, a1 = y1 * g1;                  // d x_hat
+    const float m1 = wave_sum(a0 + a1) * (1.f / 128.f);
+    const float m2 = wave_sum(a0 * h0 + a1 * h1) * (1.f / 128.f);
+    gX[(size_t)row * ldgx + lane] = rs * (a0 - m1 - h0 * m2);
+    gX[(size_t)row * ldgx + 64 + lane] = rs * (a1 - m1 - h1 * m2);
+  }
+  __shared__ float red[4][256];
+  const int w = threadIdx.x >> 6;
+  red[w][lane] = gg0; red[w][64 + lane] = gg1; red[w][128 + lane] = gb0; red[w][192 + lane] = gb1;
+  __syncthreads();
+  const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 128) atomicAdd(ggamma + threadIdx.x, v);
+  else atomicAdd(gbeta + threadIdx.x - 128, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gW2_l[(2i)*64 + lane][j]     += sum_s X[s, 8m + j]     * T[s][i*64 + lane]
+// gW2_l[(2i + 1)*64 + lane][j] += sum_s X[s, 8m + 4 + j] * T[s][i*64 + lane]       (lane = (g, m), i = 0..31)
+// blockIdx.y selects 4 consecutive i; one wave per segment stride.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fold_wgrad_kernel(const float* X, int ldx, const float* T, int n, const int* ids,
+                                                         float* gW2_l) {
+  const int lane = threadIdx.x & 63, m = lane & 15;
+  const int i0 = blockIdx.y * 4;
+  float acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[a][d] = 0.f;
+  for (int si = blockIdx.x * 4 + (threadIdx.x >> 6); si < n; si += gridDim.x * 4) {
+    const int s = ids ? ids[si] : si;
+    const float* xp = X + (size_t)s * ldx + 8 * m;
+    const f4 xa = *reinterpret_cast<const f4*>(xp), xb = *reinterpret_cast<const f4*>(xp + 4);
+    const float* tp = T + (size_t)s * 2048 + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float tv = tp[(i0 + a) * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[a][j] = fmaf(xa[j], tv, acc[a][j]);
+        acc[a][4 + j] = fmaf(xb[j], tv, acc[a][4 + j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      atomicAdd(gW2_l + ((size_t)(2 * (i0 + a)) * 64 + lane) * 4 + j, acc[a][j]);
+      atomicAdd(gW2_l + ((size_t)(2 * (i0 + a) + 1) * 64 + lane) * 4 + j, acc[a][4 + j]);
+    }
+}
+
+}  // namespace pg
+
+using namespace pg;
+
+extern "C" int pg_gemm_wgrad(const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* gW, int ldgw,
+                             float* gb, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
+  const int bn = (N + 63) / 64, bk = (K + 63) / 64;
+  int split = (4 * kNumCU + bn * bk - 1) / (bn * bk);
+  const int chunks = (M + 31) / 32;
+  if (split > chunks) split = chunks;
+  if (split < 1) split = 1;
+  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(bn, bk, split), dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K,
+                     gW, ldgw, gb);
+  return check_launch("pg_gemm_wgrad");
+}
+
+extern "C" int pg_ln_relu(const float* X, int ldx, const float* gamma, const float* beta, int M, float* Y, int ldy,
+                          void* stream) {
+  if (M <= 0) return PG_OK;
+  int blocks = (M + 3) / 4;
+  if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
+  hipLaunchKernelGGL(ln_relu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, gamma, beta, M, Y, ldy);
+  return check_launch("pg_ln_relu");
+}
+
+extern "C" int pg_ln_relu_bwd(const float* X, int ldx, const float* gamma, const float* beta, const float* gY, int ldgy,
+                              int M, float* gX, int ldgx, float* ggamma, float* gbeta, void* stream) {
+  if (M <= 0) return PG_OK;
+  int blocks = (M + 3) / 4;
+  if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
+  hipLaunchKernelGGL(ln_relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, gamma, beta, gY, ldgy, M,
+                     gX, ldgx, ggamma, gbeta);
+  return check_launch("pg_ln_relu_bwd");
+}
+
+extern "C" int pg_attn_fold_wgrad(const float* X, int ldx, const float* T, int n, const int* ids, float* gW2_l,
+                                  void* stream) {
+  if (n <= 0) return PG_OK;
+  int blocks = (n + 3) / 4;
+  if (blocks > kNumCU) blocks = kNumCU;
+  hipLaunchKernelGGL(fold_wgrad_kernel, dim3(blocks, 8), dim3(256), 0, (hipStream_t)stream, X, ldx, T, n, ids, gW2_l);
+  return check_launch("pg_attn_fold_wgrad");
+}

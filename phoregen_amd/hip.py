@@ -47,6 +47,15 @@ class PgSegAttn(C.Structure):
                 ('accumulate_dx', C.c_int)]
 
 
+class PgSegAttnGrad(C.Structure):
+    _fields_ = [('gS', c_fp), ('gswn', c_fp), ('gdx', c_fp), ('gU', c_fp),
+                ('gCdst_k', c_fp), ('gCdst_v', c_fp), ('ld_gcdst', C.c_int),
+                ('gCsrc_k', c_fp), ('gCsrc_v', c_fp), ('ld_gcsrc', C.c_int),
+                ('gWf_k', c_fp), ('gWf_v', c_fp), ('gbk', c_fp), ('gbv', c_fp),
+                ('gW2xv_l', c_fp), ('gb2xv', c_fp), ('gx', c_fp), ('gnrm', c_fp), ('gew', c_fp),
+                ('rowbuf', c_fp), ('rowbuf_rows', C.c_int), ('grid', C.c_int)]
+
+
 SEG_KNN_NODE, SEG_KNN_POS, SEG_BOND_NODE, SEG_BOND_POS, SEG_TRIPLET, SEG_PHORE = range(6)
 ACT_NONE, ACT_SSP, ACT_RELU = 0, 1, 2
 
@@ -61,6 +70,7 @@ _PROTOS = {
     'pg_embed_bond': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 7 + [C.c_void_p]),
     'pg_knn_ctx': (C.c_int, [C.POINTER(PgTopo), c_fp, C.c_int, c_ip, c_ip, C.c_void_p]),
     'pg_lig_normals': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_ip, c_fp, C.c_void_p]),
+    'pg_lig_nn3': (C.c_int, [C.POINTER(PgTopo), c_fp, c_ip, C.c_void_p]),
     'pg_edge_gate': (C.c_int, [C.POINTER(PgTopo), c_fp, c_ip, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
                                C.c_float, c_fp, C.c_void_p]),
     'pg_bond_smear': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, C.c_void_p]),
@@ -75,6 +85,13 @@ _PROTOS = {
                                            C.c_uint64, C.c_uint32, C.c_uint32, c_fp, c_fp, c_fp, C.c_void_p]),
     'pg_posterior_position': (C.c_int, [c_fp, c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_uint64,
                                         C.c_uint32, C.c_uint32, C.c_int, c_fp, c_fp, c_fp, C.c_void_p]),
+    'pg_gemm_wgrad': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_void_p]),
+    'pg_ln_relu': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, c_fp, C.c_int, C.c_void_p]),
+    'pg_ln_relu_bwd': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp,
+                                 C.c_void_p]),
+    'pg_seg_attn_bwd_waves': (C.c_int, [C.c_int]),
+    'pg_seg_attn_bwd': (C.c_int, [C.POINTER(PgTopo), C.POINTER(PgSegAttn), C.POINTER(PgSegAttnGrad), C.c_void_p]),
+    'pg_attn_fold_wgrad': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_ip, c_fp, C.c_void_p]),
     'pg_guidance_grad': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_ip, c_ip, C.c_int, C.c_float, C.c_float,
                                    C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
 }

@@ -195,6 +195,7 @@ class LayerPack:
         self.W_node1, self.b_node1 = fuse_blocks(b_ne + b_nb + b_tb)       # [1920,128]
         self.W_node2, self.b_node2 = fuse_blocks(b_pe + b_pb)              # [1280,128]
         Wl = sd[p + '.lin_node.weight']
+        self.W_lin = Wl
         self.W_lin2 = torch.cat([Wl, Wl], 1).contiguous()                  # (aggE | aggB) @ [W | W]^T
         self.b_lin = sd[p + '.lin_node.bias'].contiguous()
 
@@ -209,12 +210,14 @@ def pack_gate(sd, p='denoiser.edge_pred_layer'):
 class ModelPack:
     """All kernel-layout weights of a PhoreDiff state_dict (tensors must already be on the GPU)."""
 
-    def __init__(self, sd, num_layers=6):
-        sd = {k: v.detach() for k, v in sd.items()}
+    def __init__(self, sd, num_layers=6, detach=True):
+        """detach=False (training.py): the packed tensors stay attached to the parameters' autograd graph."""
+        if detach:
+            sd = {k: v.detach() for k, v in sd.items()}
         self.layers = [LayerPack(sd, f'denoiser.base_block.{l}') for l in range(num_layers)]
         self.PH, b_ph = pack_phore(sd)
         self.W_ph, self.b_ph = fuse_blocks(b_ph)                           # [640,128]
-        self.gate = pack_gate(sd)
+        self.gate = pack_gate(sd) if detach else None       # training composes the gate MLP from the raw parameters
         c = lambda k: sd[k].contiguous()
         self.W_node_emb, self.W_edge_emb = c('node_embedder.weight'), c('edge_embedder.weight')
         self.t_off, self.t_coeff = c('time_emb.0.offset'), c('time_emb.0.coeff')

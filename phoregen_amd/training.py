@@ -1,0 +1,428 @@
+"""Training path (PhoreDiff.compute_loss, reference models/diffusion.py:249-352): the denoiser forward with
+autograd, every matrix product and every attention sub-layer a HIP kernel with a hand-written HIP adjoint.
+
+torch.autograd is the tape and nothing more: each `Function` below launches the forward kernel of the C ABI and, in
+`backward`, its adjoint (`pg_gemm` with the transposed weight, `pg_gemm_wgrad`, `pg_ln_relu_bwd`, `pg_seg_attn_bwd`,
+`pg_attn_fold_wgrad`, fold <-> unfold as each other's adjoints).  Gradients reach the reference-schema parameters
+through `packing.py` run WITHOUT detaching (centring, sign/|gamma| folding and the lane-fixed gathers are plain
+differentiable tensor ops on 128x128-sized weights).  Index plumbing of the geometry that the sampler does inside
+fused kernels (distances for the edge gate, bond-length smearing, mean of the 3 nearest atoms, residual adds, the loss
+itself) is composed from elementwise tensor ops here; the kNN searches stay in the HIP kernels.
+No CPU fallback: every entry point raises without the library / a GPU.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .packing import HEAD_SCALE, ModelPack
+
+_SMEAR_OFF = (0., 1., 1.25, 1.5, 1.75, 2., 2.25, 2.5, 2.75, 3., 3.5, 4., 4.5, 5., 5.5, 6., 7., 8., 9., 10.)
+
+
+def _st():
+    return hip.stream_ptr()
+
+
+def _rowmajor(t):
+    return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
+
+
+def _gemm_raw(X, W, Y, bias=None):
+    """Y = X @ W^T (+ bias) through pg_gemm."""
+    g = hip.PgGemm()
+    M, K = X.shape
+    g.X, g.ldx, g.K1 = X.data_ptr(), X.stride(0), K
+    g.W, g.ldw = W.data_ptr(), W.stride(0)
+    g.bias = hip.ptr(bias)
+    g.out_scale, g.act = 1.0, hip.ACT_NONE
+    g.Y, g.ldy, g.M, g.N = Y.data_ptr(), Y.stride(0), M, W.shape[0]
+    hip.check(hip.lib().pg_gemm(C.byref(g), _st()), 'pg_gemm')
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear: Y = X W^T + b."""
+
+    @staticmethod
+    def forward(ctx, X, W, b):
+        X, W = _rowmajor(X), _rowmajor(W)
+        Y = torch.empty(X.shape[0], W.shape[0], dtype=torch.float32, device=X.device)
+        if X.shape[0]:
+            _gemm_raw(X, W, Y, b.contiguous() if b is not None else None)
+        ctx.save_for_backward(X, W)
+        ctx.has_bias = b is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        X, W = ctx.saved_tensors
+        gY = _rowmajor(gY)
+        lib = hip.lib()
+        gX = gW = gb = None
+        M = X.shape[0]
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty_like(X)
+            if M:
+                _gemm_raw(gY, W.t().contiguous(), gX)
+        if ctx.needs_input_grad[1] or ctx.has_bias:
+            gW = torch.zeros_like(W)
+            gb = torch.zeros(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_bias else None
+            hip.check(lib.pg_gemm_wgrad(gY.data_ptr(), gY.stride(0), X.data_ptr(), X.stride(0), M, W.shape[0], W.shape[1],
+                                        gW.data_ptr(), gW.stride(0), hip.ptr(gb), _st()), 'pg_gemm_wgrad')
+        return gX, gW, gb
+
+
+def linear(X, W, b=None):
+    return LinearFn.apply(X, W, b)
+
+
+class LnReluFn(torch.autograd.Function):
+    """ReLU(LayerNorm_128(X) * gamma + beta)  (middle of models/common.py:99-119 MLP)."""
+
+    @staticmethod
+    def forward(ctx, X, gamma, beta):
+        X = _rowmajor(X)
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        Y = torch.empty(X.shape[0], 128, dtype=torch.float32, device=X.device)
+        hip.check(hip.lib().pg_ln_relu(X.data_ptr(), X.stride(0), gamma.data_ptr(), beta.data_ptr(), X.shape[0],
+                                       Y.data_ptr(), Y.stride(0), _st()), 'pg_ln_relu')
+        ctx.save_for_backward(X, gamma, beta)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        X, gamma, beta = ctx.saved_tensors
+        gY = _rowmajor(gY)
+        gX = torch.empty_like(X)
+        gg, gb = torch.zeros_like(gamma), torch.zeros_like(beta)
+        hip.check(hip.lib().pg_ln_relu_bwd(X.data_ptr(), X.stride(0), gamma.data_ptr(), beta.data_ptr(), gY.data_ptr(),
+                                           gY.stride(0), X.shape[0], gX.data_ptr(), gX.stride(0), gg.data_ptr(),
+                                           gb.data_ptr(), _st()), 'pg_ln_relu_bwd')
+        return gX, gg, gb
+
+
+def mlp(X, W1, b1, g, b, W2, b2):
+    """models/common.py:99-119 (Linear -> LayerNorm -> ReLU -> Linear) on 128 hidden channels."""
+    return linear(LnReluFn.apply(linear(X, W1, b1), g, b), W2, b2)
+
+
+def _fold(q, W2_l, ids, n_ids, out):
+    hip.check(hip.lib().pg_attn_fold_query(q.data_ptr(), q.stride(0), W2_l.data_ptr(), n_ids, hip.ptr(ids),
+                                           out.data_ptr(), _st()), 'pg_attn_fold_query')
+
+
+def _unfold(S, swn, W2_l, b2, ids, n_ids, out):
+    hip.check(hip.lib().pg_attn_unfold_value(S.data_ptr(), hip.ptr(swn), W2_l.data_ptr(), hip.ptr(b2), n_ids,
+                                             hip.ptr(ids), out.data_ptr(), out.stride(0), _st()), 'pg_attn_unfold_value')
+
+
+def _fold_wgrad(X, T, ids, n_ids, W2_l):
+    gW = torch.zeros_like(W2_l)
+    hip.check(hip.lib().pg_attn_fold_wgrad(X.data_ptr(), X.stride(0), T.data_ptr(), n_ids, hip.ptr(ids), gW.data_ptr(),
+                                           _st()), 'pg_attn_fold_wgrad')
+    return gW
+
+
+class FoldFn(torch.autograd.Function):
+    """U[s][c][h] = sum_d q[s,8h+d] W2k[8h+d,c]: second key Linear folded into the query (rows `ids`)."""
+
+    @staticmethod
+    def forward(ctx, q, W2_l, ids, n_ids):
+        q, W2_l = _rowmajor(q), W2_l.contiguous()
+        U = torch.zeros(q.shape[0], 2048, dtype=torch.float32, device=q.device)
+        _fold(q, W2_l, ids, n_ids, U)
+        ctx.save_for_backward(q, W2_l)
+        ctx.ids, ctx.n_ids = ids, n_ids
+        return U
+
+    @staticmethod
+    def backward(ctx, gU):
+        q, W2_l = ctx.saved_tensors
+        gU = gU.contiguous()
+        gq = torch.zeros_like(q)
+        _unfold(gU, None, W2_l, None, ctx.ids, ctx.n_ids, gq)
+        return gq, _fold_wgrad(q, gU, ctx.ids, ctx.n_ids, W2_l), None, None
+
+
+class UnfoldFn(torch.autograd.Function):
+    """out[s,8h+d] = sum_c W2v[8h+d,c] S[s][c][h] + b2v[8h+d] swn[s][h]: second value Linear after the aggregation."""
+
+    @staticmethod
+    def forward(ctx, S, swn, W2_l, b2, ids, n_ids):
+        S, swn, W2_l, b2 = S.contiguous(), swn.contiguous(), W2_l.contiguous(), b2.contiguous()
+        out = torch.zeros(S.shape[0], 128, dtype=torch.float32, device=S.device)
+        _unfold(S, swn, W2_l, b2, ids, n_ids, out)
+        ctx.save_for_backward(S, swn, W2_l, b2)
+        ctx.ids, ctx.n_ids = ids, n_ids
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        S, swn, W2_l, b2 = ctx.saved_tensors
+        gout = _rowmajor(gout)
+        gS = torch.zeros_like(S)
+        _fold(gout, W2_l, ctx.ids, ctx.n_ids, gS)
+        g3 = gout.reshape(-1, 16, 8)
+        sel = torch.zeros(S.shape[0], 1, 1, dtype=torch.float32, device=S.device)
+        idl = ctx.ids.long() if ctx.ids is not None else None
+        if idl is None:
+            sel += 1.0
+        else:
+            sel[idl] = 1.0
+        g3 = g3 * sel
+        gswn = (g3 * b2.view(1, 16, 8)).sum(-1)
+        gb2 = (g3 * swn.view(-1, 16, 1)).sum(0).reshape(128)
+        return gS, gswn, _fold_wgrad(gout, S, ctx.ids, ctx.n_ids, W2_l), gb2, None, None
+
+
+class SegCoreFn(torch.autograd.Function):
+    """pg_seg_attn between the folded query and the unfolded value: (S, swn) for the feature-update modes, dx for the
+    coordinate-update modes.  `cfg` carries the non-differentiable launch description."""
+
+    @staticmethod
+    def forward(ctx, cfg, Ydst, Ysrc, U, x, nrm, ew, Wf_k, Wf_v, bk, bv, W2xv_l, b2xv):
+        lib = hip.lib()
+        pos = cfg['mode'] in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
+        dev = Ydst.device
+        Ydst, Ysrc, U = _rowmajor(Ydst), _rowmajor(Ysrc), U.contiguous()
+        x = x.contiguous()
+        tensors = dict(Ydst=Ydst, Ysrc=Ysrc, U=U, x=x, nrm=None if nrm is None else nrm.contiguous(),
+                       ew=None if ew is None else ew.contiguous(), Wf_k=None if Wf_k is None else Wf_k.contiguous(),
+                       Wf_v=None if Wf_v is None else Wf_v.contiguous(), bk=bk.contiguous(), bv=bv.contiguous(),
+                       W2xv_l=None if W2xv_l is None else W2xv_l.contiguous(),
+                       b2xv=None if b2xv is None else b2xv.contiguous())
+        n_rows = cfg['n_out_rows']
+        if pos:
+            out = (torch.zeros(n_rows, 3, dtype=torch.float32, device=dev),)
+        else:
+            out = (torch.zeros(n_rows, 2048, dtype=torch.float32, device=dev),
+                   torch.zeros(n_rows, 16, dtype=torch.float32, device=dev))
+        s = SegCoreFn._struct(cfg, tensors)
+        if pos:
+            s.dx, s.accumulate_dx = out[0].data_ptr(), 0
+        else:
+            s.S, s.swn = out[0].data_ptr(), out[1].data_ptr()
+        hip.check(lib.pg_seg_attn(cfg['topo'], C.byref(s), _st()), 'pg_seg_attn')
+        ctx.cfg, ctx.tensors, ctx.pos = cfg, tensors, pos
+        return out if not pos else out[0]
+
+    @staticmethod
+    def _struct(cfg, t):
+        s = hip.PgSegAttn()
+        s.mode, s.n_seg, s.seg_ids, s.knn_k = cfg['mode'], cfg['n_seg'], hip.ptr(cfg['seg_ids']), cfg['k']
+        s.x, s.nrm, s.ew = t['x'].data_ptr(), hip.ptr(t['nrm']), hip.ptr(t['ew'])
+        s.nbr, s.deg = hip.ptr(cfg.get('nbr')), hip.ptr(cfg.get('deg'))
+        Yd, Ys = t['Ydst'], t['Ysrc']
+        s.Cdst_k, s.Cdst_v, s.ld_cdst = Yd.data_ptr(), Yd.data_ptr() + 128 * 4, Yd.stride(0)
+        s.Csrc_k, s.Csrc_v, s.ld_csrc = Ys.data_ptr(), Ys.data_ptr() + 128 * 4, Ys.stride(0)
+        s.Wf_k, s.Wf_v = hip.ptr(t['Wf_k']), hip.ptr(t['Wf_v'])
+        s.ln_gk, s.ln_bk, s.ln_gv, s.ln_bv = (t['bk'].data_ptr(), t['bk'].data_ptr(), t['bv'].data_ptr(),
+                                              t['bv'].data_ptr())
+        s.U = t['U'].data_ptr()
+        s.W2xv_l, s.b2xv = hip.ptr(t['W2xv_l']), hip.ptr(t['b2xv'])
+        return s
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib, cfg, t, pos = hip.lib(), ctx.cfg, ctx.tensors, ctx.pos
+        dev = t['x'].device
+        z = lambda ref: None if ref is None else torch.zeros_like(ref)
+        gYdst, gYsrc, gU = z(t['Ydst']), z(t['Ysrc']), z(t['U'])
+        gx = z(t['x']) if cfg['need_gx'] else None
+        gnrm = z(t['nrm']) if (cfg['need_gx'] and t['nrm'] is not None) else None
+        gew = z(t['ew'])
+        gWf_k, gWf_v, gbk, gbv = z(t['Wf_k']), z(t['Wf_v']), z(t['bk']), z(t['bv'])
+        gW2, gb2 = z(t['W2xv_l']), z(t['b2xv'])
+        g = hip.PgSegAttnGrad()
+        keep = []
+        if pos:
+            gdx = gouts[0].contiguous()
+            g.gdx = gdx.data_ptr()
+            keep.append(gdx)
+        else:
+            gS = gouts[0].contiguous() if gouts[0] is not None else torch.zeros(cfg['n_out_rows'], 2048, device=dev)
+            gsw = gouts[1].contiguous() if gouts[1] is not None else torch.zeros(cfg['n_out_rows'], 16, device=dev)
+            g.gS, g.gswn = gS.data_ptr(), gsw.data_ptr()
+            keep += [gS, gsw]
+        g.gU = gU.data_ptr()
+        g.gCdst_k, g.gCdst_v, g.ld_gcdst = gYdst.data_ptr(), gYdst.data_ptr() + 128 * 4, gYdst.stride(0)
+        g.gCsrc_k, g.gCsrc_v, g.ld_gcsrc = gYsrc.data_ptr(), gYsrc.data_ptr() + 128 * 4, gYsrc.stride(0)
+        g.gWf_k, g.gWf_v, g.gbk, g.gbv = hip.ptr(gWf_k), hip.ptr(gWf_v), gbk.data_ptr(), gbv.data_ptr()
+        g.gW2xv_l, g.gb2xv = hip.ptr(gW2), hip.ptr(gb2)
+        g.gx, g.gnrm, g.gew = hip.ptr(gx), hip.ptr(gnrm), hip.ptr(gew)
+        waves = lib.pg_seg_attn_bwd_waves(cfg['mode'])
+        grid = max(1, min((cfg['n_seg'] + waves - 1) // waves, 1024))
+        rows = (cfg['max_rows'] + 15) // 16 * 16
+        rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
+        g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
+        s = SegCoreFn._struct(cfg, t)
+        hip.check(lib.pg_seg_attn_bwd(cfg['topo'], C.byref(s), C.byref(g), _st()), 'pg_seg_attn_bwd')
+        # first-layer blocks: the k|v target halves live in Ydst[:, 0:256], the source halves in Ysrc[:, 0:256]
+        return (None, gYdst, gYsrc, gU, gx, gnrm, gew, gWf_k, gWf_v, gbk, gbv, gW2, gb2)
+
+
+def seg_core(cfg, Ydst, Ysrc, U, x, nrm=None, ew=None, Wf_k=None, Wf_v=None, bk=None, bv=None, W2xv_l=None, b2xv=None):
+    return SegCoreFn.apply(cfg, Ydst, Ysrc, U, x, nrm, ew, Wf_k, Wf_v, bk, bv, W2xv_l, b2xv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# model
+# ------------------------------------------------------------------------------------------------------------------
+def shifted_softplus(x):
+    return F.softplus(x) - 0.6931471805599453
+
+
+def gaussian_smearing(d):
+    off = torch.tensor(_SMEAR_OFF, dtype=torch.float32, device=d.device)
+    return torch.exp(-0.5 * (d.unsqueeze(-1) - off) ** 2)
+
+
+class TrainForward:
+    """Differentiable PhoreDiff.forward on one batch plan (same launch order as engine.Engine, autograd-composed)."""
+
+    def __init__(self, params, plan, knn_k=32, num_layers=6, ex_col=12):
+        self.lib = hip.lib()
+        self.sd, self.plan, self.k, self.L, self.ex_col = params, plan, knn_k, num_layers, ex_col
+        self.pack = ModelPack(params, num_layers, detach=False)
+        self.dev = plan.device
+
+    # -- one attention sub-layer: first-layer blocks Y [.., 640] = k_dst | v_dst | k_src | v_src | q_hid
+    def _attention(self, mode, a, Y, x, dst_lists, Ysrc=None, nrm=None, ew=None, nbr=None, deg=None, max_rows=None,
+                   need_gx=True):
+        p = self.plan
+        pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
+        knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
+        n = Y.shape[0]
+        q = linear(LnReluFn.apply(Y[:, 512:640], a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
+        Ydst = Y[:, 0:256]
+        if Ysrc is None:
+            Ysrc = Y[:, 256:512]
+        total = None
+        for seg_ids, n_seg, is_lig in dst_lists:
+            if n_seg == 0:
+                continue
+            U = FoldFn.apply(q, a.W2k_l, seg_ids, n_seg)
+            cfg = dict(mode=mode, n_seg=n_seg, seg_ids=seg_ids, k=self.k, topo=p.topo_ref, nbr=nbr, deg=deg,
+                       n_out_rows=n, max_rows=max_rows, need_gx=need_gx)
+            kw = {}
+            if knn:
+                kw.update(Wf_k=a.Wf_k[is_lig], Wf_v=a.Wf_v[is_lig])
+            elif mode == hip.SEG_PHORE:
+                kw.update(Wf_k=a.Wf_k, Wf_v=a.Wf_v)
+            if pos:
+                out = seg_core(cfg, Ydst, Ysrc, U, x, nrm, ew, bk=a.ln_bk, bv=a.ln_bv, W2xv_l=a.W2xv_l, b2xv=a.b2xv, **kw)
+            else:
+                S, swn = seg_core(cfg, Ydst, Ysrc, U, x, nrm, ew, bk=a.ln_bk, bv=a.ln_bv, **kw)
+                out = UnfoldFn.apply(S, swn, a.W2v_l, a.b2v, seg_ids, n_seg)
+            total = out if total is None else total + out
+        return total
+
+    def phore_encode(self, h_phore, pos_phore):
+        """diffusion.py:186-191: embedding -> p x p attention (output replaces the embedding)."""
+        p, pk = self.plan, self.pack
+        n = p.n_ctx
+        h_ctx = torch.zeros(n, h_phore.shape[1], dtype=torch.float32, device=self.dev).index_copy(0, p.phore2ctx_long, h_phore.float())
+        x_ctx = torch.zeros(n, 3, dtype=torch.float32, device=self.dev).index_copy(0, p.phore2ctx_long, pos_phore.float())
+        hp = linear(h_ctx, pk.W_pe, pk.b_pe)
+        Yp = linear(hp, pk.W_ph, pk.b_ph)
+        max_rows = int(p.g_nph.max()) if p.n_graphs else 0
+        enc = self._attention(hip.SEG_PHORE, pk.PH, Yp, x_ctx, [(p.phore2ctx, p.n_phore, False)], max_rows=max_rows,
+                              need_gx=False)
+        return enc.index_select(0, p.phore2ctx_long)
+
+    def atom_count(self, hp_emb, h_phore, batch_phore):
+        """diffusion.py:148-163."""
+        B = self.plan.n_graphs
+        sd = self.sd
+
+        def head(name, xx):
+            return torch.sigmoid(linear(torch.relu(linear(xx, sd[name + '.0.weight'], sd[name + '.0.bias'])),
+                                        sd[name + '.2.weight'], sd[name + '.2.bias']))
+
+        def seg_mean(v, idx):
+            c = torch.bincount(idx, minlength=B).clamp(min=1).unsqueeze(-1).to(v.dtype)
+            return torch.zeros(B, v.shape[1], dtype=v.dtype, device=v.device).index_add(0, idx, v) / c
+        c_all = seg_mean(head('atom_mlp', hp_emb), batch_phore)
+        m = h_phore[:, self.ex_col] != 1
+        c_l = seg_mean(head('atom_mlp_1', hp_emb[m]), batch_phore[m])
+        return c_l, c_l + F.relu(c_all - c_l)
+
+    def time_smearing(self, t):
+        off, coeff = self.sd['time_emb.0.offset'], self.sd['time_emb.0.coeff']
+        return torch.exp(coeff * (t.float().unsqueeze(-1) - off.view(1, -1)) ** 2)
+
+    def forward(self, h_node_pert, pos_pert, h_edge_pert, time_step, h_phore, pos_phore, phore_norm, batch_phore):
+        p, pk, sd, dev, lib = self.plan, self.pack, self.sd, self.dev, self.lib
+        n, E = p.n_ctx, p.n_bond
+        hp_emb = self.phore_encode(h_phore, pos_phore)
+        counts = self.atom_count(hp_emb, h_phore, batch_phore)
+        # embeddings (diffusion.py:180-183,205) and the ctx order of compose_context (common.py:180-208)
+        h_lig = torch.cat([linear(h_node_pert.float(), sd['node_embedder.weight']), self.time_smearing(time_step[p.batch_node])], -1)
+        hb = torch.cat([linear(h_edge_pert.float(), sd['edge_embedder.weight']), self.time_smearing(time_step[p.batch_edge])], -1)
+        h = torch.zeros(n, 128, dtype=torch.float32, device=dev).index_copy(0, p.lig2ctx_long, h_lig)
+        h = h.index_copy(0, p.phore2ctx_long, hp_emb)
+        x = torch.zeros(n, 3, dtype=torch.float32, device=dev).index_copy(0, p.lig2ctx_long, pos_pert.float())
+        x = x.index_copy(0, p.phore2ctx_long, pos_phore.float())
+        nrm_ph = torch.zeros(n, 3, dtype=torch.float32, device=dev).index_copy(0, p.phore2ctx_long, phore_norm.float())
+        is_lig = p.ctx_is_lig.bool().unsqueeze(-1)
+
+        # knn graph + global edge gate, once per forward (uni_denoiser.py:396-415)
+        nbr = torch.zeros(n, self.k, dtype=torch.int32, device=dev)
+        deg = torch.zeros(n, dtype=torch.int32, device=dev)
+        x0 = x.detach().contiguous()
+        hip.check(lib.pg_knn_ctx(p.topo_ref, x0.data_ptr(), self.k, nbr.data_ptr(), deg.data_ptr(), _st()), 'pg_knn_ctx')
+        slot_ok = torch.arange(self.k, device=dev).view(1, -1) < deg.view(-1, 1)
+        nbr_safe = torch.where(slot_ok, nbr.long(), torch.arange(n, device=dev).view(-1, 1).expand(-1, self.k))
+        dist = (x.unsqueeze(1) - x[nbr_safe]).pow(2).sum(-1).clamp(min=1e-24).sqrt()
+        gp = 'denoiser.edge_pred_layer.net.'
+        ew = torch.sigmoid(mlp(gaussian_smearing(dist.reshape(-1)), sd[gp + '0.weight'], sd[gp + '0.bias'], sd[gp + '1.weight'],
+                               sd[gp + '1.bias'], sd[gp + '3.weight'], sd[gp + '3.bias'])).view(n, self.k)
+        ew = ew * slot_ok.to(ew.dtype)
+
+        lig = [(p.lig2ctx, p.n_lig, True)]
+        both = [(p.lig2ctx, p.n_lig, True), (p.phore2ctx, p.n_phore, False)]
+        max_lig = int(p.num_atoms.max()) if p.n_graphs else 0
+        bsrc, bdst = p.bond_src.long(), p.bond_dst.long()
+        for L in pk.layers:
+            # direction vectors: mean of the 3 nearest ligand atoms - x (common.py:300-304), file normals for phore nodes
+            nn3 = torch.full((p.n_lig, 3), -1, dtype=torch.int32, device=dev)
+            xc = x.detach().contiguous()
+            hip.check(lib.pg_lig_nn3(p.topo_ref, xc.data_ptr(), nn3.data_ptr(), _st()), 'pg_lig_nn3')
+            ok = (nn3 >= 0).to(x.dtype).unsqueeze(-1)
+            nsum = (x[nn3.clamp(min=0).long()] * ok).sum(1)
+            l_norm = nsum / ok.sum(1).clamp(min=1.0) - x[p.lig2ctx_long]
+            nrm = nrm_ph.index_copy(0, p.lig2ctx_long, l_norm)
+            G = gaussian_smearing((x[bsrc] - x[bdst]).pow(2).sum(-1).clamp(min=1e-24).sqrt())        # [E,20]
+
+            Y1 = linear(h, L.W_node1, L.b_node1)                                       # [n,1920]
+            aggE = self._attention(hip.SEG_KNN_NODE, L.NE, Y1[:, 0:640], x, both, nrm=nrm, ew=ew, nbr=nbr, deg=deg,
+                                   max_rows=self.k)
+            CsB = linear(hb, L.NB.W_hb) + Y1[:, 7 * 128:9 * 128].index_select(0, bsrc)
+            aggB = self._attention(hip.SEG_BOND_NODE, L.NB, Y1[:, 640:1280], x, lig, Ysrc=CsB, max_rows=max_lig)
+            # bond update over triplets (uni_denoiser.py:101-165)
+            a = L.TB
+            P = (linear(torch.cat([hb, G], -1), a.W_hbg) + Y1[:, 10 * 128:12 * 128].index_select(0, bsrc)
+                 + Y1[:, 12 * 128:14 * 128].index_select(0, bdst))
+            Q = linear(G, torch.cat([a.Wg2_k.t(), a.Wg2_v.t()], 0))                    # smear(d_ji) columns, per segment
+            qhid = linear(hb, a.W_q_hb) + Y1[:, 14 * 128:15 * 128].index_select(0, bdst)
+            qT = linear(LnReluFn.apply(qhid, a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
+            U = FoldFn.apply(qT, a.W2k_l, None, E)
+            cfg = dict(mode=hip.SEG_TRIPLET, n_seg=E, seg_ids=None, k=self.k, topo=p.topo_ref, n_out_rows=E,
+                       max_rows=max_lig, need_gx=True)
+            S, swn = seg_core(cfg, Q, P, U, x, Wf_k=a.Wf_k, Wf_v=a.Wf_v, bk=a.ln_bk, bv=a.ln_bv)
+            hb_new = hb + UnfoldFn.apply(S, swn, a.W2v_l, a.b2v, None, E)
+            h_new = h + linear(aggE + aggB, L.W_lin, L.b_lin)
+            # coordinate updates from h', h_bond' and the old geometry (uni_denoiser.py:291-296)
+            Y2 = linear(h_new, L.W_node2, L.b_node2)
+            dxe = self._attention(hip.SEG_KNN_POS, L.PE, Y2[:, 0:640], x, lig, nrm=nrm, ew=ew, nbr=nbr, deg=deg,
+                                  max_rows=self.k)
+            CsB2 = linear(hb_new, L.PB.W_hb) + Y2[:, 7 * 128:9 * 128].index_select(0, bsrc)
+            dxb = self._attention(hip.SEG_BOND_POS, L.PB, Y2[:, 640:1280], x, lig, Ysrc=CsB2, max_rows=max_lig)
+            x = x + (dxe + dxb) * is_lig.to(x.dtype)
+            h, hb = h_new, hb_new
+
+        v0, b0 = pk.v0, pk.b0
+        v = linear(shifted_softplus(linear(h.index_select(0, p.lig2ctx_long), v0[0], v0[1])), v0[2], v0[3])
+        bond = linear(shifted_softplus(linear(hb, b0[0], b0[1])), b0[2], b0[3])
+        return v, x.index_select(0, p.lig2ctx_long), bond, counts
