@@ -297,6 +297,58 @@ def g_posterior(model):
     save('g_posterior', **arrays)
 
 
+def g6_compute_loss(model, name, seed, n_atoms, n_phore):
+    """G6: the reference's compute_loss (diffusion.py:249-352) + backward on a synthetic HeteroData batch; the draws of
+    sample_time / add_noise are recorded (torch.randint, Tensor.normal_, torch.rand_like)."""
+    from torch_geometric.data import Batch
+    from oracle.make_inputs import synthetic_train_batch
+    d = synthetic_train_batch(seed, n_atoms, n_phore)
+    data = Batch()
+    object.__setattr__(data, 'num_graphs', len(n_atoms))
+    data['ligand'].x, data['ligand'].pos = d['ligand_x'], d['ligand_pos']
+    data['ligand'].batch, data['ligand'].ptr = d['ligand_batch'], d['ligand_ptr']
+    e = data['ligand', 'ligand']
+    e.f_edge_index, e.f_edge_attr, e.f_edge_attr_batch = d['f_edge_index'], d['f_edge_attr'], d['f_edge_batch']
+    ph = data['phore']
+    ph.x, ph.pos, ph.norm, ph.batch = d['phore_x'], d['phore_pos'], d['phore_norm'], d['phore_batch']
+    seed_all(seed)
+    normal_draws = []
+    orig_normal = torch.Tensor.normal_
+
+    def rec_normal(self, *a, **k):
+        out = orig_normal(self, *a, **k)
+        normal_draws.append(out.detach().clone())
+        return out
+    model.zero_grad()
+    torch.Tensor.normal_ = rec_normal
+    try:
+        with RngTape() as tape:
+            loss, info = model.compute_loss(data)
+    finally:
+        torch.Tensor.normal_ = orig_normal
+    loss.backward()
+    draws = {n: [t for (nn_, t) in tape.tape if nn_ == n] for n in ('randint', 'rand_like')}
+    assert len(draws['randint']) == 1 and len(draws['rand_like']) == 2 and len(normal_draws) == 1, \
+        (len(draws['randint']), len(draws['rand_like']), len(normal_draws))
+    names = [k for k, p in model.named_parameters()]
+    gn = np.array([float(p.grad.norm()) if p.grad is not None else 0.0 for k, p in model.named_parameters()])
+    arrays = {k: v for k, v in d.items()}
+    arrays.update(time_draw=draws['randint'][0], pos_noise=normal_draws[0], u_node=draws['rand_like'][0],
+                  u_edge=draws['rand_like'][1], loss=loss.detach(),
+                  info_keys=np.array(sorted(info)), info_vals=np.array([info[k] for k in sorted(info)], dtype=np.float64),
+                  param_names=np.array(names), grad_norm=gn)
+    params = dict(model.named_parameters())
+    for k in ('v_inference.2.bias', 'bond_inference.0.bias', 'node_embedder.weight', 'edge_embedder.weight',
+              'atom_mlp.2.weight', 'phore_encoder.hq_func.net.0.bias', 'denoiser.edge_pred_layer.net.1.weight',
+              'denoiser.base_block.0.dire_embedding.weight', 'denoiser.base_block.0.bond_layer.hk_func.net.1.weight',
+              'denoiser.base_block.2.pos_layer_with_edge.xv_func.net.3.weight',
+              'denoiser.base_block.3.node_layer_with_bond.hv_func.net.3.bias',
+              'denoiser.base_block.5.pos_layer_with_bond.xq_func.net.3.bias', 'denoiser.base_block.5.lin_node.bias'):
+        arrays['grad::' + k] = params[k].grad
+    model.zero_grad()
+    save(name, **arrays)
+
+
 def g8_phore_parse():
     """datasets/get_phore_data.py:24-105 on a shipped pharmacophore file, no transform: the input side of `sample`."""
     path = os.path.join(ref_import.REFERENCE, 'data/phores_for_sampling/P03211_merge.phore')
@@ -342,5 +394,7 @@ if __name__ == '__main__':
     g5_sample(model, 'g5_sample_head3', seed=2032, n_atoms=[6, 9], n_steps=3, t_total=1000)
     g5_sample(model, 'g5_sample_tail4', seed=2033, n_atoms=[7, 5, 8], n_steps=4, t_total=4)
     g5_sample(model, 'g5_sample_full25', seed=2034, n_atoms=[8, 6], n_steps=25, t_total=25)
+    g6_compute_loss(model, 'g6_loss_a', seed=61, n_atoms=[6, 9], n_phore=[7, 12])
+    g6_compute_loss(model, 'g6_loss_b', seed=64, n_atoms=[11, 4, 8], n_phore=[23, 9, 15])
     g5_sample(model, 'g5_sample_guid3', seed=2035, n_atoms=[6, 7], n_steps=3, t_total=3,
               guidance=[{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}])

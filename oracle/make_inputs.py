@@ -41,3 +41,35 @@ def synthetic_batch(seed, n_atoms, n_phore, t_values):
                 edge_index=edge_index, batch_edge=batch_edge, time_step=torch.tensor(t_values),
                 h_phore=torch.cat(hp), pos_phore=torch.cat(pp), phore_norm=torch.cat(pn),
                 batch_phore=torch.cat(bp))
+
+
+def synthetic_train_batch(seed, n_atoms, n_phore):
+    """A synthetic `compute_loss` batch with the fields of SURVEY.md Appendix G (datasets/phoregen.py:356-384,
+    datasets/transform.py:488-501): atom classes 0..10, bond classes 0..4 on the complete directed graph in the
+    dst-major order of FeaturizeLigandBond, ligand coordinates centred on the pharmacophore centre."""
+    gen = torch.Generator().manual_seed(seed)
+    na = torch.tensor(n_atoms)
+    B = len(n_atoms)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), na.cumsum(0)])
+    srcs, dsts, attrs, ebat = [], [], [], []
+    for gi, n in enumerate(n_atoms):
+        dst = torch.repeat_interleave(torch.arange(n), n)
+        src = torch.arange(n).repeat(n)
+        m = dst != src
+        src, dst = src[m], dst[m]
+        sym = torch.randint(0, 5, (n, n), generator=gen)
+        sym = torch.where(torch.rand(n, n, generator=gen) < 0.7, torch.zeros_like(sym), sym)     # mostly "no bond"
+        sym = torch.triu(sym, 1)
+        sym = sym + sym.t()
+        srcs.append(src + off[gi]), dsts.append(dst + off[gi]), attrs.append(sym[src, dst])
+        ebat.append(torch.full((src.numel(),), gi))
+    N = int(na.sum())
+    hp, pp, pn, bp = [], [], [], []
+    for gi, p in enumerate(n_phore):
+        x, ps, nr = synthetic_phore(gen, p)
+        hp.append(x), pp.append(ps), pn.append(nr), bp.append(torch.full((p,), gi))
+    return dict(ligand_x=torch.randint(0, 11, (N,), generator=gen), ligand_pos=1.5 * torch.randn(N, 3, generator=gen),
+                ligand_batch=torch.repeat_interleave(torch.arange(B), na), ligand_ptr=off,
+                f_edge_index=torch.stack([torch.cat(srcs), torch.cat(dsts)]), f_edge_attr=torch.cat(attrs),
+                f_edge_batch=torch.cat(ebat), phore_x=torch.cat(hp), phore_pos=torch.cat(pp), phore_norm=torch.cat(pn),
+                phore_batch=torch.cat(bp))

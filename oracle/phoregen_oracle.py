@@ -219,6 +219,15 @@ def q_v_posterior(tab, log_v0, log_vt, t, batch):
     return torch.where((tb == 0).unsqueeze(-1), log_v0, out)
 
 
+def qd_loss(y_true, y_l, y_u, a=0.05, s=160, nd=15, factor=1, epsilon=1e-12):
+    """common.py:261-281 (mode='soft'): quality-driven interval loss of the atom-count heads."""
+    n = y_true.shape[0]
+    k_h = torch.relu(torch.sign(y_u - y_true)) * torch.relu(torch.sign(y_true - y_l))
+    k_s = torch.sigmoid((y_u - y_true) * s) * torch.sigmoid((y_true - y_l) * s)
+    mpiw = torch.sum((y_u - y_l) * k_h) / (torch.sum(k_h) + epsilon) * factor
+    return mpiw + (torch.relu((1 - a) - torch.mean(k_s)) ** 2) * (n ** 0.5) * nd
+
+
 def gumbel_argmax(logits, uniform):
     """common.py:425-431."""
     g = -torch.log(-torch.log(uniform + 1e-30) + 1e-30)
@@ -399,6 +408,56 @@ class Oracle:
         bond = self.lin('bond_inference.2', shifted_softplus(self.lin('bond_inference.0', h_bond)))
         return v, x[mask_l], bond, self.atom_count(hp, batch_phore, h_phore, B)
 
+    # ---- training objective (diffusion.py:249-352) with an explicit noise source ----
+    def compute_loss(self, b, rng, loss_weight=(1., 100., 100.), count_factor=1.):
+        """`b`: dict with the Appendix-G fields (ligand_x [N] int64, ligand_pos, ligand_batch, ligand_ptr,
+        f_edge_index [2,E] (any order of the complete directed graph), f_edge_attr [E], f_edge_batch, phore_*).
+        `rng` provides .randint(high, n), .randn(shape), .rand(shape) in the reference's draw order:
+        sample_time (diffusion.py:138-145), pos noise (transition.py:28-41), node Gumbel uniforms, edge Gumbel uniforms
+        (transition.py:245-263, common.py:425-431).  Returns (loss, dict)."""
+        B = int(b['ligand_ptr'].numel() - 1)
+        ts = rng.randint(self.T, B // 2 + 1)
+        t = torch.cat([ts, self.T - ts - 1])[:B]
+        bn, be = b['ligand_batch'], b['f_edge_batch']
+        ab = self.tab_pos['alphas_bar'][t][bn].unsqueeze(-1)
+        pos0 = b['ligand_pos']
+        pos_pert = ab.sqrt() * pos0 + (1 - ab).sqrt() * rng.randn(pos0.shape)
+
+        def noise_cat(tab, v, K, batch):
+            log_v0 = torch.log(F.one_hot(v, K).float().clamp(min=1e-30))                     # common.py:398-402
+            q = torch.einsum('bi,bij->bj', log_v0.exp(), tab['q_mats'][t[batch]])             # transition.py:265-271
+            log_q = torch.log(q + 1e-30).clamp_min(-32.)
+            cls = gumbel_argmax(log_q, rng.rand(log_q.shape))
+            return F.one_hot(cls, K).float(), torch.log(F.one_hot(cls, K).float().clamp(min=1e-30)), log_v0
+        h_node, log_node_t, log_node_0 = noise_cat(self.tab_node, b['ligand_x'], 12, bn)
+        h_edge, log_edge_t, log_edge_0 = noise_cat(self.tab_edge, b['f_edge_attr'], 6, be)
+        pred_node, pred_pos, pred_edge, (c_l, c_u) = self.forward(
+            h_node, pos_pert, bn, h_edge, b['f_edge_index'], be, t, b['phore_x'], b['phore_pos'], b['phore_norm'],
+            b['phore_batch'])
+        loss_pos = F.mse_loss(pred_pos, pos0) * loss_weight[0]
+
+        def cat_loss(tab, pred, log_t, log_0, batch):
+            log_rec = F.log_softmax(pred, -1)
+            post_true = q_v_posterior(tab, log_0, log_t, t, batch)
+            post_pred = q_v_posterior(tab, log_rec, log_t, t, batch)
+            kl = (post_true.exp() * (post_true - post_pred)).sum(-1)                           # common.py:434-436
+            nll = -(log_0.exp() * post_pred).sum(-1)                                           # common.py:439-440
+            m = (t == 0).float()[batch]
+            return torch.mean(m * nll + (1 - m) * kl)                                          # transition.py:317-329
+        loss_node = cat_loss(self.tab_node, pred_node, log_node_t, log_node_0, bn) * loss_weight[1]
+        loss_edge = cat_loss(self.tab_edge, pred_edge, log_edge_t, log_edge_0, be) * loss_weight[2]
+        true = ((b['ligand_ptr'][1:] - b['ligand_ptr'][:-1]).float() - self.min_atom) / (self.max_atom - self.min_atom)
+        loss_count = qd_loss(true.unsqueeze(-1), c_l, c_u, factor=count_factor)
+        loss = loss_pos + loss_node + loss_edge + loss_count
+
+        def acc(true_cls, logits, batch):                                                      # common.py:284-297
+            bad = torch.zeros(B).index_add(0, batch, (logits.argmax(-1) != true_cls).float())
+            return float((bad[batch.unique()] == 0).sum()) / batch.unique().numel()
+        info = dict(loss=loss.item(), loss_pos=loss_pos.item(), loss_node=loss_node.item(), loss_count=loss_count.item(),
+                    loss_edge=loss_edge.item(), node_acc=acc(b['ligand_x'], pred_node, bn),
+                    edge_acc=acc(b['f_edge_attr'], pred_edge, be))
+        return loss, info
+
     # ---- sampler (diffusion.py:391-525) with an explicit noise source ----
     def sample(self, h_phore, pos_phore, phore_norm, center, num_atoms, rng, t_total=None, guidance=None):
         """`rng` provides .randn(shape), .rand64(shape), .rand(shape) in the reference's draw order
@@ -481,6 +540,26 @@ class TapeRng:
         return torch.as_tensor(a)
 
     randn = rand = rand64 = _next
+
+
+class TrainTapeRng:
+    """Replays the recorded draws of one compute_loss call: randint, normal_, rand_like, rand_like."""
+
+    def __init__(self, time_draw, pos_noise, u_node, u_edge):
+        self.time_draw, self.pos_noise, self.u = time_draw, pos_noise, [u_node, u_edge]
+
+    def randint(self, high, n):
+        assert self.time_draw.numel() == n
+        return self.time_draw
+
+    def randn(self, shape):
+        assert tuple(shape) == tuple(self.pos_noise.shape)
+        return self.pos_noise
+
+    def rand(self, shape):
+        u = self.u.pop(0)
+        assert tuple(shape) == tuple(u.shape)
+        return u
 
 
 class TorchCpuRng:

@@ -41,6 +41,30 @@ class PhoreGraph:
         return PhoreGraph(st.x.clone(), st.pos.clone(), st.norm.clone(), self.center.clone(), self.name)
 
 
+class TrainBatch:
+    """The slice of a collated PyG HeteroData batch that PhoreDiff.compute_loss reads (SURVEY.md Appendix G;
+    datasets/phoregen.py:356-384 + DataLoader(follow_batch=['f_edge_attr']), run/run.py:96-101)."""
+
+    def __init__(self, ligand_x, ligand_pos, ligand_batch, ligand_ptr, f_edge_index, f_edge_attr, f_edge_batch,
+                 phore_x, phore_pos, phore_norm, phore_batch):
+        self.num_graphs = int(ligand_ptr.numel() - 1)
+        self._stores = {'ligand': _Store(x=ligand_x, pos=ligand_pos, batch=ligand_batch, ptr=ligand_ptr),
+                        ('ligand', 'ligand'): _Store(f_edge_index=f_edge_index, f_edge_attr=f_edge_attr,
+                                                     f_edge_attr_batch=f_edge_batch),
+                        'phore': _Store(x=phore_x, pos=phore_pos, norm=phore_norm, batch=phore_batch)}
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple) and len(key) == 3:
+            key = (key[0], key[2])
+        return self._stores[key]
+
+    def to(self, device):
+        for st in self._stores.values():
+            for k in list(st):
+                st[k] = st[k].to(device)
+        return self
+
+
 def parse_phore_file(path, center=True):
     """`.phore` text -> PhoreGraph with the 18-wide feature row of datasets/get_phore_data.py:24-73
     (13 type one-hot | alpha | has_norm one-hot 2 | exclusion one-hot 2), positions centred on the

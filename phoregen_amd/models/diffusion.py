@@ -1,8 +1,8 @@
 """PhoreDiff with the reference's nn.Module surface (models/diffusion.py:19-525), HIP-backed.
 
 Same constructor, same attribute / state_dict names, same `forward` and `sample` contracts, so the
-reference's sample_all.py can drive it.  `compute_loss` (training, config 5) needs backward kernels and
-is not available yet: it raises instead of silently falling back to a CPU path.
+reference's sample_all.py / train.py can drive it.  `compute_loss` (training, config 5) runs the same kernels with
+their hand-written HIP adjoints (phoregen_amd/training.py).
 
 Design differences that do not change results:
   * everything that is constant over the 1000 reverse steps is computed once per `sample` call:
@@ -74,6 +74,15 @@ class PhoreDiff(nn.Module):
         self._engine = None
 
     # ------------------------------------------------------------------ engine plumbing
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) (EMA helpers, tests): the kernel-side caches hold raw pointers and are rebuilt lazily."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            object.__setattr__(new, k, None if k in ('_pack', '_pack_version', '_plan', '_engine') else copy.deepcopy(v, memo))
+        return new
+
     @property
     def ex_col(self):
         return 12 if self.data_name in ('zinc_300', 'pdbbind') else 10          # diffusion.py:152-155
@@ -112,9 +121,97 @@ class PhoreDiff(nn.Module):
         w = eng.ws
         return v.clone(), x0, bond.clone(), (w.count_l.clone().unsqueeze(-1), w.count_u.clone().unsqueeze(-1))
 
-    def compute_loss(self, data):
-        raise NotImplementedError('phoregen_amd: compute_loss (training, SURVEY.md 8 a19) needs the backward kernels, '
-                                  'which are not built yet; there is deliberately no CPU fallback.')
+    # ------------------------------------------------------------------ training objective (diffusion.py:249-352)
+    def sample_time(self, num_graphs, device, **kwargs):
+        """diffusion.py:138-145: antithetic time steps."""
+        ts = torch.randint(0, self.num_timesteps, size=(num_graphs // 2 + 1,), device=device)
+        ts = torch.cat([ts, self.num_timesteps - ts - 1], dim=0)[:num_graphs]
+        return ts, torch.ones_like(ts).float() / self.num_timesteps
+
+    def compute_loss(self, data, draws=None):
+        """Reference contract: (loss with grad, dict of floats).  The denoiser forward and its adjoint run in the HIP
+        kernels (phoregen_amd/training.py); the noising, the posteriors and the loss terms are elementwise tensor ops
+        on the device.  `draws` (tests): dict(time_draw, pos_noise, u_node, u_edge) replaces the four random draws
+        of sample_time / add_noise (transition.py:28-41,245-263) in the reference's order."""
+        from ..training import TrainForward
+        dev = self._device()
+        if dev.type != 'cuda':
+            raise RuntimeError('phoregen_amd: compute_loss runs on the MI355X HIP path only (no CPU fallback)')
+        hip.lib()
+        lig, e, ph = data['ligand'], data['ligand', 'ligand'], data['phore']
+        B = int(data.num_graphs)
+        bn, be = lig.batch.to(dev), e.f_edge_attr_batch.to(dev)
+        pos0, x_cls, e_cls = lig.pos.to(dev).float(), lig.x.to(dev), e.f_edge_attr.to(dev)
+        T = self.num_timesteps
+        if draws is None:
+            t, _ = self.sample_time(B, dev)
+            eps = torch.zeros_like(pos0).normal_()
+            u_n = torch.rand(x_cls.numel(), 12, device=dev)
+            u_e = torch.rand(e_cls.numel(), 6, device=dev)
+        else:
+            ts = draws['time_draw'].to(dev)
+            t = torch.cat([ts, T - ts - 1], dim=0)[:B]
+            eps, u_n, u_e = draws['pos_noise'].to(dev), draws['u_node'].to(dev), draws['u_edge'].to(dev)
+        ab = self.pos_transition.alphas_bar[t][bn].unsqueeze(-1)
+        pos_pert = ab.sqrt() * pos0 + (1 - ab).sqrt() * eps                                  # transition.py:28-41
+
+        def noise_cat(tr, v, K, batch, u):
+            log_v0 = torch.log(F.one_hot(v, K).float().clamp(min=1e-30))                     # common.py:398-402
+            q = torch.einsum('bi,bij->bj', log_v0.exp(), tr.q_mats[t[batch]])                 # transition.py:265-271
+            cls = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + torch.log(q + tr.eps).clamp_min(-32.)).argmax(-1)
+            oh = F.one_hot(cls, K).float()
+            return oh, torch.log(oh.clamp(min=1e-30)), log_v0
+        h_node, log_node_t, log_node_0 = noise_cat(self.node_transition, x_cls, 12, bn, u_n)
+        h_edge, log_edge_t, log_edge_0 = noise_cat(self.edge_transition, e_cls, 6, be, u_e)
+
+        if self._plan is None or not self._plan.matches(lig.batch, ph.batch, e.f_edge_index):
+            self._plan = BatchPlan(lig.batch, ph.batch, e.f_edge_index, e.f_edge_attr_batch, B, dev)
+        params = {**dict(self.named_buffers()), **dict(self.named_parameters())}
+        tf = TrainForward(params, self._plan, knn_k=self.denoiser.k, num_layers=self.denoiser.num_layers, ex_col=self.ex_col)
+        pred_node, pred_pos, pred_edge, (c_l, c_u) = tf.forward(h_node, pos_pert, h_edge, t, ph.x.to(dev).float(),
+                                                                ph.pos.to(dev).float(), ph.norm.to(dev).float(),
+                                                                ph.batch.to(dev))
+        loss_pos = F.mse_loss(pred_pos, pos0) * self.loss_weight[0]
+
+        def posterior(tr, log_v0, log_vt, batch):                                              # transition.py:285-315
+            tb = t[batch]
+            f1 = torch.einsum('bj,bjk->bk', log_vt.exp(), tr.transpopse_q_onestep_mats[tb])
+            f2 = torch.einsum('bj,bjk->bk', log_v0.exp(), tr.q_mats[torch.clamp(tb - 1, min=0)])
+            out = torch.log(f1 + tr.eps).clamp_min(-32.) + torch.log(f2 + tr.eps).clamp_min(-32.)
+            out = out - torch.logsumexp(out, -1, keepdim=True)
+            return torch.where((tb == 0).unsqueeze(-1), log_v0, out)
+
+        def cat_loss(tr, pred, log_t, log_0, batch):                                           # transition.py:317-329
+            post_true = posterior(tr, log_0, log_t, batch)
+            post_pred = posterior(tr, F.log_softmax(pred, -1), log_t, batch)
+            kl = (post_true.exp() * (post_true - post_pred)).sum(-1)
+            nll = -(log_0.exp() * post_pred).sum(-1)
+            m = (t == 0).float()[batch]
+            return torch.mean(m * nll + (1 - m) * kl)
+        loss_node = cat_loss(self.node_transition, pred_node, log_node_t, log_node_0, bn) * self.loss_weight[1]
+        loss_edge = cat_loss(self.edge_transition, pred_edge, log_edge_t, log_edge_0, be) * self.loss_weight[2]
+        ptr = lig.ptr.to(dev)
+        true = ((ptr[1:] - ptr[:-1]).float() - self.min_atom) / (self.max_atom - self.min_atom)
+        loss_count = self.compute_count_loss(true.unsqueeze(-1), (c_l, c_u))
+        loss = loss_pos + loss_node + loss_edge + loss_count
+
+        def acc(true_cls, logits, batch):                                                      # common.py:284-297
+            bad = torch.zeros(B, device=dev).index_add(0, batch, (logits.argmax(-1) != true_cls).float())
+            present = torch.zeros(B, device=dev).index_add(0, batch, torch.ones_like(batch, dtype=torch.float32)) > 0
+            return float(((bad == 0) & present).sum()) / max(int(present.sum()), 1)
+        info = {'loss': loss.item(), 'loss_pos': loss_pos.item(), 'loss_node': loss_node.item(),
+                'loss_count': loss_count.item(), 'loss_edge': loss_edge.item(),
+                'node_acc': acc(x_cls, pred_node.detach(), bn), 'edge_acc': acc(e_cls, pred_edge.detach(), be)}
+        return loss, info
+
+    def compute_count_loss(self, true_norm, pred_count, a=0.05, s=160, nd=15, epsilon=1e-12):
+        """common.py:261-281 (qd_loss, mode='soft') on the normalised atom counts (diffusion.py:166-172)."""
+        y_l, y_u = pred_count
+        n = true_norm.shape[0]
+        k_h = torch.relu(torch.sign(y_u - true_norm)) * torch.relu(torch.sign(true_norm - y_l))
+        k_s = torch.sigmoid((y_u - true_norm) * s) * torch.sigmoid((true_norm - y_l) * s)
+        mpiw = torch.sum((y_u - y_l) * k_h) / (torch.sum(k_h) + epsilon) * self.count_factor
+        return mpiw + (torch.relu((1 - a) - torch.mean(k_s)) ** 2) * (n ** 0.5) * nd
 
     # ------------------------------------------------------------------ atom-count sampling (diffusion.py:355-387)
     @torch.no_grad()

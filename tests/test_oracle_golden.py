@@ -157,3 +157,35 @@ def test_g5_sampler(oracle, name):
         assert rmsd <= 1e-4, rmsd
         assert rel_err(res['pred'][1], g['pred_pos']) <= 5 * TOL
         assert np.array_equal(res['lig_info'][2].numpy(), g['lig_edge_index'])
+
+
+def _train_batch(g):
+    keys = ('ligand_x', 'ligand_pos', 'ligand_batch', 'ligand_ptr', 'f_edge_index', 'f_edge_attr', 'f_edge_batch',
+            'phore_x', 'phore_pos', 'phore_norm', 'phore_batch')
+    return {k: t(g[k]) for k in keys}
+
+
+@pytest.mark.parametrize('name', ['g6_loss_a', 'g6_loss_b'])
+def test_compute_loss_and_gradients_match_reference(name):
+    """G6: loss terms and every parameter-gradient norm of the reference's compute_loss + backward
+    (diffusion.py:249-352), replaying its recorded draws through the oracle's autograd."""
+    from oracle import phoregen_oracle as po
+    g = golden(name)
+    orc = make_oracle()
+    names = [str(k) for k in g['param_names']]
+    for k in names:
+        orc.sd[k].requires_grad_(True)
+    rng = po.TrainTapeRng(t(g['time_draw']), t(g['pos_noise']), t(g['u_node']), t(g['u_edge']))
+    loss, info = orc.compute_loss(_train_batch(g), rng)
+    ref = dict(zip([str(k) for k in g['info_keys']], g['info_vals']))
+    assert abs(float(loss) - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    for k, v in ref.items():
+        assert abs(info[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, info[k], v)
+    loss.backward()
+    gn = np.array([float(orc.sd[k].grad.norm()) if orc.sd[k].grad is not None else 0.0 for k in names])
+    big = g['grad_norm'] > 1e-4 * g['grad_norm'].max()
+    assert np.abs(gn - g['grad_norm'])[big].max() / g['grad_norm'][big].max() < 1e-4
+    assert (np.abs(gn - g['grad_norm'])[big] / g['grad_norm'][big]).max() < 2e-3
+    for key in g.files:
+        if key.startswith('grad::'):
+            assert rel_err(orc.sd[key[6:]].grad, g[key]) < 2e-3, key
