@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5: one forward + backward of PhoreDiff.compute_loss on 256 synthetic ligand-pharmacophore
+pairs (n ~ N(25,5^2) clamp [8,60] atoms, pharmacophores of the LigPhore shape, random bond labels), 1x MI355X.
+Prints one JSON line (ms per training step, and the share of the adjoint kernels when --profile is given)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from bench import ligphore_workload
+
+
+def train_workload(n_graphs=256, seed=4321):
+    from phoregen_amd.data import TrainBatch
+    g = torch.Generator().manual_seed(seed)
+    w = ligphore_workload(n_graphs, seed)
+    na = (25 + 5 * torch.randn(n_graphs, generator=g)).round().clamp(8, 60).long()
+    off = torch.cat([torch.zeros(1, dtype=torch.long), na.cumsum(0)])
+    N = int(na.sum())
+    srcs, dsts, attrs, eb = [], [], [], []
+    for gi, n in enumerate(na.tolist()):                      # datasets/transform.py:488-501 (dst-major complete graph)
+        dst = torch.repeat_interleave(torch.arange(n), n)
+        src = torch.arange(n).repeat(n)
+        m = dst != src
+        src, dst = src[m], dst[m]
+        sym = torch.randint(1, 5, (n, n), generator=g) * (torch.rand(n, n, generator=g) < 2.2 / n).long()
+        sym = torch.triu(sym, 1)
+        sym = sym + sym.t()
+        srcs.append(src + off[gi]); dsts.append(dst + off[gi]); attrs.append(sym[src, dst]); eb.append(torch.full((src.numel(),), gi))
+    batch = TrainBatch(torch.randint(0, 11, (N,), generator=g), 1.5 * torch.randn(N, 3, generator=g),
+                       torch.repeat_interleave(torch.arange(n_graphs), na), off,
+                       torch.stack([torch.cat(srcs), torch.cat(dsts)]), torch.cat(attrs), torch.cat(eb),
+                       w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'])
+    return batch, na
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--graphs', type=int, default=256)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    a = ap.parse_args()
+    from phoregen_amd.config import default_model_config
+    from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.weights import init_deterministic_
+    dev = 'cuda'
+    model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).to(dev)
+    batch, na = train_workload(a.graphs)
+    batch.to(dev)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    torch.manual_seed(0)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, info = model.compute_loss(batch)
+        loss.backward()
+        opt.step()
+        return info
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        info = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    e_bond = int((na * (na - 1)).sum()); e3 = int((na * (na - 1) * (na - 2)).sum())
+    print(json.dumps({'metric': 'train step (compute_loss forward + backward + Adam), batch=256', 'value': ms, 'unit': 'ms/step',
+                      'higher_is_better': False, 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'dtype': 'f32',
+                      'data': 'synthetic', 'config': {'workload': 'BASELINE.json configs[4]: 256 synthetic ligand-phore pairs, n~N(25,5)',
+                                                      'graphs': a.graphs, 'n_lig': int(na.sum()), 'e_bond': e_bond, 'e3': e3},
+                      'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30, 'last_loss': info['loss']}))
+
+
+if __name__ == '__main__':
+    main()
