@@ -109,8 +109,16 @@ __device__ __forceinline__ void ln_stats(const f4 (&hid)[8], float& rs, float& s
   sigma = var * rs;
 }
 
+// the row buffer is written and read by lanes of the same wave only: workgroup-scope ordering is enough (an agent-scope
+// fence writes the L2 back on a multi-XCD part)
+__device__ __forceinline__ void rowbuf_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct BwdLds {
-  float *wf_k, *wf_v, *acc_k, *acc_v, *bk, *bv;
+  float *wf_k, *wf_v, *acc_k, *acc_v, *bk, *bv, *accP;
   float *sT, *sF, *sGF, *sR;
   int* sI;
 };
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     L.acc_v = q; q += NSTEP * 512;
     L.bk = q; q += 128;
     L.bv = q; q += 128;
+    L.accP = q; if (T::TRI) q += (size_t)t.max_nlig * 256;      // triplet: d P[k -> j] of the workgroup's source atom
     q += wave * PW;
     L.sT = q; q += 128 * 17;
     L.sF = q; q += 16 * FS;
@@ -164,8 +173,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   float* const rb = gr.rowbuf + (size_t)(blockIdx.x * NW + wave) * gr.rowbuf_rows * ROWBUF;
   const float bx = T::POS ? p.b2xv[m] : 0.f;
 
-  for (int si = blockIdx.x * NW + wave; si < p.n_seg; si += gridDim.x * NW) {
-    const Seg<MODE> s = setup_seg<MODE>(t, p, si);
+  auto process = [&](const Seg<MODE>& s) {
     const int dst_ctx = T::TRI ? s.ci : s.seg;
     const int n_rows = s.n_rows;
     const int n_tiles = (n_rows + 15) >> 4;
@@ -263,8 +271,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         }
       }
     }
-    __threadfence();
-    __builtin_amdgcn_wave_barrier();
+    rowbuf_sync();
 
     // =============================== softmax backward per head m (rows r = g, g+4, ...) ===============================
     {
@@ -310,8 +317,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         rb[r * ROWBUF + 32 + m] = LN2 * a * (rb[r * ROWBUF + 32 + m] - D);
       }
     }
-    __threadfence();
-    __builtin_amdgcn_wave_barrier();
+    rowbuf_sync();
 
     // =============================== pass 2: gradients ===============================
     f4 gU[8];
@@ -510,8 +516,17 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
             const int ci = L.sI[rr];
             if (ci >= 0) {
               const float v0 = L.sT[lane * 17 + rr], v1 = L.sT[(64 + lane) * 17 + rr];
-              atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + lane, v0);
-              atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + 64 + lane, v1);
+              if constexpr (T::TRI) {
+                float* ap = L.accP + (tile * 16 + rr) * 256 + (kp ? 0 : 128);
+                atomicAdd(ap + lane, v0);
+                atomicAdd(ap + 64 + lane, v1);
+              } else if constexpr (T::BOND) {
+                gsrc[(size_t)ci * gr.ld_gcsrc + lane] = v0;
+                gsrc[(size_t)ci * gr.ld_gcsrc + 64 + lane] = v1;
+              } else {
+                atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + lane, v0);
+                atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + 64 + lane, v1);
+              }
               a0 += v0; a1 += v1;
             }
           }
@@ -616,7 +631,41 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       cv[lane] = gcd_v0; cv[64 + lane] = gcd_v1;
     }
     __builtin_amdgcn_wave_barrier();
-  }  // segments
+  };  // process(segment)
+
+  if constexpr (T::TRI) {
+    // one workgroup per source atom j: its n-1 segments (j -> i) all scatter into the rows P[k -> j], which no other
+    // source touches: accumulate them in LDS and store each row once
+    for (int a = blockIdx.x; a < t.n_lig; a += gridDim.x) {
+      const int cj = t.lig2ctx[a];
+      const int gi = t.ctx_graph[cj];
+      const int n = t.g_nlig[gi], lig0 = t.g_ctx_off[gi] + t.g_nph[gi], lj = cj - lig0;
+      const int* eid_g = t.eid + t.g_eid_off[gi];
+      for (int i = tid; i < n * 256; i += blockDim.x) L.accP[i] = 0.f;
+      __syncthreads();
+      for (int il = wave; il < n; il += NW) {
+        if (il == lj) continue;
+        Seg<MODE> s;
+        s.seg = eid_g[lj * n + il];
+        s.n_rows = s.n = n;
+        s.lig0 = lig0; s.li = il; s.lj = lj; s.first = 0;
+        s.ci = lig0 + il; s.cj = cj;
+        s.eid_g = eid_g;
+        process(s);
+      }
+      __syncthreads();
+      for (int i = tid; i < n * 256; i += blockDim.x) {
+        const int k = i >> 8, c = i & 255;
+        if (k == lj) continue;
+        const int e = eid_g[k * n + lj];
+        float* dst = (c < 128 ? gr.gCsrc_k : gr.gCsrc_v) + (size_t)e * gr.ld_gcsrc + (c & 127);
+        *dst = L.accP[i];
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int si = blockIdx.x * NW + wave; si < p.n_seg; si += gridDim.x * NW) process(setup_seg<MODE>(t, p, si));
+  }
 
   // ---------------- flush the weight-gradient accumulators ----------------
   __syncthreads();
@@ -647,15 +696,16 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32;
-  const size_t lds = ((size_t)4 * NSTEP * 512 + 256 + (size_t)NW * PW) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t lds = ((size_t)4 * NSTEP * 512 + 256 + (T::TRI ? (size_t)t->max_nlig * 256 : 0) + (size_t)NW * PW) * sizeof(float);
+  if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
+  static size_t attr_set = 0;
+  if (attr_set < lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("pg_seg_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = true;
+    attr_set = lds;
   }
-  int blocks = (p->n_seg + NW - 1) / NW;
+  int blocks = T::TRI ? t->n_lig : (p->n_seg + NW - 1) / NW;
   if (blocks > gr->grid) blocks = gr->grid;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr);
@@ -666,7 +716,7 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
 
 using namespace pg;
 
-extern "C" int pg_seg_attn_bwd_waves(int mode) { return (mode == PG_SEG_KNN_NODE || mode == PG_SEG_KNN_POS) ? 2 : 4; }
+extern "C" int pg_seg_attn_bwd_waves(int mode) { (void)mode; return 4; }
 
 extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, void* stream) {
   if (!t || !p || !gr) { set_error("pg_seg_attn_bwd: null argument"); return PG_ERR_ARG; }
@@ -677,8 +727,8 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
   }
   hipStream_t st = (hipStream_t)stream;
   switch (p->mode) {
-    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 2>(t, p, gr, st);
-    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 2>(t, p, gr, st);
+    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 4>(t, p, gr, st);
+    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
     case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
     case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
     case PG_SEG_TRIPLET: return launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);

@@ -130,7 +130,7 @@ class FoldFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, W2_l, ids, n_ids):
         q, W2_l = _rowmajor(q), W2_l.contiguous()
-        U = torch.zeros(q.shape[0], 2048, dtype=torch.float32, device=q.device)
+        U = (torch.zeros if ids is not None else torch.empty)(q.shape[0], 2048, dtype=torch.float32, device=q.device)
         _fold(q, W2_l, ids, n_ids, U)
         ctx.save_for_backward(q, W2_l)
         ctx.ids, ctx.n_ids = ids, n_ids
@@ -140,7 +140,7 @@ class FoldFn(torch.autograd.Function):
     def backward(ctx, gU):
         q, W2_l = ctx.saved_tensors
         gU = gU.contiguous()
-        gq = torch.zeros_like(q)
+        gq = torch.zeros_like(q) if ctx.ids is not None else torch.empty_like(q)
         _unfold(gU, None, W2_l, None, ctx.ids, ctx.n_ids, gq)
         return gq, _fold_wgrad(q, gU, ctx.ids, ctx.n_ids, W2_l), None, None
 
@@ -151,7 +151,7 @@ class UnfoldFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, S, swn, W2_l, b2, ids, n_ids):
         S, swn, W2_l, b2 = S.contiguous(), swn.contiguous(), W2_l.contiguous(), b2.contiguous()
-        out = torch.zeros(S.shape[0], 128, dtype=torch.float32, device=S.device)
+        out = (torch.zeros if ids is not None else torch.empty)(S.shape[0], 128, dtype=torch.float32, device=S.device)
         _unfold(S, swn, W2_l, b2, ids, n_ids, out)
         ctx.save_for_backward(S, swn, W2_l, b2)
         ctx.ids, ctx.n_ids = ids, n_ids
@@ -161,7 +161,7 @@ class UnfoldFn(torch.autograd.Function):
     def backward(ctx, gout):
         S, swn, W2_l, b2 = ctx.saved_tensors
         gout = _rowmajor(gout)
-        gS = torch.zeros_like(S)
+        gS = torch.zeros_like(S) if ctx.ids is not None else torch.empty_like(S)
         _fold(gout, W2_l, ctx.ids, ctx.n_ids, gS)
         g3 = gout.reshape(-1, 16, 8)
         sel = torch.zeros(S.shape[0], 1, 1, dtype=torch.float32, device=S.device)
@@ -193,11 +193,12 @@ class SegCoreFn(torch.autograd.Function):
                        W2xv_l=None if W2xv_l is None else W2xv_l.contiguous(),
                        b2xv=None if b2xv is None else b2xv.contiguous())
         n_rows = cfg['n_out_rows']
+        full = cfg['seg_ids'] is None and cfg['n_seg'] == n_rows        # every output row is written by the kernel
+        alloc = torch.empty if full else torch.zeros
         if pos:
-            out = (torch.zeros(n_rows, 3, dtype=torch.float32, device=dev),)
+            out = (alloc(n_rows, 3, dtype=torch.float32, device=dev),)
         else:
-            out = (torch.zeros(n_rows, 2048, dtype=torch.float32, device=dev),
-                   torch.zeros(n_rows, 16, dtype=torch.float32, device=dev))
+            out = (alloc(n_rows, 2048, dtype=torch.float32, device=dev), alloc(n_rows, 16, dtype=torch.float32, device=dev))
         s = SegCoreFn._struct(cfg, tensors)
         if pos:
             s.dx, s.accumulate_dx = out[0].data_ptr(), 0
@@ -228,7 +229,10 @@ class SegCoreFn(torch.autograd.Function):
         lib, cfg, t, pos = hip.lib(), ctx.cfg, ctx.tensors, ctx.pos
         dev = t['x'].device
         z = lambda ref: None if ref is None else torch.zeros_like(ref)
-        gYdst, gYsrc, gU = z(t['Ydst']), z(t['Ysrc']), z(t['U'])
+        full = cfg['seg_ids'] is None and cfg['n_seg'] == cfg['n_out_rows']
+        gYdst, gU = (torch.empty_like(t['Ydst']), torch.empty_like(t['U'])) if full else (z(t['Ydst']), z(t['U']))
+        # bond / triplet modes store every dCsrc row exactly once; the knn / phore modes accumulate with atomics
+        gYsrc = torch.empty_like(t['Ysrc']) if (full and cfg['mode'] == hip.SEG_TRIPLET) else z(t['Ysrc'])
         gx = z(t['x']) if cfg['need_gx'] else None
         gnrm = z(t['nrm']) if (cfg['need_gx'] and t['nrm'] is not None) else None
         gew = z(t['ew'])
