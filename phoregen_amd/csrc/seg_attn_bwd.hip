@@ -164,11 +164,10 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     return f < F ? wf[((f >> 2) * 8 + (c >> 4)) * 64 + (f & 3) * 16 + (c & 15)] : 0.f;
   };
 
-  f4 gbk_acc[8], gbv_acc[8], gw2_acc[8];
+  f4 gw2_acc[8];
 #pragma unroll
-  for (int tq = 0; tq < 8; ++tq) {
-    gbk_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f}; gbv_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f}; gw2_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int tq = 0; tq < 8; ++tq) gw2_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f};
+  float gbk0 = 0.f, gbk1 = 0.f, gbv0 = 0.f, gbv1 = 0.f;        // d b'[lane], d b'[lane + 64] of the two paths
   float gbx_acc = 0.f;
   float* const rb = gr.rowbuf + (size_t)(blockIdx.x * NW + wave) * gr.rowbuf_rows * ROWBUF;
   const float bx = T::POS ? p.b2xv[m] : 0.f;
@@ -178,17 +177,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     const int n_rows = s.n_rows;
     const int n_tiles = (n_rows + 15) >> 4;
 
-    // ---- per-segment constants in the transposed layout (c = 16 tau + 4g + r) ----
-    f4 cdk[8], cdv[8];
-    {
-      const float* ck = p.Cdst_k + (size_t)s.seg * p.ld_cdst;
-      const float* cv = p.Cdst_v + (size_t)s.seg * p.ld_cdst;
-#pragma unroll
-      for (int tq = 0; tq < 8; ++tq) {
-        cdk[tq] = *reinterpret_cast<const f4*>(ck + 16 * tq + 4 * g);
-        cdv[tq] = *reinterpret_cast<const f4*>(cv + 16 * tq + 4 * g);
-      }
-    }
+    // per-segment constants (Cdst rows) are re-read where used: they stay in L1 and cost no live registers
+    const float* const cdk = p.Cdst_k + (size_t)s.seg * p.ld_cdst + 4 * g;
+    const float* const cdv = p.Cdst_v + (size_t)s.seg * p.ld_cdst + 4 * g;
     const float* Uk = p.U + (size_t)s.seg * 2048;                                     // [c][h] lane-fixed
     const float* Mv = T::POS ? p.W2xv_l : gr.gS + (size_t)s.seg * 2048;              // [c][h] lane-fixed
     auto m_plain = [&](const float* M, int c, int h) -> float {                       // M[c][h] out of the lane-fixed layout
@@ -214,31 +205,28 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     const float gswn_m = T::POS ? 0.f : gr.gswn[(size_t)s.seg * 16 + m];
 
     // hidden^T tile of one path: gather + per-segment constant + feature product
-    auto hidden_tile = [&](const float* Csrc, const f4* cd, const float* wf, const RowInfo& rk, const float (&feat)[NS],
+    auto hidden_tile = [&](const float* Csrc, const float* cd, const float* wf, const RowInfo& rk, const float (&feat)[NS],
                            f4 (&hid)[8]) {
       const float* pk = Csrc + (size_t)rk.csrc * p.ld_csrc + 4 * g;
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq) {
         f4 c = {0.f, 0.f, 0.f, 0.f};
         if (rk.valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
-        hid[tq] = c + cd[tq];
+        hid[tq] = c + *reinterpret_cast<const f4*>(cd + 16 * tq);
       }
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf[(st * 8 + tq) * 64 + lane], feat[st], hid[tq]);
     };
-    // z = ReLU(hidden + b' sigma) in place, then y[row = 4g+r][h = m] = z . M[:,h]   (unscaled by rstd)
-    auto relu_project = [&](f4 (&hid)[8], const float* bp, float sigma, const float* M) -> f4 {
+    // y[row = 4g+r][h = m] = ReLU(hidden + b' sigma) . M[:,h]   (unscaled by rstd); hidden stays as it is
+    auto relu_project = [&](const f4 (&hid)[8], const float* bp, float sigma, const float* M) -> f4 {
       f4 y = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq) {
         const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          hid[tq][r] = fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f);
-          y = mfma16(hid[tq][r], M[(tq * 4 + r) * 64 + lane], y);
-        }
+        for (int r = 0; r < 4; ++r) y = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), M[(tq * 4 + r) * 64 + lane], y);
       }
       return y;
     };
@@ -355,13 +343,11 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         const float* wf = kp ? L.wf_k : L.wf_v;
         float* acc = kp ? L.acc_k : L.acc_v;
         const float* M = kp ? Uk : Mv;
-        f4 hid[8], z[8];
+        f4 hid[8];
         float rs, sg;
         hidden_tile(kp ? p.Csrc_k : p.Csrc_v, kp ? cdk : cdv, wf, rk, feat, hid);
         ln_stats(hid, rs, sg);
-#pragma unroll
-        for (int tq = 0; tq < 8; ++tq) z[tq] = hid[tq];
-        const f4 y = relu_project(z, bp, sg, M);                    // z = ReLU(..) now; y unscaled, rows 4g+r, head m
+        const f4 y = relu_project(hid, bp, sg, M);                  // y unscaled, rows 4g+r, head m
         // coefficient of y in the loss, rows 4g+r: k path dlogit ; v path cw * alpha
         f4 coefD;
 #pragma unroll
@@ -421,9 +407,11 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         if (g == 0) L.sR[16 + m] = rs;
         // z^T tile to LDS for the products contracted over rows
 #pragma unroll
-        for (int tq = 0; tq < 8; ++tq)
+        for (int tq = 0; tq < 8; ++tq) {
+          const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = z[tq][r];
+          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = fmaxf(fmaf(bt[r], sg, hid[tq][r]), 0.f);
+        }
         wave_lds_sync();
         const float grs = L.sR[m];
         // dM[c,h] += sum_row z[c,row] * rstd[row] * coef[row,h]      (k path: dU; pos v path: dW2xv)
@@ -459,26 +447,34 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            gz[tq][r] = z[tq][r] > 0.f ? gz[tq][r] : 0.f;
+            gz[tq][r] = fmaf(bt[r], sg, hid[tq][r]) > 0.f ? gz[tq][r] : 0.f;
             s1 = fmaf(gz[tq][r], bt[r], s1);
           }
         }
         s1 += __shfl_xor(s1, 16);
         s1 += __shfl_xor(s1, 32);
         const float gvar = 0.5f * rs * s1 - 0.5f * grs * rs * rs * rs;
-        f4* gb_acc = kp ? gbk_acc : gbv_acc;
+        wave_lds_sync();   // products over sT (z) are done
+        // d b'[c] += sum_row dpre[c,row] * sigma[row]: through the LDS tile, each lane sums its two channels
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = gz[tq][r] * sg;
+        wave_lds_sync();
+        {
+          float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < 16; ++rr) { a0 += L.sT[lane * 17 + rr]; a1 += L.sT[(64 + lane) * 17 + rr]; }
+          if (kp) { gbk0 += a0; gbk1 += a1; } else { gbv0 += a0; gbv1 += a1; }
+        }
+        wave_lds_sync();
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            gb_acc[tq][r] = fmaf(gz[tq][r], sg, gb_acc[tq][r]);
             gz[tq][r] = fmaf(gvar * (1.f / 64.f), hid[tq][r], gz[tq][r]);       // d hidden
+            L.sT[(16 * tq + 4 * g + r) * 17 + m] = gz[tq][r];
           }
-        wave_lds_sync();   // products over sT (z) are done
-#pragma unroll
-        for (int tq = 0; tq < 8; ++tq)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = gz[tq][r];
         wave_lds_sync();
         if constexpr (NSTEP > 0) {
           // d feat[row, f] += sum_c dhidden[c,row] * Wf[c,f]
@@ -673,17 +669,14 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     if (L.acc_k[i] != 0.f) atomicAdd(gr.gWf_k + i, L.acc_k[i]);
     if (L.acc_v[i] != 0.f) atomicAdd(gr.gWf_v + i, L.acc_v[i]);
   }
+  atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1);
+  atomicAdd(gr.gbv + lane, gbv0); atomicAdd(gr.gbv + 64 + lane, gbv1);
+  if constexpr (T::POS) {
 #pragma unroll
-  for (int tq = 0; tq < 8; ++tq)
+    for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float a = row16_total(gbk_acc[tq][r]), b = row16_total(gbv_acc[tq][r]);
-      if (m == 0) {
-        atomicAdd(gr.gbk + 16 * tq + 4 * g + r, a);
-        atomicAdd(gr.gbv + 16 * tq + 4 * g + r, b);
-      }
-      if constexpr (T::POS) atomicAdd(gr.gW2xv_l + (tq * 4 + r) * 64 + lane, gw2_acc[tq][r]);
-    }
+      for (int r = 0; r < 4; ++r) atomicAdd(gr.gW2xv_l + (tq * 4 + r) * 64 + lane, gw2_acc[tq][r]);
+  }
   if constexpr (T::POS) {
     gbx_acc += __shfl_xor(gbx_acc, 16);
     gbx_acc += __shfl_xor(gbx_acc, 32);
@@ -716,7 +709,7 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
 
 using namespace pg;
 
-extern "C" int pg_seg_attn_bwd_waves(int mode) { (void)mode; return 4; }
+extern "C" int pg_seg_attn_bwd_waves(int mode) { return mode == PG_SEG_TRIPLET ? 8 : 4; }   // upper bound (row-buffer sizing)
 
 extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, void* stream) {
   if (!t || !p || !gr) { set_error("pg_seg_attn_bwd: null argument"); return PG_ERR_ARG; }
@@ -731,7 +724,8 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
     case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
     case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
     case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
-    case PG_SEG_TRIPLET: return launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
+    case PG_SEG_TRIPLET:   // 8 waves (2 per SIMD) share one LDS accumulator of the source atom's rows when it fits
+      return t->max_nlig <= 44 ? launch_bwd<PG_SEG_TRIPLET, 8>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
     case PG_SEG_PHORE: return launch_bwd<PG_SEG_PHORE, 4>(t, p, gr, st);
   }
   set_error("pg_seg_attn_bwd: unknown mode %d", p->mode);
