@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from phoregen_amd.parallel import gather_predictions, partition_graphs
+from phoregen_amd.parallel import allreduce_gradients, gather_predictions, partition_graphs
 
 
 def _free_port():
@@ -63,3 +63,35 @@ def test_gather_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+        net[1].bias.requires_grad_(False)
+        for i, p in enumerate(net.parameters()):
+            if p.requires_grad and not (rank == 1 and i == 0):          # rank 1 has no gradient for the first tensor
+                p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        n = allreduce_gradients(net.parameters())
+        exp = {0: 0.5 * 1.0, 1: 1.5 * 2.0, 2: 1.5 * 3.0}                # mean over ranks of (rank+1)*(i+1); tensor 0: (1+0)/2
+        ok = n == 7 * 5 + 5 + 5 * 3 and all(torch.allclose(p.grad, torch.full_like(p, exp[i]))
+                                             for i, p in enumerate(net.parameters()) if p.requires_grad)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce_world_size_2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: True, 1: True}
