@@ -22,6 +22,19 @@
 
 namespace pg {
 
+#ifdef PG_BWD_PROF
+__device__ unsigned long long g_bwd_prof[16];
+#define PROF_DECL() long long _pacc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long _t0 = 0
+#define PROF_T0() _t0 = __builtin_readcyclecounter()
+#define PROF(i) do { long long _t1 = __builtin_readcyclecounter(); _pacc[i] += _t1 - _t0; _t0 = _t1; } while (0)
+#define PROF_FLUSH() do { if (lane == 0) for (int _i = 0; _i < 13; ++_i) atomicAdd(&g_bwd_prof[_i], (unsigned long long)_pacc[_i]); } while (0)
+#else
+#define PROF_DECL() do {} while (0)
+#define PROF_T0() do {} while (0)
+#define PROF(i) do {} while (0)
+#define PROF_FLUSH() do {} while (0)
+#endif
+
 namespace {
 
 constexpr float LN2 = 0.69314718055994530942f;
@@ -118,19 +131,19 @@ __device__ __forceinline__ void rowbuf_sync() {
 }
 
 struct BwdLds {
-  float *wf_k, *wf_v, *acc_k, *acc_v, *bk, *bv, *accP;
-  float *sT, *sF, *sGF, *sR;
+  float *wf_k, *wf_v, *acc_k, *acc_v, *bk, *bv, *accP, *wfp_k, *wfp_v;
+  float *sT, *sF, *sGF, *sR, *sC;
   int* sI;
 };
 
 }  // namespace
 
 template <int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAttn p, PgSegAttnGrad gr) {
+__global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAttn p, PgSegAttnGrad gr, int ab) {
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
   constexpr int FS = 16 * NF + 1;
-  constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32;       // per-wave floats
+  constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;       // per-wave floats
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, m = lane & 15;
@@ -144,18 +157,29 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     L.acc_v = q; q += NSTEP * 512;
     L.bk = q; q += 128;
     L.bv = q; q += 128;
-    L.accP = q; if (T::TRI) q += (size_t)t.max_nlig * 256;      // triplet: d P[k -> j] of the workgroup's source atom
+    L.accP = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * 256;   // triplet: d P[k -> j] of the workgroup's source atom
+    L.wfp_k = q; if (NFT == 1) q += 128 * 17;                  // Wf[c][f] (stride 17) for d feat = Wf^T . d hidden
+    L.wfp_v = q; if (NFT == 1) q += 128 * 17;
     q += wave * PW;
     L.sT = q; q += 128 * 17;
     L.sF = q; q += 16 * FS;
     L.sGF = q; q += 16 * FS;
     L.sR = q; q += 64;
-    L.sI = reinterpret_cast<int*>(q);
+    L.sI = reinterpret_cast<int*>(q); q += 32;
+    L.sC = q;
   }
   for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
     L.wf_k[i] = p.Wf_k[i]; L.wf_v[i] = p.Wf_v[i]; L.acc_k[i] = 0.f; L.acc_v[i] = 0.f;
   }
   for (int i = tid; i < 128; i += blockDim.x) { L.bk[i] = p.ln_bk[i]; L.bv[i] = p.ln_bv[i]; }
+  if constexpr (NFT == 1) {
+    for (int i = tid; i < 128 * 16; i += blockDim.x) {
+      const int c = i >> 4, f = i & 15;
+      const int src = ((f >> 2) * 8 + (c >> 4)) * 64 + (f & 3) * 16 + (c & 15);
+      L.wfp_k[c * 17 + f] = f < F ? p.Wf_k[src] : 0.f;
+      L.wfp_v[c * 17 + f] = f < F ? p.Wf_v[src] : 0.f;
+    }
+  }
   for (int i = lane; i < 16 * FS; i += 64) { L.sF[i] = 0.f; L.sGF[i] = 0.f; }
   __syncthreads();
 
@@ -168,23 +192,39 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq) gw2_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f};
   float gbk0 = 0.f, gbk1 = 0.f, gbv0 = 0.f, gbv1 = 0.f;        // d b'[lane], d b'[lane + 64] of the two paths
+  f4 gwf_acc[2][8];                                            // d Wf of the single-f-tile modes: [path][tau] -> (c = 16 tau + 4g + r, f = m)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int tq = 0; tq < 8; ++tq) gwf_acc[a][tq] = (f4){0.f, 0.f, 0.f, 0.f};
   float gbx_acc = 0.f;
   float* const rb = gr.rowbuf + (size_t)(blockIdx.x * NW + wave) * gr.rowbuf_rows * ROWBUF;
   const float bx = T::POS ? p.b2xv[m] : 0.f;
 
+  PROF_DECL();
   auto process = [&](const Seg<MODE>& s) {
     const int dst_ctx = T::TRI ? s.ci : s.seg;
     const int n_rows = s.n_rows;
     const int n_tiles = (n_rows + 15) >> 4;
 
-    // per-segment constants (Cdst rows) are re-read where used: they stay in L1 and cost no live registers
-    const float* const cdk = p.Cdst_k + (size_t)s.seg * p.ld_cdst + 4 * g;
-    const float* const cdv = p.Cdst_v + (size_t)s.seg * p.ld_cdst + 4 * g;
-    const float* Uk = p.U + (size_t)s.seg * 2048;                                     // [c][h] lane-fixed
-    const float* Mv = T::POS ? p.W2xv_l : gr.gS + (size_t)s.seg * 2048;              // [c][h] lane-fixed
-    auto m_plain = [&](const float* M, int c, int h) -> float {                       // M[c][h] out of the lane-fixed layout
-      return M[((c >> 4) * 4 + (c & 3)) * 64 + ((c >> 2) & 3) * 16 + h];
-    };
+    // one global round trip per segment: the Cdst rows go to LDS, U and M (dS of the segment / W2xv) to registers in
+    // the B-operand layout of the projections (lane-fixed [c = 16 tau + 4g + r][h = m])
+    L.sC[lane] = p.Cdst_k[(size_t)s.seg * p.ld_cdst + lane];
+    L.sC[64 + lane] = p.Cdst_k[(size_t)s.seg * p.ld_cdst + 64 + lane];
+    L.sC[128 + lane] = p.Cdst_v[(size_t)s.seg * p.ld_cdst + lane];
+    L.sC[192 + lane] = p.Cdst_v[(size_t)s.seg * p.ld_cdst + 64 + lane];
+    f4 Ur[8], Mr[8];
+    {
+      const float* Uk = p.U + (size_t)s.seg * 2048 + lane;
+      const float* Mv = (T::POS ? p.W2xv_l : gr.gS + (size_t)s.seg * 2048) + lane;
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Ur[tq][r] = Uk[(tq * 4 + r) * 64]; Mr[tq][r] = Mv[(tq * 4 + r) * 64]; }
+    }
+    wave_lds_sync();
+    const float* const cdk = L.sC + 4 * g;
+    const float* const cdv = L.sC + 128 + 4 * g;
     float xd[3] = {0.f, 0.f, 0.f}, nd[3] = {0.f, 0.f, 0.f}, xj[3] = {0.f, 0.f, 0.f}, gdx[3] = {0.f, 0.f, 0.f};
     if constexpr (T::KNN || T::PH || T::POS || T::TRI) {
 #pragma unroll
@@ -220,19 +260,21 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf[(st * 8 + tq) * 64 + lane], feat[st], hid[tq]);
     };
     // y[row = 4g+r][h = m] = ReLU(hidden + b' sigma) . M[:,h]   (unscaled by rstd); hidden stays as it is
-    auto relu_project = [&](const f4 (&hid)[8], const float* bp, float sigma, const float* M) -> f4 {
+    auto relu_project = [&](const f4 (&hid)[8], const float* bp, float sigma, const f4 (&M)[8]) -> f4 {
       f4 y = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq) {
         const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), M[(tq * 4 + r) * 64 + lane], y);
+        for (int r = 0; r < 4; ++r) y = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), M[tq][r], y);
       }
       return y;
     };
 
+    PROF_T0();
+    PROF(0);   // segment setup
     // =============================== pass 1: logits and tv of every row ===============================
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    for (int tile = 0; tile < ((ab & 32) ? 0 : n_tiles); ++tile) {
       const RowInfo rk = row_info<MODE>(t, p, s, tile * 16 + m);
       float feat[NS];
       RowGeo<MODE> geo;
@@ -241,12 +283,12 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       float rs, sg;
       hidden_tile(p.Csrc_k, cdk, L.wf_k, rk, feat, hid);
       ln_stats(hid, rs, sg);
-      f4 y = relu_project(hid, L.bk, sg, Uk);
+      f4 y = relu_project(hid, L.bk, sg, Ur);
 #pragma unroll
       for (int r = 0; r < 4; ++r) y[r] *= __shfl(rs, 4 * g + r);
       hidden_tile(p.Csrc_v, cdv, L.wf_v, rk, feat, hid);
       ln_stats(hid, rs, sg);
-      f4 tv = relu_project(hid, L.bv, sg, Mv);
+      f4 tv = relu_project(hid, L.bv, sg, Mr);
 #pragma unroll
       for (int r = 0; r < 4; ++r) tv[r] = tv[r] * __shfl(rs, 4 * g + r) + bx;
 #pragma unroll
@@ -260,9 +302,10 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       }
     }
     rowbuf_sync();
+    PROF(1);   // pass 1
 
     // =============================== softmax backward per head m (rows r = g, g+4, ...) ===============================
-    {
+    if (!(ab & 16)) {
       float mx = NEG_BIG;
       for (int r = g; r < n_rows; r += 4) mx = fmaxf(mx, rb[r * ROWBUF + m]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -306,6 +349,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       }
     }
     rowbuf_sync();
+    PROF(2);   // softmax
 
     // =============================== pass 2: gradients ===============================
     f4 gU[8];
@@ -313,7 +357,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     for (int tq = 0; tq < 8; ++tq) gU[tq] = (f4){0.f, 0.f, 0.f, 0.f};
     float gcd_k0 = 0.f, gcd_k1 = 0.f, gcd_v0 = 0.f, gcd_v1 = 0.f;
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    for (int tile = 0; tile < ((ab & 64) ? 0 : n_tiles); ++tile) {
       const int row_m = tile * 16 + m;
       const RowInfo rk = row_info<MODE>(t, p, s, row_m);
       float feat[NS];
@@ -335,27 +379,37 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       f4 gfeat[NF];
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) gfeat[ft] = (f4){0.f, 0.f, 0.f, 0.f};
+      // row-buffer values of this tile in one batch of loads: rows 4g + r at head m, and row m at heads 4g .. 4g+3
+      f4 aD = {0.f, 0.f, 0.f, 0.f}, glD = {0.f, 0.f, 0.f, 0.f}, aK = {0.f, 0.f, 0.f, 0.f}, glK = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = tile * 16 + 4 * g + r;
+        if (row < n_rows) { aD[r] = rb[row * ROWBUF + m]; glD[r] = rb[row * ROWBUF + 32 + m]; }
+      }
+      if (row_m < n_rows) {
+        aK = *reinterpret_cast<const f4*>(rb + row_m * ROWBUF + 4 * g);
+        glK = *reinterpret_cast<const f4*>(rb + row_m * ROWBUF + 32 + 4 * g);
+      }
 
 #pragma unroll
-      for (int path = 0; path < 2; ++path) {
+      for (int path = 0; path < ((ab & 8) ? 1 : 2); ++path) {
         const bool kp = path == 0;
         const float* bp = kp ? L.bk : L.bv;
         const float* wf = kp ? L.wf_k : L.wf_v;
         float* acc = kp ? L.acc_k : L.acc_v;
-        const float* M = kp ? Uk : Mv;
         f4 hid[8];
         float rs, sg;
         hidden_tile(kp ? p.Csrc_k : p.Csrc_v, kp ? cdk : cdv, wf, rk, feat, hid);
         ln_stats(hid, rs, sg);
-        const f4 y = relu_project(hid, bp, sg, M);                  // y unscaled, rows 4g+r, head m
+        PROF(3);   // tile head: features, row buffer loads
+        const f4 y = kp ? relu_project(hid, bp, sg, Ur) : relu_project(hid, bp, sg, Mr);   // unscaled, rows 4g+r, head m
+        PROF(4);   // recompute
         // coefficient of y in the loss, rows 4g+r: k path dlogit ; v path cw * alpha
         f4 coefD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = tile * 16 + 4 * g + r;
-          float c = 0.f;
-          if (row < n_rows) c = kp ? rb[row * ROWBUF + 32 + m] : rb[row * ROWBUF + m] * L.sR[32 + 4 * g + r];
-          coefD[r] = c;
+          coefD[r] = kp ? glD[r] : aD[r] * L.sR[32 + 4 * g + r];
         }
         wave_lds_sync();   // sR[32..] written above is read here by other lanes only after this point on later paths
         if (!kp) {
@@ -364,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = tile * 16 + 4 * g + r;
-            const float a = row < n_rows ? rb[row * ROWBUF + m] : 0.f;
+            const float a = aD[r];
             const float vfull = y[r] * __shfl(rs, 4 * g + r);          // rstd_v * z_v . M
             av[r] = row16_total(a * (T::POS ? vfull + bx : vfull + gswn_m));
           }
@@ -414,32 +468,38 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         }
         wave_lds_sync();
         const float grs = L.sR[m];
+        PROF(5);   // gate/rstd sums, z tile to LDS
         // dM[c,h] += sum_row z[c,row] * rstd[row] * coef[row,h]      (k path: dU; pos v path: dW2xv)
         if (kp || T::POS) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const int rowk = tile * 16 + 4 * ks + g;
-            float b = 0.f;
-            if (rowk < n_rows) b = (kp ? rb[rowk * ROWBUF + 32 + m] : rb[rowk * ROWBUF + m] * L.sR[32 + 4 * ks + g]) * L.sR[16 + 4 * ks + g];
+          for (int ks = 0; ks < 4; ++ks) {           // contraction index (row) of this k-step: 4g + ks
+            const float b = coefD[ks] * L.sR[16 + 4 * g + ks];
 #pragma unroll
             for (int tq = 0; tq < 8; ++tq) {
-              const float a = L.sT[(16 * tq + m) * 17 + 4 * ks + g];
+              const float a = L.sT[(16 * tq + m) * 17 + 4 * g + ks];
               if (kp) gU[tq] = mfma16(a, b, gU[tq]);
               else gw2_acc[tq] = mfma16(a, b, gw2_acc[tq]);
             }
           }
         }
-        // dz^T[c,row] = sum_h M[c,h] * coef[row,h] * rstd[row]
+        PROF(6);   // dM product
+        // dz^T[c,row] = sum_h M[c,h] * coef[row,h] * rstd[row]; M^T comes out of the registers through the LDS tile
+        wave_lds_sync();   // products over sT (z) are done
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = kp ? Ur[tq][r] : Mr[tq][r];
+        wave_lds_sync();
         f4 gz[8];
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq) gz[tq] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          float b = 0.f;
-          if (row_m < n_rows) b = (kp ? rb[row_m * ROWBUF + 32 + 4 * ks + g] : rb[row_m * ROWBUF + 4 * ks + g] * cw_m) * rs;
+        for (int ks = 0; ks < 4; ++ks) {             // contraction index (head) of this k-step: 4g + ks
+          const float b = (kp ? glK[ks] : aK[ks] * cw_m) * rs;
 #pragma unroll
-          for (int tq = 0; tq < 8; ++tq) gz[tq] = mfma16(m_plain(M, 16 * tq + m, 4 * ks + g), b, gz[tq]);
+          for (int tq = 0; tq < 8; ++tq) gz[tq] = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], b, gz[tq]);
         }
+        PROF(7);   // dz product
         // folded LayerNorm backward: z = ReLU(h + b' sigma), sigma = sqrt(var), rstd = 1/sigma, var = mean(h^2) + eps
         float s1 = 0.f;
 #pragma unroll
@@ -454,7 +514,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         s1 += __shfl_xor(s1, 16);
         s1 += __shfl_xor(s1, 32);
         const float gvar = 0.5f * rs * s1 - 0.5f * grs * rs * rs * rs;
-        wave_lds_sync();   // products over sT (z) are done
+        wave_lds_sync();   // products over sT (M^T) are done
         // d b'[c] += sum_row dpre[c,row] * sigma[row]: through the LDS tile, each lane sums its two channels
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq)
@@ -476,7 +536,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
             L.sT[(16 * tq + 4 * g + r) * 17 + m] = gz[tq][r];
           }
         wave_lds_sync();
-        if constexpr (NSTEP > 0) {
+        PROF(8);   // LN adjoint, db', dhidden tile
+        if (NSTEP > 0 && !(ab & 4)) {
           // d feat[row, f] += sum_c dhidden[c,row] * Wf[c,f]
           if constexpr (!T::PH) {
 #pragma unroll
@@ -485,50 +546,71 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
               for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                  gfeat[ft] = mfma16(gz[tq][r], wf_plain(wf, 16 * tq + 4 * g + r, 16 * ft + m), gfeat[ft]);
+                  gfeat[ft] = mfma16(gz[tq][r], NFT == 1 ? (kp ? L.wfp_k : L.wfp_v)[(16 * tq + 4 * g + r) * 17 + m]
+                                                           : wf_plain(wf, 16 * tq + 4 * g + r, 16 * ft + m), gfeat[ft]);
           }
-          // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]   (LDS accumulator in the lane-fixed layout)
+          // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]
+          if constexpr (NFT == 1) {             // registers for the whole kernel
 #pragma unroll
-          for (int ft = 0; ft < NF; ++ft) {
-            const int f = 16 * ft + m;
-#pragma unroll
-            for (int tq = 0; tq < 8; ++tq) {
-              f4 a4 = {0.f, 0.f, 0.f, 0.f};
+            for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
               for (int ks = 0; ks < 4; ++ks)
-                a4 = mfma16(L.sT[(16 * tq + m) * 17 + 4 * ks + g], L.sF[(4 * ks + g) * FS + f], a4);
-              if (f < F) {
+                gwf_acc[path][tq] = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], L.sF[(4 * g + ks) * FS + m], gwf_acc[path][tq]);
+          } else {                              // LDS accumulator in the lane-fixed layout
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&acc[((f >> 2) * 8 + tq) * 64 + (f & 3) * 16 + 4 * g + r], a4[r]);
+            for (int ft = 0; ft < NF; ++ft) {
+              const int f = 16 * ft + m;
+#pragma unroll
+              for (int tq = 0; tq < 8; ++tq) {
+                f4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                  a4 = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], L.sF[(4 * g + ks) * FS + f], a4);
+                if (f < F) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) atomicAdd(&acc[((f >> 2) * 8 + tq) * 64 + (f & 3) * 16 + 4 * g + r], a4[r]);
+                }
               }
             }
           }
         }
+        PROF(9);   // dfeat, dWf
         // d Csrc (scatter) and d Cdst (row sum): lane owns channels lane and lane + 64
-        {
+        if (!(ab & 2)) {
           float* gsrc = kp ? gr.gCsrc_k : gr.gCsrc_v;
           float a0 = 0.f, a1 = 0.f;
-          for (int rr = 0; rr < 16; ++rr) {
-            const int ci = L.sI[rr];
-            if (ci >= 0) {
+          if constexpr (T::TRI) {               // LDS accumulation per source atom; rows that are masked out carry exact zeros
+            float* ap = L.accP + (size_t)tile * 16 * 256 + (kp ? 0 : 128);
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
               const float v0 = L.sT[lane * 17 + rr], v1 = L.sT[(64 + lane) * 17 + rr];
-              if constexpr (T::TRI) {
-                float* ap = L.accP + (tile * 16 + rr) * 256 + (kp ? 0 : 128);
-                atomicAdd(ap + lane, v0);
-                atomicAdd(ap + 64 + lane, v1);
-              } else if constexpr (T::BOND) {
-                gsrc[(size_t)ci * gr.ld_gcsrc + lane] = v0;
-                gsrc[(size_t)ci * gr.ld_gcsrc + 64 + lane] = v1;
-              } else {
-                atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + lane, v0);
-                atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + 64 + lane, v1);
+              if (ab & 128) { ap[rr * 256 + lane] += v0; ap[rr * 256 + 64 + lane] += v1; }   // timing experiment (racy)
+              else {
+                atomicAdd(ap + rr * 256 + lane, v0);
+                atomicAdd(ap + rr * 256 + 64 + lane, v1);
               }
               a0 += v0; a1 += v1;
+            }
+          } else {
+            for (int rr = 0; rr < 16; ++rr) {
+              const int ci = L.sI[rr];
+              if (ci >= 0) {
+                const float v0 = L.sT[lane * 17 + rr], v1 = L.sT[(64 + lane) * 17 + rr];
+                if constexpr (T::BOND) {          // every row is written exactly once
+                  gsrc[(size_t)ci * gr.ld_gcsrc + lane] = v0;
+                  gsrc[(size_t)ci * gr.ld_gcsrc + 64 + lane] = v1;
+                } else {
+                  atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + lane, v0);
+                  atomicAdd(gsrc + (size_t)ci * gr.ld_gcsrc + 64 + lane, v1);
+                }
+                a0 += v0; a1 += v1;
+              }
             }
           }
           if (kp) { gcd_k0 += a0; gcd_k1 += a1; } else { gcd_v0 += a0; gcd_v1 += a1; }
         }
         wave_lds_sync();   // sT is rewritten by the next path / tile
+        PROF(10);  // scatter
       }  // paths
 
       // ---------------- geometry: d feat -> positions / direction vectors; pos modes: d rel_x ----------------
@@ -539,7 +621,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           for (int r = 0; r < 4; ++r) L.sGF[(4 * g + r) * FS + 16 * ft + m] = gfeat[ft][r];
         wave_lds_sync();
       }
-      if (g == 0 && rk.valid && gr.gx) {
+      if (g == 0 && rk.valid && gr.gx && !(ab & 1)) {
         const float* gf = L.sGF + m * FS;
         float grel[3] = {0.f, 0.f, 0.f};
         if constexpr (T::KNN) {
@@ -612,6 +694,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         }
       }
       wave_lds_sync();
+      PROF(11);  // geometry
     }  // tiles
 
     // ---------------- per-segment outputs ----------------
@@ -627,6 +710,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       cv[lane] = gcd_v0; cv[64 + lane] = gcd_v1;
     }
     __builtin_amdgcn_wave_barrier();
+    PROF(12);  // segment outputs
   };  // process(segment)
 
   if constexpr (T::TRI) {
@@ -637,7 +721,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       const int gi = t.ctx_graph[cj];
       const int n = t.g_nlig[gi], lig0 = t.g_ctx_off[gi] + t.g_nph[gi], lj = cj - lig0;
       const int* eid_g = t.eid + t.g_eid_off[gi];
-      for (int i = tid; i < n * 256; i += blockDim.x) L.accP[i] = 0.f;
+      for (int i = tid; i < ((n + 15) & ~15) * 256; i += blockDim.x) L.accP[i] = 0.f;
       __syncthreads();
       for (int il = wave; il < n; il += NW) {
         if (il == lj) continue;
@@ -664,10 +748,24 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   }
 
   // ---------------- flush the weight-gradient accumulators ----------------
+  PROF_FLUSH();
   __syncthreads();
-  for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
-    if (L.acc_k[i] != 0.f) atomicAdd(gr.gWf_k + i, L.acc_k[i]);
-    if (L.acc_v[i] != 0.f) atomicAdd(gr.gWf_v + i, L.acc_v[i]);
+  if constexpr (NFT == 1) {
+    if (m < F) {
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = ((m >> 2) * 8 + tq) * 64 + (m & 3) * 16 + 4 * g + r;
+          atomicAdd(gr.gWf_k + idx, gwf_acc[0][tq][r]);
+          atomicAdd(gr.gWf_v + idx, gwf_acc[1][tq][r]);
+        }
+    }
+  } else {
+    for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
+      if (L.acc_k[i] != 0.f) atomicAdd(gr.gWf_k + i, L.acc_k[i]);
+      if (L.acc_v[i] != 0.f) atomicAdd(gr.gWf_v + i, L.acc_v[i]);
+    }
   }
   atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1);
   atomicAdd(gr.gbv + lane, gbv0); atomicAdd(gr.gbv + 64 + lane, gbv1);
@@ -688,8 +786,9 @@ template <int MODE, int NW>
 static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st) {
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
-  constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32;
-  const size_t lds = ((size_t)4 * NSTEP * 512 + 256 + (T::TRI ? (size_t)t->max_nlig * 256 : 0) + (size_t)NW * PW) * sizeof(float);
+  constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;
+  const size_t lds = ((size_t)4 * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 256 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
+                      (size_t)NW * PW) * sizeof(float);
   if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
   static size_t attr_set = 0;
   if (attr_set < lds) {
@@ -701,7 +800,9 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   int blocks = T::TRI ? t->n_lig : (p->n_seg + NW - 1) / NW;
   if (blocks > gr->grid) blocks = gr->grid;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr);
+  static int ablate = -1;
+  if (ablate < 0) { const char* e = getenv("PG_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }   // timing experiments only
+  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr, ablate);
   return check_launch("pg_seg_attn_bwd");
 }
 
@@ -709,7 +810,15 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
 
 using namespace pg;
 
-extern "C" int pg_seg_attn_bwd_waves(int mode) { return mode == PG_SEG_TRIPLET ? 8 : 4; }   // upper bound (row-buffer sizing)
+#ifdef PG_BWD_PROF
+extern "C" int pg_debug_bwd_prof(unsigned long long* out, int reset) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pg::g_bwd_prof), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pg::g_bwd_prof), z, sizeof(z)); }
+  return 0;
+}
+#endif
+
+extern "C" int pg_seg_attn_bwd_waves(int mode) { (void)mode; return 4; }
 
 extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, void* stream) {
   if (!t || !p || !gr) { set_error("pg_seg_attn_bwd: null argument"); return PG_ERR_ARG; }
@@ -720,12 +829,12 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
   }
   hipStream_t st = (hipStream_t)stream;
   switch (p->mode) {
-    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 4>(t, p, gr, st);
-    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
+    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 3>(t, p, gr, st);
+    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 3>(t, p, gr, st);
     case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
     case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
-    case PG_SEG_TRIPLET:   // 8 waves (2 per SIMD) share one LDS accumulator of the source atom's rows when it fits
-      return t->max_nlig <= 44 ? launch_bwd<PG_SEG_TRIPLET, 8>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
+    case PG_SEG_TRIPLET:
+      return launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
     case PG_SEG_PHORE: return launch_bwd<PG_SEG_PHORE, 4>(t, p, gr, st);
   }
   set_error("pg_seg_attn_bwd: unknown mode %d", p->mode);
