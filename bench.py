@@ -52,6 +52,15 @@ def ligphore_workload(n_graphs=128, seed=1234, fixed_shape=False):
                 num_atoms=n_at, n_phore=n_ph)
 
 
+def subset_workload(w, graph_ids):
+    """The graphs `graph_ids` (ascending) of a workload, renumbered 0..len-1."""
+    keep = torch.isin(w['batch_phore'], graph_ids)
+    remap = torch.full((int(w['num_atoms'].numel()),), -1, dtype=torch.long)
+    remap[graph_ids] = torch.arange(graph_ids.numel())
+    return dict(h_phore=w['h_phore'][keep], pos_phore=w['pos_phore'][keep], phore_norm=w['phore_norm'][keep],
+                batch_phore=remap[w['batch_phore'][keep]], num_atoms=w['num_atoms'][graph_ids], n_phore=w['n_phore'][graph_ids])
+
+
 def algorithmic_counts(n_at, n_ph, knn=32, H=128):
     """Per-step algorithmic work: sizes, GEMM FLOPs of the factored form, compulsory HBM bytes."""
     n_all = int((n_at + n_ph).sum())
@@ -120,6 +129,8 @@ def main():
     ap.add_argument('--graphs', type=int, default=128)
     ap.add_argument('--fixed-shape', action='store_true', help='n=40, p=107 for every graph (closed-form counts)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--strong', action='store_true',
+                    help='strong scaling (SURVEY.md 8d): ONE batch of --graphs graphs partitioned over the ranks by n^3 cost')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -137,7 +148,15 @@ def main():
     from phoregen_amd.weights import init_deterministic_
 
     model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to(dev)
-    work = ligphore_workload(args.graphs, seed=1234 + rank, fixed_shape=args.fixed_shape)   # each rank: its own graphs
+    total_graphs = args.graphs if args.strong else world * args.graphs
+    if args.strong and world > 1:
+        from phoregen_amd.parallel import partition_graphs
+        full = ligphore_workload(args.graphs, seed=1234, fixed_shape=args.fixed_shape)
+        mine = partition_graphs(full['num_atoms'], world)[rank]
+        work = subset_workload(full, mine)
+        args.graphs = int(mine.numel())
+    else:
+        work = ligphore_workload(args.graphs, seed=1234 + rank, fixed_shape=args.fixed_shape)   # each rank: its own graphs
     counts = algorithmic_counts(work['num_atoms'], work['n_phore'])
     K, W = args.steps, args.warmup
     st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm'], work['batch_phore'],
@@ -169,7 +188,7 @@ def main():
     if world > 1:
         from phoregen_amd.parallel import gather_predictions
         tg = time.perf_counter()
-        gids = torch.arange(args.graphs) + rank * args.graphs
+        gids = mine if (args.strong and world > 1) else torch.arange(args.graphs) + rank * args.graphs
         gather_predictions(res['pred'], work['num_atoms'], gids)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
@@ -190,16 +209,16 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            'metric': 'denoise-steps/sec (batch=128, ~40-atom graphs)', 'value': world * K / dt, 'unit': 'steps/s',
+            'metric': 'denoise-steps/sec (batch=128, ~40-atom graphs)', 'value': (1 if args.strong else world) * K / dt, 'unit': 'steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': dt / K * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[2]: 128 LigPhore-shaped graphs per GPU '
                                    '(n~N(40,6) atoms, p~N(107,30) pharmacophore nodes), steps t=999.. of the 1000-step sampler, '
                                    'device Philox noise, trajectory written',
                        'graphs_per_gpu': args.graphs, 'fixed_shape': args.fixed_shape, 'n_ctx': counts['n_all'],
                        'n_lig': counts['n_lig'], 'e_knn': counts['e_knn'], 'e_bond': counts['e_bond'], 'e3': counts['e3'],
                        'parallelism': f'graph-sharded x{world}, final RCCL gather only'},
-            'graph_steps_per_sec': world * K * args.graphs / dt,
+            'graph_steps_per_sec': K * total_graphs / dt,
             'roofline': {'kernel': 'triplet_kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 launches/step)', 'bound': 'mfma',
                          'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': (achieved / peak_tf) if achieved else None, 'traffic': traffic,
