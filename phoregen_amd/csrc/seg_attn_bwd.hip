@@ -201,6 +201,22 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   float* const rb = gr.rowbuf + (size_t)(blockIdx.x * NW + wave) * gr.rowbuf_rows * ROWBUF;
   const float bx = T::POS ? p.b2xv[m] : 0.f;
 
+  // triplet: merge the 4 waves' d hidden tiles (own sT each) into the workgroup's accP rows; channel-owned, no atomics.
+  // Every wave of the workgroup must call this the same number of times (idle waves with a zeroed tile).
+  auto tri_merge = [&](int tile, bool kp) {
+    __syncthreads();
+    const int cc = 32 * wave + (lane & 31), half = lane >> 5;
+    float* ap = L.accP + (size_t)(tile * 16 + 8 * half) * 256 + (kp ? 0 : 128) + cc;
+    const float* st0 = L.sT - wave * PW + cc * 17 + 8 * half;       // wave 0's tile, this lane's channel / row block
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) v += st0[w2 * PW + rr];
+      ap[rr * 256] += v;
+    }
+    __syncthreads();
+  };
   PROF_DECL();
   auto process = [&](const Seg<MODE>& s) {
     const int dst_ctx = T::TRI ? s.ci : s.seg;
@@ -579,18 +595,13 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         if (!(ab & 2)) {
           float* gsrc = kp ? gr.gCsrc_k : gr.gCsrc_v;
           float a0 = 0.f, a1 = 0.f;
-          if constexpr (T::TRI) {               // LDS accumulation per source atom; rows that are masked out carry exact zeros
-            float* ap = L.accP + (size_t)tile * 16 * 256 + (kp ? 0 : 128);
+          if constexpr (T::TRI) {
+            // per-source-atom rows in LDS without atomics (ds_add_f32 costs ~700 cycles here, profiles/r01f_*sections.md):
+            // the 4 waves of the workgroup walk their segments in lockstep, every wave has its d hidden tile in its own
+            // sT, and wave w adds the 4 tiles' channels [32w, 32w+32) into the rows it alone owns
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-              const float v0 = L.sT[lane * 17 + rr], v1 = L.sT[(64 + lane) * 17 + rr];
-              if (ab & 128) { ap[rr * 256 + lane] += v0; ap[rr * 256 + 64 + lane] += v1; }   // timing experiment (racy)
-              else {
-                atomicAdd(ap + rr * 256 + lane, v0);
-                atomicAdd(ap + rr * 256 + 64 + lane, v1);
-              }
-              a0 += v0; a1 += v1;
-            }
+            for (int rr = 0; rr < 16; ++rr) { a0 += L.sT[lane * 17 + rr]; a1 += L.sT[(64 + lane) * 17 + rr]; }
+            tri_merge(tile, kp);
           } else {
             for (int rr = 0; rr < 16; ++rr) {
               const int ci = L.sI[rr];
@@ -723,15 +734,24 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       const int* eid_g = t.eid + t.g_eid_off[gi];
       for (int i = tid; i < ((n + 15) & ~15) * 256; i += blockDim.x) L.accP[i] = 0.f;
       __syncthreads();
-      for (int il = wave; il < n; il += NW) {
-        if (il == lj) continue;
-        Seg<MODE> s;
-        s.seg = eid_g[lj * n + il];
-        s.n_rows = s.n = n;
-        s.lig0 = lig0; s.li = il; s.lj = lj; s.first = 0;
-        s.ci = lig0 + il; s.cj = cj;
-        s.eid_g = eid_g;
-        process(s);
+      const int n_tiles_j = (n + 15) >> 4;
+      for (int base = 0; base < n; base += NW) {
+        const int il = base + wave;
+        if (il < n && il != lj) {
+          Seg<MODE> s;
+          s.seg = eid_g[lj * n + il];
+          s.n_rows = s.n = n;
+          s.lig0 = lig0; s.li = il; s.lj = lj; s.first = 0;
+          s.ci = lig0 + il; s.cj = cj;
+          s.eid_g = eid_g;
+          process(s);
+        } else if (!(ab & 2)) {       // idle wave of this round: same barrier sequence, zero contribution
+          for (int tile = 0; tile < ((ab & 64) ? 0 : n_tiles_j); ++tile)
+            for (int path = 0; path < ((ab & 8) ? 1 : 2); ++path) {
+              for (int i = lane; i < 128 * 17; i += 64) L.sT[i] = 0.f;
+              tri_merge(tile, path == 0);
+            }
+        }
       }
       __syncthreads();
       for (int i = tid; i < n * 256; i += blockDim.x) {
