@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
   constexpr int FS = 16 * NF + 1;
+  constexpr int ACS = 52, ACC = NFT > 1 ? 128 * ACS : 0;           // LDS dWf accumulator [c][f], row stride 52: 2-way bank conflicts at most
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;       // per-wave floats
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     float* q = lds_raw;
     L.wf_k = q; q += NSTEP * 512;
     L.wf_v = q; q += NSTEP * 512;
-    L.acc_k = q; q += NSTEP * 512;
-    L.acc_v = q; q += NSTEP * 512;
+    L.acc_k = q; q += ACC;
+    L.acc_v = q; q += ACC;
     L.bk = q; q += 128;
     L.bv = q; q += 128;
     L.accP = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * 256;   // triplet: d P[k -> j] of the workgroup's source atom
@@ -169,8 +170,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     L.sC = q;
   }
   for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
-    L.wf_k[i] = p.Wf_k[i]; L.wf_v[i] = p.Wf_v[i]; L.acc_k[i] = 0.f; L.acc_v[i] = 0.f;
+    L.wf_k[i] = p.Wf_k[i]; L.wf_v[i] = p.Wf_v[i];
   }
+  for (int i = tid; i < ACC; i += blockDim.x) { L.acc_k[i] = 0.f; L.acc_v[i] = 0.f; }
   for (int i = tid; i < 128; i += blockDim.x) { L.bk[i] = p.ln_bk[i]; L.bv[i] = p.ln_bv[i]; }
   if constexpr (NFT == 1) {
     for (int i = tid; i < 128 * 16; i += blockDim.x) {
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
                   a4 = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], L.sF[(4 * g + ks) * FS + f], a4);
                 if (f < F) {
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) atomicAdd(&acc[((f >> 2) * 8 + tq) * 64 + (f & 3) * 16 + 4 * g + r], a4[r]);
+                  for (int r = 0; r < 4; ++r) atomicAdd(&acc[(16 * tq + 4 * g + r) * ACS + f], a4[r]);
                 }
               }
             }
@@ -782,9 +784,12 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         }
     }
   } else {
-    for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
-      if (L.acc_k[i] != 0.f) atomicAdd(gr.gWf_k + i, L.acc_k[i]);
-      if (L.acc_v[i] != 0.f) atomicAdd(gr.gWf_v + i, L.acc_v[i]);
+    for (int i = tid; i < 128 * F; i += blockDim.x) {
+      const int c = i / F, f = i - c * F;
+      const int idx = ((f >> 2) * 8 + (c >> 4)) * 64 + (f & 3) * 16 + (c & 15);       // lane-fixed layout of the forward weights
+      const float vk = L.acc_k[c * ACS + f], vv = L.acc_v[c * ACS + f];
+      if (vk != 0.f) atomicAdd(gr.gWf_k + idx, vk);
+      if (vv != 0.f) atomicAdd(gr.gWf_v + idx, vv);
     }
   }
   atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1);
@@ -807,7 +812,7 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;
-  const size_t lds = ((size_t)4 * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 256 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
+  const size_t lds = ((size_t)2 * NSTEP * 512 + (NFT > 1 ? 2 * 128 * 52 : 0) + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 256 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
                       (size_t)NW * PW) * sizeof(float);
   if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
   static size_t attr_set = 0;
