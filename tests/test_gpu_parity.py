@@ -318,6 +318,30 @@ def test_device_rng_sampler_runs_and_is_reproducible(model):
     assert torch.isfinite(a['pred'][1]).all() and a['traj'][0].sum(-1).eq(1).all()
 
 
+def test_full_1000_step_trajectory_stays_finite_and_one_hot(model):
+    """All 1000 reverse steps with the device RNG and guidance on a small ragged batch: every trajectory frame finite,
+    discrete states one-hot, shapes of the reference contract (diffusion.py:505-525), decode_data on the result."""
+    from oracle.make_inputs import synthetic_phore
+    from phoregen_amd.utils.sample_utils import decode_data, unbatch_data
+    gen = torch.Generator().manual_seed(8)
+    hp, pp, pn = synthetic_phore(gen, 25)
+    na = torch.tensor([11, 4, 17, 8])
+    B = na.numel()
+    bp = torch.repeat_interleave(torch.arange(B), 25)
+    guid = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}]
+    res = model.sample_batch(hp.repeat(B, 1), pp.repeat(B, 1), pn.repeat(B, 1), bp, na, torch.zeros(B, 3), rng='device',
+                             seed=3, pos_guidance_opt=guid, guidance_center=pp.mean(0))
+    N, E = int(na.sum()), int((na * (na - 1)).sum())
+    tn, tp, te = res['traj']
+    assert tn.shape == (1001, N, 12) and tp.shape == (1001, N, 3) and te.shape == (1001, E, 6)
+    assert torch.isfinite(tp).all() and all(torch.isfinite(x).all() for x in res['pred'])
+    assert tn.sum(-1).eq(1).all() and te.sum(-1).eq(1).all() and tn.max() == 1 and te.max() == 1
+    outs = unbatch_data({k: [x.cpu() for x in v] for k, v in res.items()}, B, include_bond=True)
+    for o, n in zip(outs, na.tolist()):
+        d = decode_data(o['pred'], o['edge_index'], include_bond=True)
+        assert len(d['element']) <= n and np.isfinite(np.asarray(d['atom_pos'])).all()
+
+
 def _headline_inputs(n_graphs=128, seed=1234):
     """PhoreDiff.forward inputs of the benchmark workload (BASELINE.json config 3) at an early reverse step."""
     import torch.nn.functional as F
