@@ -38,6 +38,11 @@ class Engine:
         # kernels of different chains interleave on the CUs, so one chain's load/store phases meet another's MFMA phases
         self.multi_stream = os.environ.get('PG_STREAMS', '1') != '0'
         self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
+        # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
+        # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
+        # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
+        self.graph_mode = os.environ.get('PG_GRAPH', '0')
+        self._graph = None
         self._lane = 0
         self._side = None
         self._alloc()
@@ -345,9 +350,26 @@ class Engine:
         w.in_t.copy_(time_step)
         return self.forward_inplace()
 
+    def _graph_wanted(self):
+        return self.graph_mode == '1' and self.timers is None and self.debug is None
+
+    def _capture(self):
+        """Capture the (static) forward launch list, side-stream forks / joins included, into one hipGraph."""
+        self._run(self.prog_fwd)              # eager once: lazy kernel attributes, side streams
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._run(self.prog_fwd)
+        self._graph = g
+
     def forward_inplace(self):
         w = self.ws
-        self._run(self.prog_fwd)
+        if self._graph_wanted():
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._run(self.prog_fwd)
         x0 = torch.index_select(w.x[self.final_idx], 0, self.plan.lig2ctx_long)
         return w.out_v, x0, w.out_bond
 
