@@ -185,3 +185,22 @@ def test_unbatch_and_decode_match_reference():
         assert np.array_equal(d['atom_pos'].numpy(), g[f'g{gi}_atom_pos'])
         assert np.array_equal(d['bond_type'].numpy(), g[f'g{gi}_bond_type'])
         assert np.array_equal(d['bond_index'].numpy(), g[f'g{gi}_bond_index'])
+
+
+def test_ema_matches_reference_formula():
+    """models/model_utils.py:21-42: shadow = beta * shadow + (1 - beta) * current, state round trip."""
+    from phoregen_amd.models.model_utils import EMA
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 2))
+    ema = EMA(0.9, net.parameters())
+    ref = [p.detach().clone() for p in net.parameters()]
+    for _ in range(3):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(torch.randn_like(p))
+        ema.update_model_average(net)
+        ref = [r * 0.9 + 0.1 * p.detach() for r, p in zip(ref, net.parameters())]
+    assert all(torch.allclose(a, b, atol=1e-6) for a, b in zip(ema.shadow_params, ref))
+    e2 = EMA(0.5, net.parameters())
+    e2.load_state_dict(ema.state_dict(), 'cpu')
+    assert e2.beta == 0.9 and all(torch.equal(a, b) for a, b in zip(e2.shadow_params, ema.shadow_params))
