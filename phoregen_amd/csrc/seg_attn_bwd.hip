@@ -14,8 +14,8 @@
 //           dfeat -> geometry (positions / direction vectors), gate gradient.
 // Matrix products whose operands are not in the register layout the MFMA wants go through a per-wave LDS tile
 // (stride 17), so every product is a plain 16x16x4 MFMA chain with operands read where they lie.
-// Weight gradients accumulate in LDS (dWf, lane-fixed layout of the forward weights) or registers (db', dW2xv) and
-// are flushed with one atomic per element per workgroup.
+// Weight gradients (dWf, db', dW2xv) accumulate in registers for the whole kernel and are flushed with one global atomic
+// per element per wave; nothing uses LDS atomics (ds_add_f32 measured ~700 cycles per instruction here).
 #include <stdlib.h>
 
 #include "seg_common.h"
@@ -131,7 +131,7 @@ __device__ __forceinline__ void rowbuf_sync() {
 }
 
 struct BwdLds {
-  float *wf_k, *wf_v, *acc_k, *acc_v, *bk, *bv, *accP, *wfp_k, *wfp_v;
+  float *wf_k, *wf_v, *bk, *bv, *accP, *wfp_k, *wfp_v;
   float *sT, *sF, *sGF, *sR, *sC;
   int* sI;
 };
@@ -143,7 +143,6 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
   constexpr int FS = 16 * NF + 1;
-  constexpr int ACS = 52, ACC = NFT > 1 ? 128 * ACS : 0;           // LDS dWf accumulator [c][f], row stride 52: 2-way bank conflicts at most
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;       // per-wave floats
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,8 +153,6 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     float* q = lds_raw;
     L.wf_k = q; q += NSTEP * 512;
     L.wf_v = q; q += NSTEP * 512;
-    L.acc_k = q; q += ACC;
-    L.acc_v = q; q += ACC;
     L.bk = q; q += 128;
     L.bv = q; q += 128;
     L.accP = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * 256;   // triplet: d P[k -> j] of the workgroup's source atom
@@ -172,7 +169,6 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
     L.wf_k[i] = p.Wf_k[i]; L.wf_v[i] = p.Wf_v[i];
   }
-  for (int i = tid; i < ACC; i += blockDim.x) { L.acc_k[i] = 0.f; L.acc_v[i] = 0.f; }
   for (int i = tid; i < 128; i += blockDim.x) { L.bk[i] = p.ln_bk[i]; L.bv[i] = p.ln_bv[i]; }
   if constexpr (NFT == 1) {
     for (int i = tid; i < 128 * 16; i += blockDim.x) {
@@ -194,11 +190,13 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq) gw2_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f};
   float gbk0 = 0.f, gbk1 = 0.f, gbv0 = 0.f, gbv1 = 0.f;        // d b'[lane], d b'[lane + 64] of the two paths
-  f4 gwf_acc[2][8];                                            // d Wf of the single-f-tile modes: [path][tau] -> (c = 16 tau + 4g + r, f = m)
+  f4 gwf_acc[2][NF][8];                                        // d Wf: [path][f tile][tau] -> (c = 16 tau + 4g + r, f = 16 ft + m)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int tq = 0; tq < 8; ++tq) gwf_acc[a][tq] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) gwf_acc[a][ft][tq] = (f4){0.f, 0.f, 0.f, 0.f};
   float gbx_acc = 0.f;
   float* const rb = gr.rowbuf + (size_t)(blockIdx.x * NW + wave) * gr.rowbuf_rows * ROWBUF;
   const float bx = T::POS ? p.b2xv[m] : 0.f;
@@ -414,7 +412,6 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         const bool kp = path == 0;
         const float* bp = kp ? L.bk : L.bv;
         const float* wf = kp ? L.wf_k : L.wf_v;
-        float* acc = kp ? L.acc_k : L.acc_v;
         f4 hid[8];
         float rs, sg;
         hidden_tile(kp ? p.Csrc_k : p.Csrc_v, kp ? cdk : cdv, wf, rk, feat, hid);
@@ -568,29 +565,15 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
                                                            : wf_plain(wf, 16 * tq + 4 * g + r, 16 * ft + m), gfeat[ft]);
           }
           // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]
-          if constexpr (NFT == 1) {             // registers for the whole kernel
+          // registers for the whole kernel (LDS ds_add_f32 accumulation measured ~700 cycles per instruction)
+#pragma unroll
+          for (int ft = 0; ft < NF; ++ft)
 #pragma unroll
             for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
               for (int ks = 0; ks < 4; ++ks)
-                gwf_acc[path][tq] = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], L.sF[(4 * g + ks) * FS + m], gwf_acc[path][tq]);
-          } else {                              // LDS accumulator in the lane-fixed layout
-#pragma unroll
-            for (int ft = 0; ft < NF; ++ft) {
-              const int f = 16 * ft + m;
-#pragma unroll
-              for (int tq = 0; tq < 8; ++tq) {
-                f4 a4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                  a4 = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], L.sF[(4 * g + ks) * FS + f], a4);
-                if (f < F) {
-#pragma unroll
-                  for (int r = 0; r < 4; ++r) atomicAdd(&acc[(16 * tq + 4 * g + r) * ACS + f], a4[r]);
-                }
-              }
-            }
-          }
+                gwf_acc[path][ft][tq] = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], L.sF[(4 * g + ks) * FS + 16 * ft + m],
+                                               gwf_acc[path][ft][tq]);
         }
         PROF(9);   // dfeat, dWf
         // d Csrc (scatter) and d Cdst (row sum): lane owns channels lane and lane + 64
@@ -772,24 +755,18 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   // ---------------- flush the weight-gradient accumulators ----------------
   PROF_FLUSH();
   __syncthreads();
-  if constexpr (NFT == 1) {
-    if (m < F) {
+#pragma unroll
+  for (int ft = 0; ft < NF; ++ft) {
+    const int f = 16 * ft + m;
+    if (NSTEP > 0 && f < F) {
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int idx = ((m >> 2) * 8 + tq) * 64 + (m & 3) * 16 + 4 * g + r;
-          atomicAdd(gr.gWf_k + idx, gwf_acc[0][tq][r]);
-          atomicAdd(gr.gWf_v + idx, gwf_acc[1][tq][r]);
+          const int idx = ((f >> 2) * 8 + tq) * 64 + (f & 3) * 16 + 4 * g + r;       // lane-fixed layout of the forward weights
+          atomicAdd(gr.gWf_k + idx, gwf_acc[0][ft][tq][r]);
+          atomicAdd(gr.gWf_v + idx, gwf_acc[1][ft][tq][r]);
         }
-    }
-  } else {
-    for (int i = tid; i < 128 * F; i += blockDim.x) {
-      const int c = i / F, f = i - c * F;
-      const int idx = ((f >> 2) * 8 + (c >> 4)) * 64 + (f & 3) * 16 + (c & 15);       // lane-fixed layout of the forward weights
-      const float vk = L.acc_k[c * ACS + f], vv = L.acc_v[c * ACS + f];
-      if (vk != 0.f) atomicAdd(gr.gWf_k + idx, vk);
-      if (vv != 0.f) atomicAdd(gr.gWf_v + idx, vv);
     }
   }
   atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1);
@@ -812,7 +789,7 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;
-  const size_t lds = ((size_t)2 * NSTEP * 512 + (NFT > 1 ? 2 * 128 * 52 : 0) + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 256 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
+  const size_t lds = ((size_t)2 * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 256 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
                       (size_t)NW * PW) * sizeof(float);
   if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
   static size_t attr_set = 0;
@@ -854,8 +831,8 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
   }
   hipStream_t st = (hipStream_t)stream;
   switch (p->mode) {
-    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 3>(t, p, gr, st);
-    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 3>(t, p, gr, st);
+    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 4>(t, p, gr, st);
+    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
     case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
     case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
     case PG_SEG_TRIPLET:
