@@ -277,14 +277,16 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     };
     // y[row = 4g+r][h = m] = ReLU(hidden + b' sigma) . M[:,h]   (unscaled by rstd); hidden stays as it is
     auto relu_project = [&](const f4 (&hid)[8], const float* bp, float sigma, const f4 (&M)[8]) -> f4 {
-      f4 y = {0.f, 0.f, 0.f, 0.f};
+      f4 y[4];                                   // 4 independent accumulation chains (a dependent MFMA waits ~10 extra cycles)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq) {
         const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), M[tq][r], y);
+        for (int r = 0; r < 4; ++r) y[r] = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), M[tq][r], y[r]);
       }
-      return y;
+      return (y[0] + y[1]) + (y[2] + y[3]);
     };
 
     PROF_T0();
@@ -555,14 +557,21 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         if (NSTEP > 0 && !(ab & 4)) {
           // d feat[row, f] += sum_c dhidden[c,row] * Wf[c,f]
           if constexpr (!T::PH) {
+            f4 gfp[NF][4];                         // independent chains per r, folded below
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) gfp[ft][r] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ft = 0; ft < NF; ++ft)
 #pragma unroll
               for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                  gfeat[ft] = mfma16(gz[tq][r], NFT == 1 ? (kp ? L.wfp_k : L.wfp_v)[(16 * tq + 4 * g + r) * 17 + m]
-                                                           : wf_plain(wf, 16 * tq + 4 * g + r, 16 * ft + m), gfeat[ft]);
+                  gfp[ft][r] = mfma16(gz[tq][r], NFT == 1 ? (kp ? L.wfp_k : L.wfp_v)[(16 * tq + 4 * g + r) * 17 + m]
+                                                            : wf_plain(wf, 16 * tq + 4 * g + r, 16 * ft + m), gfp[ft][r]);
+#pragma unroll
+            for (int ft = 0; ft < NF; ++ft) gfeat[ft] += (gfp[ft][0] + gfp[ft][1]) + (gfp[ft][2] + gfp[ft][3]);
           }
           // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]
           // registers for the whole kernel (LDS ds_add_f32 accumulation measured ~700 cycles per instruction)
