@@ -50,7 +50,27 @@ struct RowGeo {
   bool src_lig;
 };
 
-// features of row rk for f = 4 step + g (identical arithmetic to seg_attn.hip), plus what the backward needs
+// sin(x) or cos(x) for 0 <= x <= ~10 (angular code arguments are bounded by 3 pi): k = rint(x * 2/pi), two-constant
+// Cody-Waite reduction, degree-9 / degree-8 polynomials on [-pi/4, pi/4], quadrant select (csrc/triplet.hip uses the same)
+__device__ __forceinline__ float sincos_bounded(float arg, bool want_cos) {
+  const float kf = rintf(arg * 0.63661977236758134308f);
+  float r = fmaf(-kf, 1.57079637050628662109375f, arg);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  const int q = ((int)kf + (want_cos ? 1 : 0)) & 3;
+  const float s = r * r;
+  float ps = fmaf(s, 2.7557314297e-6f, -1.9841270114e-4f);
+  ps = fmaf(ps, s, 8.3333337680e-3f);
+  ps = fmaf(ps, s, -1.6666667163e-1f);
+  ps = fmaf(ps * s, r, r);
+  float pc = fmaf(s, 2.4801587642e-5f, -1.3888889225e-3f);
+  pc = fmaf(pc, s, 4.1666667908e-2f);
+  pc = fmaf(pc, s, -0.5f);
+  pc = fmaf(pc, s, 1.0f);
+  const float v = (q & 1) ? pc : ps;
+  return (q & 2) ? -v : v;
+}
+
+// features of row rk for f = 4 step + g (same definitions as seg_attn.hip), plus what the backward needs
 template <int MODE, int NS>
 __device__ __forceinline__ void row_features(const PgTopo& t, const PgSegAttn& p, const RowInfo& rk, const float (&xd)[3],
                                              const float (&nd)[3], const float (&xj)[3], int g, float (&feat)[NS],
@@ -97,9 +117,7 @@ __device__ __forceinline__ void row_features(const PgTopo& t, const PgSegAttn& p
 #pragma unroll
     for (int st = 0; st < 3; ++st) {
       const int f = 4 * st + g;
-      float sn, cs;
-      sincosf(geo.theta * kAngFreq[f], &sn, &cs);
-      float v = f >= 6 ? cs : sn;
+      float v = sincos_bounded(geo.theta * kAngFreq[f], f >= 6);
       v = f == 0 ? geo.theta : v;
       feat[st] = (rk.valid && f != 11) ? v : 0.f;
     }
@@ -667,12 +685,12 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         }
         if constexpr (T::TRI) {
           // theta = atan2(|u x v|, u.v), u = x_j - x_i, v = x_k - x_i
+          // d theta: the derivative of sin(w theta) is w cos(w theta) = w * feature[f + 5], of cos(w theta) it is
+          // -w * feature[f - 5]: both already sit in the row's feature tile
+          const float* ff = L.sF + m * FS;
           float gth = gf[0];
-          for (int f = 1; f < 11; ++f) {
-            float sn, cs;
-            sincosf(geo.theta * kAngFreq[f], &sn, &cs);
-            gth += gf[f] * kAngFreq[f] * (f >= 6 ? -sn : cs);
-          }
+#pragma unroll
+          for (int f = 1; f < 6; ++f) gth += kAngFreq[f] * (gf[f] * ff[f + 5] - gf[f + 5] * ff[f]);
           float u[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) u[c] = xj[c] - xd[c];
