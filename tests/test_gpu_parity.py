@@ -129,6 +129,20 @@ def test_forward_against_oracle_larger_graphs(model, oracle):
     assert max(errs.values()) <= TOL, errs
 
 
+def test_forward_row_tile_boundaries(model, oracle):
+    """Ligand sizes on both sides of every 16-row tile boundary of the segment kernels (15..17, 31..33, 47..49, 64, 65) and
+    pharmacophores around the knn degree (k = 32: graphs of 32, 33, 34 nodes in total)."""
+    from oracle.make_inputs import synthetic_batch
+    n_atoms = [15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 65]
+    n_phore = [17, 16, 17, 23, 40, 24, 30, 31, 55, 23, 44]
+    inp = synthetic_batch(13, n_atoms, n_phore, [999 - 83 * i for i in range(len(n_atoms))])
+    with torch.no_grad():
+        ref = oracle.forward(**inp)
+        out = model(**{k: v.to(DEV) for k, v in inp.items()})
+    errs = dict(v=rel_err(out[0].cpu(), ref[0]), x0=rel_err(out[1].cpu(), ref[1]), bond=rel_err(out[2].cpu(), ref[2]))
+    assert max(errs.values()) <= TOL, errs
+
+
 def test_forward_max_size_ligand_and_generic_kernel_fallback(model, oracle):
     """78-atom ligand (the reference's max_atom: 5 row tiles in the triplet / bond kernels) next to a 4-atom one, and the
     one-pass generic segment kernel (PG_GENERIC_SEG=1, the fallback for shapes the two-pass kernels do not hold)."""
