@@ -95,3 +95,23 @@ def test_gradient_bucket_allreduce_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == {0: True, 1: True}
+
+
+def test_strong_scaling_partition_covers_the_workload():
+    """bench.py --strong: the per-rank sub-workloads are a partition of the 128-graph batch (same graphs, same order
+    inside a rank, pharmacophore rows follow their graphs)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import ligphore_workload, subset_workload
+    w = ligphore_workload(16, seed=1234)
+    parts = partition_graphs(w['num_atoms'], 4)
+    seen = []
+    for ids in parts:
+        s = subset_workload(w, ids)
+        assert torch.equal(s['num_atoms'], w['num_atoms'][ids]) and torch.equal(s['n_phore'], w['n_phore'][ids])
+        assert s['batch_phore'].min() == 0 and s['batch_phore'].max() == ids.numel() - 1
+        assert torch.equal(torch.bincount(s['batch_phore']), w['n_phore'][ids])
+        first = int((w['batch_phore'] == ids[0]).nonzero()[0])
+        assert torch.equal(s['h_phore'][0], w['h_phore'][first])
+        seen += ids.tolist()
+    assert sorted(seen) == list(range(16))
