@@ -149,7 +149,7 @@ __device__ __forceinline__ void rowbuf_sync() {
 }
 
 struct BwdLds {
-  float *wf_k, *wf_v, *bk, *bv, *accP, *wfp_k, *wfp_v;
+  float *wf_k, *wf_v, *bk, *bv, *accP, *accX, *wfp_k, *wfp_v;
   float *sT, *sF, *sGF, *sR, *sC;
   int* sI;
 };
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     L.bk = q; q += 128;
     L.bv = q; q += 128;
     L.accP = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * 256;   // triplet: d P[k -> j] of the workgroup's source atom
+    L.accX = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * 3;     // triplet: d x_k of the workgroup's graph rows
     L.wfp_k = q; if (NFT == 1) q += 128 * 17;                  // Wf[c][f] (stride 17) for d feat = Wf^T . d hidden
     L.wfp_v = q; if (NFT == 1) q += 128 * 17;
     q += wave * PW;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
 #pragma unroll
     for (int tq = 0; tq < 8; ++tq) gU[tq] = (f4){0.f, 0.f, 0.f, 0.f};
     float gcd_k0 = 0.f, gcd_k1 = 0.f, gcd_v0 = 0.f, gcd_v1 = 0.f;
+    float gxs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // d x_j, d x_i (triplet) / d x_dst, d nrm_dst (knn, pos) summed over the segment's rows: one atomic each
 
     for (int tile = 0; tile < ((ab & 64) ? 0 : n_tiles); ++tile) {
       const int row_m = tile * 16 + m;
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               atomicAdd(gr.gnrm + rk.src * 3 + c, gns[c]);
-              atomicAdd(gr.gnrm + dst_ctx * 3 + c, gnd[c]);
+              gxs[3 + c] += gnd[c];
             }
           }
         }
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         if constexpr (T::KNN || T::POS) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            atomicAdd(gr.gx + dst_ctx * 3 + c, grel[c]);
+            gxs[c] += grel[c];
             atomicAdd(gr.gx + rk.src * 3 + c, -grel[c]);
           }
         }
@@ -709,9 +711,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
             for (int c = 0; c < 3; ++c) {
               const float gu = ka * v[c] + kb * vxc[c];
               const float gv = ka * u[c] + kb * cxu[c];
-              atomicAdd(gr.gx + s.cj * 3 + c, gu);
-              atomicAdd(gr.gx + rk.src * 3 + c, gv);
-              atomicAdd(gr.gx + dst_ctx * 3 + c, -(gu + gv));
+              gxs[c] += gu;
+              gxs[3 + c] -= gu + gv;
+              atomicAdd(L.accX + (tile * 16 + m) * 3 + c, gv);
             }
           }
         }
@@ -721,6 +723,24 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     }  // tiles
 
     // ---------------- per-segment outputs ----------------
+    if constexpr (T::TRI) {
+      if (gr.gx) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const float v = wave_sum(gxs[c]);
+          if (lane == 0) atomicAdd(gr.gx + (c < 3 ? s.cj : dst_ctx) * 3 + (c % 3), v);
+        }
+      }
+    } else if constexpr (T::KNN || T::POS) {
+      if (gr.gx) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          if (c >= 3 && !(T::KNN && gr.gnrm)) break;
+          const float v = wave_sum(gxs[c]);
+          if (lane == 0) atomicAdd((c < 3 ? gr.gx : gr.gnrm) + dst_ctx * 3 + (c % 3), v);
+        }
+      }
+    }
     {
       float* up = gr.gU + (size_t)s.seg * 2048 + lane;
 #pragma unroll
@@ -745,6 +765,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       const int n = t.g_nlig[gi], lig0 = t.g_ctx_off[gi] + t.g_nph[gi], lj = cj - lig0;
       const int* eid_g = t.eid + t.g_eid_off[gi];
       for (int i = tid; i < ((n + 15) & ~15) * 256; i += blockDim.x) L.accP[i] = 0.f;
+      for (int i = tid; i < ((n + 15) & ~15) * 3; i += blockDim.x) L.accX[i] = 0.f;
       __syncthreads();
       const int n_tiles_j = (n + 15) >> 4;
       for (int base = 0; base < n; base += NW) {
@@ -773,6 +794,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         float* dst = (c < 128 ? gr.gCsrc_k : gr.gCsrc_v) + (size_t)e * gr.ld_gcsrc + (c & 127);
         *dst = L.accP[i];
       }
+      if (gr.gx)
+        for (int i = tid; i < n * 3; i += blockDim.x) atomicAdd(gr.gx + (lig0 + i / 3) * 3 + (i % 3), L.accX[i]);
       __syncthreads();
     }
   } else {
@@ -816,7 +839,7 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;
-  const size_t lds = ((size_t)2 * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 256 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
+  const size_t lds = ((size_t)2 * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 259 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
                       (size_t)NW * PW) * sizeof(float);
   if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
   static size_t attr_set = 0;

@@ -116,28 +116,47 @@ __global__ __launch_bounds__(256) void fold_wgrad_kernel(const float* X, int ldx
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[a][d] = 0.f;
-  for (int si = blockIdx.x * 4 + (threadIdx.x >> 6); si < n; si += gridDim.x * 4) {
-    const int s = ids ? ids[si] : si;
-    const float* xp = X + (size_t)s * ldx + 8 * m;
-    const f4 xa = *reinterpret_cast<const f4*>(xp), xb = *reinterpret_cast<const f4*>(xp + 4);
-    const float* tp = T + (size_t)s * 2048 + lane;
+  // 4 segments per iteration: 4 x (2 float4 of X + 4 dwords of T) loads in flight per lane (the kernel is pure streaming)
+  const int stride = gridDim.x * 4;
+  for (int si0 = blockIdx.x * 4 + (threadIdx.x >> 6); si0 < n; si0 += 4 * stride) {
+    f4 xa[4], xb[4];
+    float tv[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const float tv = tp[(i0 + a) * 64];
+    for (int u = 0; u < 4; ++u) {
+      const int si = si0 + u * stride;
+      const bool ok = si < n;
+      const int s = ok ? (ids ? ids[si] : si) : 0;
+      const float* xp = X + (size_t)s * ldx + 8 * m;
+      xa[u] = ok ? *reinterpret_cast<const f4*>(xp) : (f4){0.f, 0.f, 0.f, 0.f};
+      xb[u] = ok ? *reinterpret_cast<const f4*>(xp + 4) : (f4){0.f, 0.f, 0.f, 0.f};
+      const float* tp = T + (size_t)s * 2048 + lane;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[a][j] = fmaf(xa[j], tv, acc[a][j]);
-        acc[a][4 + j] = fmaf(xb[j], tv, acc[a][4 + j]);
-      }
+      for (int a = 0; a < 4; ++a) tv[u][a] = ok ? tp[(i0 + a) * 64] : 0.f;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[a][j] = fmaf(xa[u][j], tv[u][a], acc[a][j]);
+          acc[a][4 + j] = fmaf(xb[u][j], tv[u][a], acc[a][4 + j]);
+        }
   }
+  // the 4 waves of the workgroup hold partial sums of the same 64 x 32 values: reduce them in LDS, one global atomic per
+  // value per workgroup (the flush, not the streaming, dominated this kernel when every wave flushed on its own)
+  __shared__ float red[4][32][64];
+  const int w = threadIdx.x >> 6;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      atomicAdd(gW2_l + ((size_t)(2 * (i0 + a)) * 64 + lane) * 4 + j, acc[a][j]);
-      atomicAdd(gW2_l + ((size_t)(2 * (i0 + a) + 1) * 64 + lane) * 4 + j, acc[a][4 + j]);
-    }
+    for (int d = 0; d < 8; ++d) red[w][a * 8 + d][lane] = acc[a][d];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+    const int e = i >> 6, l = i & 63, a = e >> 3, d = e & 7;
+    const float v = red[0][e][l] + red[1][e][l] + red[2][e][l] + red[3][e][l];
+    atomicAdd(gW2_l + ((size_t)(2 * (i0 + a) + (d >> 2)) * 64 + l) * 4 + (d & 3), v);
+  }
 }
 
 }  // namespace pg
@@ -180,7 +199,7 @@ extern "C" int pg_attn_fold_wgrad(const float* X, int ldx, const float* T, int n
                                   void* stream) {
   if (n <= 0) return PG_OK;
   int blocks = (n + 3) / 4;
-  if (blocks > kNumCU) blocks = kNumCU;
+  if (blocks > kNumCU / 2) blocks = kNumCU / 2;     // x 8 column groups = 1024 workgroups; few flushes, long streams
   hipLaunchKernelGGL(fold_wgrad_kernel, dim3(blocks, 8), dim3(256), 0, (hipStream_t)stream, X, ldx, T, n, ids, gW2_l);
   return check_launch("pg_attn_fold_wgrad");
 }
