@@ -9,13 +9,14 @@ namespace pg {
 // ------------------------------------------------------------------------------------------------
 // gW[n,k] += sum_r dY[r,n] * X[r,k]       (rows are the contraction index; M is huge, N and K are small)
 // Workgroup = 4 waves in 2x2, output tile 64(n) x 64(k), one 32x32x2 accumulator per wave; blockIdx.z strides over
-// row chunks of 32 and the partial tile is added with atomics.  Both operands are read from LDS with the lane
+// row chunks of 64 (float4 loads) and the partial tile is added with atomics.  Both operands are read from LDS with the lane
 // running along the row-major fast dimension: A[i=n][kk=row] = sdY[row][n], B[kk=row][j=k] = sX[row][k].
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* dY, int ldy, const float* X, int ldx, int M, int N,
                                                          int K, float* gW, int ldgw, float* gb) {
-  __shared__ float sdY[32][64 + 1];
-  __shared__ float sX[32][64 + 1];
+  constexpr int R = 64;                                  // rows per staged chunk
+  __shared__ __attribute__((aligned(16))) float sdY[R][64 + 4];
+  __shared__ __attribute__((aligned(16))) float sX[R][64 + 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
   const int wn = (wave & 1) * 32, wk = (wave >> 1) * 32;
@@ -23,22 +24,38 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* dY, int ld
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float colsum = 0.f;
-  const int lr = tid >> 3, lc = (tid & 7) * 8;     // loader: row lr, 8 consecutive columns from lc
-  for (int row0 = blockIdx.z * 32; row0 < M; row0 += gridDim.z * 32) {
+  const int lr = tid >> 2, lc = (tid & 3) * 16;          // loader: row lr, 16 consecutive columns from lc (4 x float4)
+  const bool vecY = (ldy & 3) == 0 && ((size_t)dY & 15) == 0 && n0 + 64 <= N;
+  const bool vecX = (ldx & 3) == 0 && ((size_t)X & 15) == 0 && k0 + 64 <= K;
+  for (int row0 = blockIdx.z * R; row0 < M; row0 += gridDim.z * R) {
     const int row = row0 + lr;
+    const bool in = row < M;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int n = n0 + lc + j, k = k0 + lc + j;
-      sdY[lr][lc + j] = (row < M && n < N) ? dY[(size_t)row * ldy + n] : 0.f;
-      sX[lr][lc + j] = (row < M && k < K) ? X[(size_t)row * ldx + k] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int c = lc + 4 * q;
+      f4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      if (in) {
+        if (vecY) vy = *reinterpret_cast<const f4*>(dY + (size_t)row * ldy + n0 + c);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n0 + c + j < N) vy[j] = dY[(size_t)row * ldy + n0 + c + j];
+        }
+        if (vecX) vx = *reinterpret_cast<const f4*>(X + (size_t)row * ldx + k0 + c);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (k0 + c + j < K) vx[j] = X[(size_t)row * ldx + k0 + c + j];
+        }
+      }
+      *reinterpret_cast<f4*>(&sdY[lr][c]) = vy;
+      *reinterpret_cast<f4*>(&sX[lr][c]) = vx;
     }
     __syncthreads();
     if (gb && blockIdx.y == 0 && tid < 64) {
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) colsum += sdY[r][tid];
+      for (int r = 0; r < R; ++r) colsum += sdY[r][tid];
     }
-#pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
+#pragma unroll 8
+    for (int kk = 0; kk < R; kk += 2) {
       const int rr = kk + (lane >> 5);
       acc = mfma32(sdY[rr][wn + (lane & 31)], sX[rr][wk + (lane & 31)], acc);
     }
@@ -167,8 +184,8 @@ extern "C" int pg_gemm_wgrad(const float* dY, int ldy, const float* X, int ldx, 
                              float* gb, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
   const int bn = (N + 63) / 64, bk = (K + 63) / 64;
-  int split = (4 * kNumCU + bn * bk - 1) / (bn * bk);
-  const int chunks = (M + 31) / 32;
+  int split = (8 * kNumCU + bn * bk - 1) / (bn * bk);
+  const int chunks = (M + 63) / 64;
   if (split > chunks) split = chunks;
   if (split < 1) split = 1;
   hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(bn, bk, split), dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K,
