@@ -581,7 +581,9 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
     case PG_SEG_BOND_POS: return launch_seg<PG_SEG_BOND_POS>(t, p, st);
     case PG_SEG_TRIPLET:
       // the occupancy-tuned kernel holds the logits of <= 5 row tiles in registers (ligands of <= 80 atoms)
-      return (t->max_nlig <= 80 && !p->S) ? launch_triplet(t, p, st) : launch_seg<PG_SEG_TRIPLET>(t, p, st);
+      // S / swn output (training): the tuned kernel when the query-side inputs are given too, else the generic form
+      return (t->max_nlig <= 80 && (!p->S || (p->q && p->W2k_l && p->G))) ? launch_triplet(t, p, st)
+                                                                        : launch_seg<PG_SEG_TRIPLET>(t, p, st);
     case PG_SEG_PHORE: return launch_seg<PG_SEG_PHORE>(t, p, st);
   }
   set_error("pg_seg_attn: unknown mode %d", p->mode);

@@ -308,6 +308,17 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
       }
     }
 
+    if (p.S) {
+      // training form: hand S (normalised) and the attention mass to pg_attn_unfold_value, like the node modes
+      float* sp = p.S + (size_t)seg * 2048 + lane;
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sp[(tq * 4 + r) * 64] = sT[tq][r] * inv;
+      if (g == 0) p.swn[(size_t)seg * 16 + m] = l > 0.f ? 1.f : 0.f;
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     // =============================== epilogue: out = resid + W2v_h . S[:,h] / l + b2v ===============================
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ablate & 4) {

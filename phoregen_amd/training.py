@@ -182,6 +182,8 @@ class SegCoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, Ydst, Ysrc, U, x, nrm, ew, Wf_k, Wf_v, bk, bv, W2xv_l, b2xv):
+        """cfg['tri_fwd'] (triplet only): dict(q, W2k_l, W2v_l, b2v, Wg2_k, Wg2_v, G, seg_ids, seg_chunks) lets the forward run
+        in the tuned triplet kernel (it folds q and smear(d_ji) itself); U / Ydst still feed the adjoint."""
         lib = hip.lib()
         pos = cfg['mode'] in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
         dev = Ydst.device
@@ -204,6 +206,10 @@ class SegCoreFn(torch.autograd.Function):
             s.dx, s.accumulate_dx = out[0].data_ptr(), 0
         else:
             s.S, s.swn = out[0].data_ptr(), out[1].data_ptr()
+        tf = cfg.get('tri_fwd')
+        if tf is not None:
+            for k in ('q', 'W2k_l', 'W2v_l', 'b2v', 'Wg2_k', 'Wg2_v', 'G', 'seg_ids', 'seg_chunks'):
+                setattr(s, k, tf[k].data_ptr())
         hip.check(lib.pg_seg_attn(cfg['topo'], C.byref(s), _st()), 'pg_seg_attn')
         ctx.cfg, ctx.tensors, ctx.pos = cfg, tensors, pos
         return out if not pos else out[0]
@@ -413,7 +419,10 @@ class TrainForward:
             qT = linear(LnReluFn.apply(qhid, a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
             U = FoldFn.apply(qT, a.W2k_l, None, E)
             cfg = dict(mode=hip.SEG_TRIPLET, n_seg=E, seg_ids=None, k=self.k, topo=p.topo_ref, n_out_rows=E,
-                       max_rows=max_lig, need_gx=True)
+                       max_rows=max_lig, need_gx=True,
+                       tri_fwd=dict(q=qT.detach(), W2k_l=a.W2k_l.detach(), W2v_l=a.W2v_l.detach(), b2v=a.b2v.detach(),
+                                    Wg2_k=a.Wg2_k.detach(), Wg2_v=a.Wg2_v.detach(), G=G.detach().contiguous(),
+                                    seg_ids=p.tri_order, seg_chunks=p.tri_chunks))
             S, swn = seg_core(cfg, Q, P, U, x, Wf_k=a.Wf_k, Wf_v=a.Wf_v, bk=a.ln_bk, bv=a.ln_bv)
             hb_new = hb + UnfoldFn.apply(S, swn, a.W2v_l, a.b2v, None, E)
             h_new = h + linear(aggE + aggB, L.W_lin, L.b_lin)
