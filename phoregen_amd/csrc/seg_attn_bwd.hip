@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         PROF(8);   // LN adjoint, db', dhidden tile
         if (NSTEP > 0 && !(ab & 4)) {
           // d feat[row, f] += sum_c dhidden[c,row] * Wf[c,f]
-          if constexpr (!T::PH) {
+          if (!T::PH && !(ab & 256)) {
             f4 gfp[NF][4];                         // independent chains per r, folded below
 #pragma unroll
             for (int ft = 0; ft < NF; ++ft)
@@ -595,14 +595,19 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           }
           // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]
           // registers for the whole kernel (LDS ds_add_f32 accumulation measured ~700 cycles per instruction)
+          if (!(ab & 512))
 #pragma unroll
-          for (int ft = 0; ft < NF; ++ft)
+          for (int ks = 0; ks < 4; ++ks) {           // k-step outermost: consecutive MFMAs hit different accumulators
+            float bf[NF];
 #pragma unroll
-            for (int tq = 0; tq < 8; ++tq)
+            for (int ft = 0; ft < NF; ++ft) bf[ft] = L.sF[(4 * g + ks) * FS + 16 * ft + m];
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks)
-                gwf_acc[path][ft][tq] = mfma16(L.sT[(16 * tq + m) * 17 + 4 * g + ks], L.sF[(4 * g + ks) * FS + 16 * ft + m],
-                                               gwf_acc[path][ft][tq]);
+            for (int tq = 0; tq < 8; ++tq) {
+              const float a = L.sT[(16 * tq + m) * 17 + 4 * g + ks];
+#pragma unroll
+              for (int ft = 0; ft < NF; ++ft) gwf_acc[path][ft][tq] = mfma16(a, bf[ft], gwf_acc[path][ft][tq]);
+            }
+          }
         }
         PROF(9);   // dfeat, dWf
         // d Csrc (scatter) and d Cdst (row sum): lane owns channels lane and lane + 64
