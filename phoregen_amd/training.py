@@ -66,8 +66,10 @@ class LinearFn(torch.autograd.Function):
             if M:
                 _gemm_raw(gY, W.t().contiguous(), gX)
         if ctx.needs_input_grad[1] or ctx.has_bias:
-            gW = torch.zeros_like(W)
-            gb = torch.zeros(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_bias else None
+            N, K = W.shape
+            buf = torch.zeros(N * K + (N if ctx.has_bias else 0), dtype=torch.float32, device=W.device)   # one fill for both
+            gW = buf[:N * K].view(N, K)
+            gb = buf[N * K:] if ctx.has_bias else None
             hip.check(lib.pg_gemm_wgrad(gY.data_ptr(), gY.stride(0), X.data_ptr(), X.stride(0), M, W.shape[0], W.shape[1],
                                         gW.data_ptr(), gW.stride(0), hip.ptr(gb), _st()), 'pg_gemm_wgrad')
         return gX, gW, gb
@@ -242,8 +244,17 @@ class SegCoreFn(torch.autograd.Function):
         gx = z(t['x']) if cfg['need_gx'] else None
         gnrm = z(t['nrm']) if (cfg['need_gx'] and t['nrm'] is not None) else None
         gew = z(t['ew'])
-        gWf_k, gWf_v, gbk, gbv = z(t['Wf_k']), z(t['Wf_v']), z(t['bk']), z(t['bv'])
-        gW2, gb2 = z(t['W2xv_l']), z(t['b2xv'])
+        # the small weight gradients share one zero-filled buffer (one fill launch instead of six)
+        small = [t[k] for k in ('Wf_k', 'Wf_v', 'bk', 'bv', 'W2xv_l', 'b2xv')]
+        buf = torch.zeros(sum(x.numel() for x in small if x is not None), dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for x in small:
+            if x is None:
+                views.append(None)
+            else:
+                views.append(buf[off:off + x.numel()].view(x.shape))
+                off += x.numel()
+        gWf_k, gWf_v, gbk, gbv, gW2, gb2 = views
         g = hip.PgSegAttnGrad()
         keep = []
         if pos:
