@@ -212,19 +212,16 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
           const float var = q2 * (1.f / 128.f) + 1e-5f;
           const float rs = __builtin_amdgcn_rsqf(var);
           const float sigma = var * rs;
-          f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains: 40-cycle dependent latency
+          f4 acc4[4];                                                   // four chains: dependent MFMAs wait ~10 extra cycles
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc4[r] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) {
             const f4 bt = *reinterpret_cast<const f4*>(bk + 16 * tq + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-              const float z0 = fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f);
-              const float z1 = fmaxf(fmaf(bt[r + 1], sigma, hid[tq][r + 1]), 0.f);
-              acc = mfma16(z0, U[tq][r], acc);
-              acc2 = mfma16(z1, U[tq][r + 1], acc2);
-            }
+            for (int r = 0; r < 4; ++r) acc4[r] = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), U[tq][r], acc4[r]);
           }
-          acc += acc2;
+          f4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[r] *= __shfl(rs, 4 * g + r);     // rstd of row 4g+r lives in lane m = 4g+r
           // rows of the logits layout: k = 16 tile + 4g + r
