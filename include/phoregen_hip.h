@@ -148,6 +148,7 @@ typedef struct {
   const float* resid; float* out;            /* triplet: out[e,:] = resid[e,:] + update           */
   float* dx;                 /* pos modes: [n_ctx,3]                                              */
   int accumulate_dx;         /* pos modes: dx += instead of =                                     */
+  float* alpha; int alpha_rows; /* triplet S-form, optional: softmax weights out [n_bond][alpha_rows][16] (training)  */
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 
@@ -219,6 +220,8 @@ typedef struct {
   float* gW2xv_l; float* gb2xv;            /* (+=) pos modes                                                         */
   float* gx; float* gnrm;                  /* (+=) [n_ctx,3]; NULL = not needed (pharmacophore encoder)              */
   float* gew;                              /* (=) knn modes [n_ctx,k]                                                */
+  const float* alpha; int alpha_rows;      /* triplet, optional: softmax weights of the forward [n_bond][alpha_rows][16] (PgSegAttn.alpha) */
+  const float* S; const float* swn;        /* ... with the forward's S / swn: one pass instead of two                */
   float* rowbuf; int rowbuf_rows; int grid;/* scratch: grid * pg_seg_attn_bwd_waves(mode) * rowbuf_rows * 48 floats,
                                               rowbuf_rows >= rows of the largest segment; grid = workgroups to launch */
 } PgSegAttnGrad;

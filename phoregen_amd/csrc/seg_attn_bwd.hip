@@ -156,7 +156,7 @@ struct BwdLds {
 
 }  // namespace
 
-template <int MODE, int NW>
+template <int MODE, int NW, bool OP = false>   // OP: one pass, alpha / S of the forward given (triplet training form)
 __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAttn p, PgSegAttnGrad gr, int ab) {
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     PROF_T0();
     PROF(0);   // segment setup
     // =============================== pass 1: logits and tv of every row ===============================
-    for (int tile = 0; tile < ((ab & 32) ? 0 : n_tiles); ++tile) {
+    for (int tile = 0; tile < ((OP || (ab & 32)) ? 0 : n_tiles); ++tile) {
       const RowInfo rk = row_info<MODE>(t, p, s, tile * 16 + m);
       float feat[NS];
       RowGeo<MODE> geo;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     PROF(1);   // pass 1
 
     // =============================== softmax backward per head m (rows r = g, g+4, ...) ===============================
-    if (!(ab & 16)) {
+    if (!OP && !(ab & 16)) {
       float mx = NEG_BIG;
       for (int r = g; r < n_rows; r += 4) mx = fmaxf(mx, rb[r * ROWBUF + m]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -388,6 +388,20 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     rowbuf_sync();
     PROF(2);   // softmax
 
+    // one-pass form: D[h] = sum_r alpha * dalpha = <S[:,h], dS[:,h]> + swn[h] * dswn[h] (S, swn of the forward), alpha read back
+    float Dm = 0.f;
+    const float* arow = nullptr;
+    if constexpr (OP) {
+      const float* Sp = gr.S + (size_t)s.seg * 2048 + lane;
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dm = fmaf(Sp[(tq * 4 + r) * 64], Mr[tq][r], Dm);
+      Dm += __shfl_xor(Dm, 16);
+      Dm += __shfl_xor(Dm, 32);
+      Dm = fmaf(gr.swn[(size_t)s.seg * 16 + m], gswn_m, Dm);
+      arow = gr.alpha + (size_t)s.seg * gr.alpha_rows * 16;
+    }
     // =============================== pass 2: gradients ===============================
     f4 gU[8];
 #pragma unroll
@@ -413,25 +427,35 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       if constexpr (T::POS) e_m = (gdx[0] * geo.rel[0] + gdx[1] * geo.rel[1] + gdx[2] * geo.rel[2]) * (1.f / 16.f);
       const float cw_m = rk.valid ? (T::POS ? w_m * e_m : w_m) : 0.f;
       if (g == 0) L.sR[32 + m] = cw_m;
+      if constexpr (OP) wave_lds_sync();      // the value path runs first in the one-pass form and reads cw right away
 
       f4 gfeat[NF];
 #pragma unroll
       for (int ft = 0; ft < NF; ++ft) gfeat[ft] = (f4){0.f, 0.f, 0.f, 0.f};
       // row-buffer values of this tile in one batch of loads: rows 4g + r at head m, and row m at heads 4g .. 4g+3
       f4 aD = {0.f, 0.f, 0.f, 0.f}, glD = {0.f, 0.f, 0.f, 0.f}, aK = {0.f, 0.f, 0.f, 0.f}, glK = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (OP) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = tile * 16 + 4 * g + r;
-        if (row < n_rows) { aD[r] = rb[row * ROWBUF + m]; glD[r] = rb[row * ROWBUF + 32 + m]; }
-      }
-      if (row_m < n_rows) {
-        aK = *reinterpret_cast<const f4*>(rb + row_m * ROWBUF + 4 * g);
-        glK = *reinterpret_cast<const f4*>(rb + row_m * ROWBUF + 32 + 4 * g);
+        for (int r = 0; r < 4; ++r) {
+          const int row = tile * 16 + 4 * g + r;
+          if (row < n_rows) aD[r] = arow[row * 16 + m];
+        }
+        if (row_m < n_rows) aK = *reinterpret_cast<const f4*>(arow + row_m * 16 + 4 * g);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = tile * 16 + 4 * g + r;
+          if (row < n_rows) { aD[r] = rb[row * ROWBUF + m]; glD[r] = rb[row * ROWBUF + 32 + m]; }
+        }
+        if (row_m < n_rows) {
+          aK = *reinterpret_cast<const f4*>(rb + row_m * ROWBUF + 4 * g);
+          glK = *reinterpret_cast<const f4*>(rb + row_m * ROWBUF + 32 + 4 * g);
+        }
       }
 
 #pragma unroll
       for (int path = 0; path < ((ab & 8) ? 1 : 2); ++path) {
-        const bool kp = path == 0;
+        const bool kp = OP ? path == 1 : path == 0;
         const float* bp = kp ? L.bk : L.bv;
         const float* wf = kp ? L.wf_k : L.wf_v;
         f4 hid[8];
@@ -441,6 +465,20 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         PROF(3);   // tile head: features, row buffer loads
         const f4 y = kp ? relu_project(hid, bp, sg, Ur) : relu_project(hid, bp, sg, Mr);   // unscaled, rows 4g+r, head m
         PROF(4);   // recompute
+        if constexpr (OP) {
+          if (!kp) {
+            // dalpha[row,h] = cw * (rstd_v * y + dswn);  dlogit = ln2 * alpha * (dalpha - D); key path needs it in both layouts
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float ga = L.sR[32 + 4 * g + r] * fmaf(y[r], __shfl(rs, 4 * g + r), gswn_m);
+              glD[r] = LN2 * aD[r] * (ga - Dm);
+              L.sGF[(4 * g + r) * FS + m] = glD[r];
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) glK[ks] = L.sGF[m * FS + 4 * g + ks];
+          }
+        }
         // coefficient of y in the loss, rows 4g+r: k path dlogit ; v path cw * alpha
         f4 coefD;
 #pragma unroll
@@ -605,7 +643,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
             for (int tq = 0; tq < 8; ++tq) {
               const float a = L.sT[(16 * tq + m) * 17 + 4 * g + ks];
 #pragma unroll
-              for (int ft = 0; ft < NF; ++ft) gwf_acc[path][ft][tq] = mfma16(a, bf[ft], gwf_acc[path][ft][tq]);
+              for (int ft = 0; ft < NF; ++ft) gwf_acc[kp ? 0 : 1][ft][tq] = mfma16(a, bf[ft], gwf_acc[kp ? 0 : 1][ft][tq]);
             }
           }
         }
@@ -787,7 +825,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           for (int tile = 0; tile < ((ab & 64) ? 0 : n_tiles_j); ++tile)
             for (int path = 0; path < ((ab & 8) ? 1 : 2); ++path) {
               for (int i = lane; i < 128 * 17; i += 64) L.sT[i] = 0.f;
-              tri_merge(tile, path == 0);
+              tri_merge(tile, OP ? path == 1 : path == 0);
             }
         }
       }
@@ -839,7 +877,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   }
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, bool OP = false>
 static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st) {
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
@@ -849,7 +887,7 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
   static size_t attr_set = 0;
   if (attr_set < lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW, OP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { set_error("pg_seg_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
     attr_set = lds;
@@ -859,7 +897,7 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   if (blocks < 1) blocks = 1;
   static int ablate = -1;
   if (ablate < 0) { const char* e = getenv("PG_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }   // timing experiments only
-  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr, ablate);
+  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW, OP>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr, ablate);
   return check_launch("pg_seg_attn_bwd");
 }
 
@@ -891,7 +929,8 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
     case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
     case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
     case PG_SEG_TRIPLET:
-      return launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
+      return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_TRIPLET, 4, true>(t, p, gr, st)
+                                             : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
     case PG_SEG_PHORE: return launch_bwd<PG_SEG_PHORE, 4>(t, p, gr, st);
   }
   set_error("pg_seg_attn_bwd: unknown mode %d", p->mode);

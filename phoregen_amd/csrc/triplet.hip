@@ -254,6 +254,16 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if (p.alpha) {                       // training: the adjoint reads the softmax weights back instead of recomputing them
+      float* ap = p.alpha + (size_t)seg * p.alpha_rows * 16 + m;
+#pragma unroll
+      for (int tile = 0; tile < TRI_MAX_TILES; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kr = tile * 16 + 4 * g + r;
+          if (kr < p.alpha_rows) ap[kr * 16] = lg[tile][r] * inv;
+        }
+    }
 
     // =============================== pass B: S^T[c, h] = sum_rows z_v[row, c] * alpha[row, h] ===============================
     f4 sT[8];

@@ -44,7 +44,7 @@ class PgSegAttn(C.Structure):
                 ('U', c_fp), ('q', c_fp), ('W2k_l', c_fp), ('W2v_l', c_fp), ('b2v', c_fp),
                 ('W2xv_l', c_fp), ('b2xv', c_fp),
                 ('S', c_fp), ('swn', c_fp), ('resid', c_fp), ('out', c_fp), ('dx', c_fp),
-                ('accumulate_dx', C.c_int)]
+                ('accumulate_dx', C.c_int), ('alpha', c_fp), ('alpha_rows', C.c_int)]
 
 
 class PgSegAttnGrad(C.Structure):
@@ -53,6 +53,7 @@ class PgSegAttnGrad(C.Structure):
                 ('gCsrc_k', c_fp), ('gCsrc_v', c_fp), ('ld_gcsrc', C.c_int),
                 ('gWf_k', c_fp), ('gWf_v', c_fp), ('gbk', c_fp), ('gbv', c_fp),
                 ('gW2xv_l', c_fp), ('gb2xv', c_fp), ('gx', c_fp), ('gnrm', c_fp), ('gew', c_fp),
+                ('alpha', c_fp), ('alpha_rows', C.c_int), ('S', c_fp), ('swn', c_fp),
                 ('rowbuf', c_fp), ('rowbuf_rows', C.c_int), ('grid', C.c_int)]
 
 

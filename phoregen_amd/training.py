@@ -11,6 +11,7 @@ itself) is composed from elementwise tensor ops here; the kNN searches stay in t
 No CPU fallback: every entry point raises without the library / a GPU.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -209,9 +210,18 @@ class SegCoreFn(torch.autograd.Function):
         else:
             s.S, s.swn = out[0].data_ptr(), out[1].data_ptr()
         tf = cfg.get('tri_fwd')
+        alpha = None
         if tf is not None:
             for k in ('q', 'W2k_l', 'W2v_l', 'b2v', 'Wg2_k', 'Wg2_v', 'G', 'seg_ids', 'seg_chunks'):
                 setattr(s, k, tf[k].data_ptr())
+            if cfg['max_rows'] <= 80 and os.environ.get('PG_TRI_ONEPASS', '1') != '0':   # the tuned kernel runs: it can hand the softmax weights to the adjoint
+                arows = (cfg['max_rows'] + 15) // 16 * 16
+                alpha = torch.empty(cfg['n_seg'] * arows * 16, dtype=torch.float32, device=dev)
+                s.alpha, s.alpha_rows = alpha.data_ptr(), arows
+                ctx.alpha_rows = arows
+        ctx.has_alpha = alpha is not None
+        if alpha is not None:
+            ctx.save_for_backward(alpha, out[0], out[1])
         hip.check(lib.pg_seg_attn(cfg['topo'], C.byref(s), _st()), 'pg_seg_attn')
         ctx.cfg, ctx.tensors, ctx.pos = cfg, tensors, pos
         return out if not pos else out[0]
@@ -277,6 +287,11 @@ class SegCoreFn(torch.autograd.Function):
         rows = (cfg['max_rows'] + 15) // 16 * 16
         rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
         g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
+        if getattr(ctx, 'has_alpha', False):
+            a_, S_, sw_ = ctx.saved_tensors
+            g.alpha, g.alpha_rows = a_.data_ptr(), ctx.alpha_rows
+            g.S, g.swn = S_.data_ptr(), sw_.data_ptr()
+            keep += [a_, S_, sw_]
         s = SegCoreFn._struct(cfg, t)
         hip.check(lib.pg_seg_attn_bwd(cfg['topo'], C.byref(s), C.byref(g), _st()), 'pg_seg_attn_bwd')
         # first-layer blocks: the k|v target halves live in Ydst[:, 0:256], the source halves in Ysrc[:, 0:256]
