@@ -133,7 +133,8 @@ class FoldFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, W2_l, ids, n_ids):
         q, W2_l = _rowmajor(q), W2_l.contiguous()
-        U = (torch.zeros if ids is not None else torch.empty)(q.shape[0], 2048, dtype=torch.float32, device=q.device)
+        # rows outside `ids` are never read by any kernel and no tensor op touches U / S / dU / dS: no fill needed
+        U = torch.empty(q.shape[0], 2048, dtype=torch.float32, device=q.device)
         _fold(q, W2_l, ids, n_ids, U)
         ctx.save_for_backward(q, W2_l)
         ctx.ids, ctx.n_ids = ids, n_ids
@@ -164,7 +165,7 @@ class UnfoldFn(torch.autograd.Function):
     def backward(ctx, gout):
         S, swn, W2_l, b2 = ctx.saved_tensors
         gout = _rowmajor(gout)
-        gS = torch.zeros_like(S) if ctx.ids is not None else torch.empty_like(S)
+        gS = torch.empty_like(S)
         _fold(gout, W2_l, ctx.ids, ctx.n_ids, gS)
         g3 = gout.reshape(-1, 16, 8)
         sel = torch.zeros(S.shape[0], 1, 1, dtype=torch.float32, device=S.device)
@@ -203,7 +204,7 @@ class SegCoreFn(torch.autograd.Function):
         if pos:
             out = (alloc(n_rows, 3, dtype=torch.float32, device=dev),)
         else:
-            out = (alloc(n_rows, 2048, dtype=torch.float32, device=dev), alloc(n_rows, 16, dtype=torch.float32, device=dev))
+            out = (torch.empty(n_rows, 2048, dtype=torch.float32, device=dev), alloc(n_rows, 16, dtype=torch.float32, device=dev))
         s = SegCoreFn._struct(cfg, tensors)
         if pos:
             s.dx, s.accumulate_dx = out[0].data_ptr(), 0
@@ -248,7 +249,8 @@ class SegCoreFn(torch.autograd.Function):
         dev = t['x'].device
         z = lambda ref: None if ref is None else torch.zeros_like(ref)
         full = cfg['seg_ids'] is None and cfg['n_seg'] == cfg['n_out_rows']
-        gYdst, gU = (torch.empty_like(t['Ydst']), torch.empty_like(t['U'])) if full else (z(t['Ydst']), z(t['U']))
+        gYdst = torch.empty_like(t['Ydst']) if full else z(t['Ydst'])
+        gU = torch.empty_like(t['U'])
         # bond / triplet modes store every dCsrc row exactly once; the knn / phore modes accumulate with atomics
         gYsrc = torch.empty_like(t['Ysrc']) if (full and cfg['mode'] == hip.SEG_TRIPLET) else z(t['Ysrc'])
         gx = z(t['x']) if cfg['need_gx'] else None

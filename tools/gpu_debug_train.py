@@ -45,7 +45,7 @@ c = torch.arange(128, device=dev); h = torch.arange(16, device=dev)
 idx = (((c >> 4) * 4 + (c & 3)) * 64 + ((c >> 2) & 3) * 16)[:, None] + h[None, :]       # lane-fixed position of (c, h)
 U2 = torch.zeros(n, 2048, device=dev).index_put((ids.long()[:, None, None], idx[None]), Ud[ids.long()])
 (U2 * R).sum().backward()
-print('fold fwd %.1e gq %.1e gW2 %.1e' % (rel(U, U2), rel(g1[0], q.grad), rel(g1[1], W2.grad)))
+print('fold fwd %.1e gq %.1e gW2 %.1e' % (rel(U[ids.long()], U2[ids.long()]), rel(g1[0], q.grad), rel(g1[1], W2.grad)))
 S = torch.randn(n, 2048, device=dev, requires_grad=True); sw = torch.rand(n, 16, device=dev, requires_grad=True)
 b2 = torch.randn(128, device=dev, requires_grad=True); R = torch.randn(n, 128, device=dev); q.grad = W2.grad = None
 o = tr.UnfoldFn.apply(S, sw, lane_fixed_w2(W2), b2, ids, ids.numel()); (o * R).sum().backward()
@@ -54,7 +54,7 @@ Sd = S[:, idx]                                                                  
 od = torch.einsum('sch,hdc->shd', Sd, W2.view(16, 8, 128)).reshape(n, 128) + b2 * sw.repeat_interleave(8, 1)
 mask = torch.zeros(n, 1, device=dev); mask[ids.long()] = 1
 (od * mask * R).sum().backward()
-print('unfold fwd %.1e gS %.1e gsw %.1e gW2 %.1e gb2 %.1e' % (rel(o, od * mask), rel(g1[0], S.grad), rel(g1[1], sw.grad),
+print('unfold fwd %.1e gS %.1e gsw %.1e gW2 %.1e gb2 %.1e' % (rel(o, od * mask), rel(g1[0][ids.long()], S.grad[ids.long()]), rel(g1[1], sw.grad),
                                                               rel(g1[2], W2.grad), rel(g1[3], b2.grad)))
 
 # ---- whole forward ----
