@@ -459,7 +459,7 @@ class Oracle:
         return loss, info
 
     # ---- sampler (diffusion.py:391-525) with an explicit noise source ----
-    def sample(self, h_phore, pos_phore, phore_norm, center, num_atoms, rng, t_total=None, guidance=None):
+    def sample(self, h_phore, pos_phore, phore_norm, center, num_atoms, rng, t_total=None, guidance=None, n_steps=None):
         """`rng` provides .randn(shape), .rand64(shape), .rand(shape) in the reference's draw order
         (SURVEY.md Appendix B 3-5).  Returns the reference's result dict plus per-step records."""
         T = self.T if t_total is None else t_total
@@ -480,7 +480,7 @@ class Oracle:
         log_edge = torch.log(h_edge.clamp(min=1e-30))
         traj = [[h_node], [pos], [h_edge]]                      # diffusion.py:424-426 (no +center at index 0)
         steps = []
-        for step in range(T)[::-1]:
+        for step in list(range(T)[::-1])[:n_steps]:          # n_steps: only the first steps (tools/match_rate.py)
             t = torch.full((B,), step, dtype=torch.long)
             v, x0, bond, _ = self.forward(h_node, pos, batch_node, h_edge, edge_index, batch_edge, t, hp, pp, pn, bp)
             steps.append((h_node, pos, h_edge, v, x0, bond))
