@@ -223,12 +223,13 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   // triplet: merge the 4 waves' d hidden tiles (own sT each) into the workgroup's accP rows; channel-owned, no atomics.
   // Every wave of the workgroup must call this the same number of times (idle waves with a zeroed tile).
   auto tri_merge = [&](int tile, bool kp) {
+    constexpr int CPW = 128 / NW, GROUPS = 64 / CPW, RPL = 16 / GROUPS;   // channels per wave, lane groups, rows per lane
     __syncthreads();
-    const int cc = 32 * wave + (lane & 31), half = lane >> 5;
-    float* ap = L.accP + (size_t)(tile * 16 + 8 * half) * 256 + (kp ? 0 : 128) + cc;
-    const float* st0 = L.sT - wave * PW + cc * 17 + 8 * half;       // wave 0's tile, this lane's channel / row block
+    const int cc = CPW * wave + (lane % CPW), grp = lane / CPW;
+    float* ap = L.accP + (size_t)(tile * 16 + RPL * grp) * 256 + (kp ? 0 : 128) + cc;
+    const float* st0 = L.sT - wave * PW + cc * 17 + RPL * grp;      // wave 0's tile, this lane's channel / row block
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < RPL; ++rr) {
       float v = 0.f;
 #pragma unroll
       for (int w2 = 0; w2 < NW; ++w2) v += st0[w2 * PW + rr];
@@ -928,9 +929,13 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
     case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
     case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
     case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
-    case PG_SEG_TRIPLET:
-      return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_TRIPLET, 4, true>(t, p, gr, st)
-                                             : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
+    case PG_SEG_TRIPLET: {
+      // the per-source-atom rows (max_nlig x 259 floats) share the LDS with the per-wave tiles: 4 waves up to 64 atoms,
+      // 2 waves up to the reference's maximum of 78 (and beyond, to 96)
+      const bool op = gr->alpha && gr->S && gr->swn;
+      if (t->max_nlig <= 64) return op ? launch_bwd<PG_SEG_TRIPLET, 4, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
+      return op ? launch_bwd<PG_SEG_TRIPLET, 2, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 2>(t, p, gr, st);
+    }
     case PG_SEG_PHORE: return launch_bwd<PG_SEG_PHORE, 4>(t, p, gr, st);
   }
   set_error("pg_seg_attn_bwd: unknown mode %d", p->mode);

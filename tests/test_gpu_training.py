@@ -207,3 +207,35 @@ def test_gradients_on_small_and_ragged_graphs(model):
             continue
         err = float((params[k].grad.cpu().double() - r.double()).norm() / r.double().norm())
         assert err < GRAD_TOL, (k, err)
+
+
+def test_gradients_with_a_maximum_size_ligand(model):
+    """A 78-atom ligand (the reference's max_atom; 5 row tiles, the 2-wave triplet adjoint) next to a 5-atom one."""
+    from oracle import phoregen_oracle as po
+    from oracle.make_inputs import synthetic_train_batch
+    from phoregen_amd.data import TrainBatch
+    b = synthetic_train_batch(91, [78, 5], [30, 23])
+    gen = torch.Generator().manual_seed(9)
+    N, E = b['ligand_x'].numel(), b['f_edge_attr'].numel()
+    draws = dict(time_draw=torch.tensor([930, 610]), pos_noise=torch.randn(N, 3, generator=gen),
+                 u_node=torch.rand(N, 12, generator=gen), u_edge=torch.rand(E, 6, generator=gen))
+    orc = make_oracle()
+    probe = ['denoiser.base_block.0.bond_layer.hk_func.net.0.weight', 'denoiser.base_block.2.bond_layer.hv_func.net.3.weight',
+             'denoiser.base_block.5.bond_layer.hq_func.net.0.weight', 'denoiser.base_block.1.node_layer_with_bond.hk_func.net.0.weight',
+             'denoiser.base_block.3.pos_layer_with_bond.xv_func.net.0.weight', 'edge_embedder.weight', 'node_embedder.weight',
+             'denoiser.base_block.4.lin_node.weight']
+    for k in probe:
+        orc.sd[k].requires_grad_(True)
+    loss_ref, _ = orc.compute_loss(b, po.TrainTapeRng(draws['time_draw'], draws['pos_noise'], draws['u_node'], draws['u_edge']))
+    loss_ref.backward()
+    keys = ('ligand_x', 'ligand_pos', 'ligand_batch', 'ligand_ptr', 'f_edge_index', 'f_edge_attr', 'f_edge_batch',
+            'phore_x', 'phore_pos', 'phore_norm', 'phore_batch')
+    model.zero_grad()
+    loss, _ = model.compute_loss(TrainBatch(*[b[k] for k in keys]), draws=draws)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    params = dict(model.named_parameters())
+    for k in probe:
+        r = orc.sd[k].grad.double()
+        err = float((params[k].grad.cpu().double() - r).norm() / r.norm())
+        assert err < GRAD_TOL, (k, err)
