@@ -325,17 +325,19 @@ class TrainForward:
         self.pack = ModelPack(params, num_layers, detach=False)
         self.dev = plan.device
 
-    # -- one attention sub-layer: first-layer blocks Y [.., 640] = k_dst | v_dst | k_src | v_src | q_hid
-    def _attention(self, mode, a, Y, x, dst_lists, Ysrc=None, nrm=None, ew=None, nbr=None, deg=None, max_rows=None,
+    # -- one attention sub-layer. `blk(c0, c1)` yields columns [c0, c1) of its first-layer blocks
+    #    (k_dst | v_dst | k_src | v_src | q_hid = 640 columns) as a tensor of its own: one GEMM per consumer instead of
+    #    views of one wide GEMM, so autograd never pads a slice gradient back to the wide shape
+    def _attention(self, mode, a, blk, x, dst_lists, Ysrc=None, nrm=None, ew=None, nbr=None, deg=None, max_rows=None,
                    need_gx=True):
         p = self.plan
         pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
         knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
-        n = Y.shape[0]
-        q = linear(LnReluFn.apply(Y[:, 512:640], a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
-        Ydst = Y[:, 0:256]
+        n = p.n_ctx
+        q = linear(LnReluFn.apply(blk(512, 640), a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
+        Ydst = blk(0, 256)
         if Ysrc is None:
-            Ysrc = Y[:, 256:512]
+            Ysrc = blk(256, 512)
         total = None
         for seg_ids, n_seg, is_lig in dst_lists:
             if n_seg == 0:
@@ -363,7 +365,7 @@ class TrainForward:
         h_ctx = torch.zeros(n, h_phore.shape[1], dtype=torch.float32, device=self.dev).index_copy(0, p.phore2ctx_long, h_phore.float())
         x_ctx = torch.zeros(n, 3, dtype=torch.float32, device=self.dev).index_copy(0, p.phore2ctx_long, pos_phore.float())
         hp = linear(h_ctx, pk.W_pe, pk.b_pe)
-        Yp = linear(hp, pk.W_ph, pk.b_ph)
+        Yp = lambda c0, c1: linear(hp, pk.W_ph[c0:c1], pk.b_ph[c0:c1])
         max_rows = int(p.g_nph.max()) if p.n_graphs else 0
         enc = self._attention(hip.SEG_PHORE, pk.PH, Yp, x_ctx, [(p.phore2ctx, p.n_phore, False)], max_rows=max_rows,
                               need_gx=False)
@@ -433,17 +435,22 @@ class TrainForward:
             nrm = nrm_ph.index_copy(0, p.lig2ctx_long, l_norm)
             G = gaussian_smearing((x[bsrc] - x[bdst]).pow(2).sum(-1).clamp(min=1e-24).sqrt())        # [E,20]
 
-            Y1 = linear(h, L.W_node1, L.b_node1)                                       # [n,1920]
-            aggE = self._attention(hip.SEG_KNN_NODE, L.NE, Y1[:, 0:640], x, both, nrm=nrm, ew=ew, nbr=nbr, deg=deg,
-                                   max_rows=self.k)
-            CsB = linear(hb, L.NB.W_hb) + Y1[:, 7 * 128:9 * 128].index_select(0, bsrc)
-            aggB = self._attention(hip.SEG_BOND_NODE, L.NB, Y1[:, 640:1280], x, lig, Ysrc=CsB, max_rows=max_lig)
+            # first-layer blocks of the three feature sub-layers (15 x 128 columns of W_node1), one GEMM per consumer
+            if os.environ.get('PG_WIDE_GEMM') == '1':      # A/B knob: one wide GEMM + column views (padded slice gradients)
+                Y1w = linear(h, L.W_node1, L.b_node1)
+                Y1 = lambda c0, c1: Y1w[:, c0:c1]
+            else:
+                Y1 = lambda c0, c1: linear(h, L.W_node1[c0:c1], L.b_node1[c0:c1])
+            aggE = self._attention(hip.SEG_KNN_NODE, L.NE, Y1, x, both, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
+            CsB = linear(hb, L.NB.W_hb) + Y1(7 * 128, 9 * 128).index_select(0, bsrc)
+            aggB = self._attention(hip.SEG_BOND_NODE, L.NB, lambda c0, c1: Y1(640 + c0, 640 + c1), x, lig, Ysrc=CsB,
+                                   max_rows=max_lig)
             # bond update over triplets (uni_denoiser.py:101-165)
             a = L.TB
-            P = (linear(torch.cat([hb, G], -1), a.W_hbg) + Y1[:, 10 * 128:12 * 128].index_select(0, bsrc)
-                 + Y1[:, 12 * 128:14 * 128].index_select(0, bdst))
+            P = (linear(torch.cat([hb, G], -1), a.W_hbg) + Y1(10 * 128, 12 * 128).index_select(0, bsrc)
+                 + Y1(12 * 128, 14 * 128).index_select(0, bdst))
             Q = linear(G, torch.cat([a.Wg2_k.t(), a.Wg2_v.t()], 0))                    # smear(d_ji) columns, per segment
-            qhid = linear(hb, a.W_q_hb) + Y1[:, 14 * 128:15 * 128].index_select(0, bdst)
+            qhid = linear(hb, a.W_q_hb) + Y1(14 * 128, 15 * 128).index_select(0, bdst)
             qT = linear(LnReluFn.apply(qhid, a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
             U = FoldFn.apply(qT, a.W2k_l, None, E)
             cfg = dict(mode=hip.SEG_TRIPLET, n_seg=E, seg_ids=None, k=self.k, topo=p.topo_ref, n_out_rows=E,
@@ -455,11 +462,15 @@ class TrainForward:
             hb_new = hb + UnfoldFn.apply(S, swn, a.W2v_l, a.b2v, None, E)
             h_new = h + linear(aggE + aggB, L.W_lin, L.b_lin)
             # coordinate updates from h', h_bond' and the old geometry (uni_denoiser.py:291-296)
-            Y2 = linear(h_new, L.W_node2, L.b_node2)
-            dxe = self._attention(hip.SEG_KNN_POS, L.PE, Y2[:, 0:640], x, lig, nrm=nrm, ew=ew, nbr=nbr, deg=deg,
-                                  max_rows=self.k)
-            CsB2 = linear(hb_new, L.PB.W_hb) + Y2[:, 7 * 128:9 * 128].index_select(0, bsrc)
-            dxb = self._attention(hip.SEG_BOND_POS, L.PB, Y2[:, 640:1280], x, lig, Ysrc=CsB2, max_rows=max_lig)
+            if os.environ.get('PG_WIDE_GEMM') == '1':
+                Y2w = linear(h_new, L.W_node2, L.b_node2)
+                Y2 = lambda c0, c1: Y2w[:, c0:c1]
+            else:
+                Y2 = lambda c0, c1: linear(h_new, L.W_node2[c0:c1], L.b_node2[c0:c1])
+            dxe = self._attention(hip.SEG_KNN_POS, L.PE, Y2, x, lig, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
+            CsB2 = linear(hb_new, L.PB.W_hb) + Y2(7 * 128, 9 * 128).index_select(0, bsrc)
+            dxb = self._attention(hip.SEG_BOND_POS, L.PB, lambda c0, c1: Y2(640 + c0, 640 + c1), x, lig, Ysrc=CsB2,
+                                  max_rows=max_lig)
             x = x + (dxe + dxb) * is_lig.to(x.dtype)
             h, hb = h_new, hb_new
 
