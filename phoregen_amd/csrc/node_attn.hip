@@ -248,6 +248,18 @@ __global__ __launch_bounds__(THREADS, 3) void node_attn_kernel(PgTopo t, PgSegAt
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
+    if constexpr (!POS) {
+      if (p.alpha) {                     // training: softmax weight x gate of every row, read back by the one-pass adjoint
+        float* ap = p.alpha + (size_t)seg * p.alpha_rows * 16 + m;
+#pragma unroll
+        for (int tile = 0; tile < MAXT; ++tile)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kr = tile * 16 + 4 * g + r;
+            if (kr < p.alpha_rows) ap[kr * 16] = lg[tile][r] * inv;
+          }
+      }
+    }
 
     if constexpr (POS) {
       // dx = mean_h sum_rows alpha * gate * v * (x_dst - x_src)   (uni_denoiser.py:200-209)

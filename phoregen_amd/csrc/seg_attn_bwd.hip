@@ -442,6 +442,14 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           if (row < n_rows) aD[r] = arow[row * 16 + m];
         }
         if (row_m < n_rows) aK = *reinterpret_cast<const f4*>(arow + row_m * 16 + 4 * g);
+        if constexpr (T::KNN) {            // the knn forward stores alpha x gate
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float wr = L.sR[32 + 4 * g + r];
+            aD[r] = wr > 0.f ? aD[r] / wr : 0.f;
+          }
+          aK = w_m > 0.f ? aK * (1.0f / w_m) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -925,9 +933,13 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
   }
   hipStream_t st = (hipStream_t)stream;
   switch (p->mode) {
-    case PG_SEG_KNN_NODE: return launch_bwd<PG_SEG_KNN_NODE, 4>(t, p, gr, st);
+    case PG_SEG_KNN_NODE:
+      return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_KNN_NODE, 4, true>(t, p, gr, st)
+                                             : launch_bwd<PG_SEG_KNN_NODE, 4>(t, p, gr, st);
     case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
-    case PG_SEG_BOND_NODE: return launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
+    case PG_SEG_BOND_NODE:
+      return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_BOND_NODE, 4, true>(t, p, gr, st)
+                                             : launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);
     case PG_SEG_BOND_POS: return launch_bwd<PG_SEG_BOND_POS, 4>(t, p, gr, st);
     case PG_SEG_TRIPLET: {
       // the per-source-atom rows (max_nlig x 259 floats) share the LDS with the per-wave tiles: 4 waves up to 64 atoms,

@@ -212,10 +212,18 @@ class SegCoreFn(torch.autograd.Function):
             s.S, s.swn = out[0].data_ptr(), out[1].data_ptr()
         tf = cfg.get('tri_fwd')
         alpha = None
+        onepass = os.environ.get('PG_TRI_ONEPASS', '1') != '0' and not os.environ.get('PG_GENERIC_SEG')
+        if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_BOND_NODE) and onepass and \
+                (cfg['k'] <= 32 if cfg['mode'] == hip.SEG_KNN_NODE else cfg['max_rows'] <= 80):
+            # the two-pass node kernels run (csrc/node_attn.hip): they can hand alpha x gate to a one-pass adjoint
+            arows = (cfg['max_rows'] + 15) // 16 * 16
+            alpha = torch.empty(n_rows * arows * 16, dtype=torch.float32, device=dev)
+            s.alpha, s.alpha_rows = alpha.data_ptr(), arows
+            ctx.alpha_rows = arows
         if tf is not None:
             for k in ('q', 'W2k_l', 'W2v_l', 'b2v', 'Wg2_k', 'Wg2_v', 'G', 'seg_ids', 'seg_chunks'):
                 setattr(s, k, tf[k].data_ptr())
-            if cfg['max_rows'] <= 80 and os.environ.get('PG_TRI_ONEPASS', '1') != '0':   # the tuned kernel runs: it can hand the softmax weights to the adjoint
+            if cfg['max_rows'] <= 80 and onepass:   # the tuned kernel runs: it can hand the softmax weights to the adjoint
                 arows = (cfg['max_rows'] + 15) // 16 * 16
                 alpha = torch.empty(cfg['n_seg'] * arows * 16, dtype=torch.float32, device=dev)
                 s.alpha, s.alpha_rows = alpha.data_ptr(), arows
