@@ -118,11 +118,18 @@ def load_library(path=None):
     return lib
 
 
+_gpu_checked = False
+
+
 def lib():
-    """The library, for compute calls: additionally requires a visible GPU."""
+    """The library, for compute calls: additionally requires a visible GPU (checked once, then cached)."""
+    global _gpu_checked
+    if _gpu_checked:
+        return _lib
     l = load_library()
     if not torch.cuda.is_available():
         raise RuntimeError('phoregen_amd: no MI355X / ROCm device visible; the HIP path has no CPU fallback.')
+    _gpu_checked = True
     return l
 
 

@@ -319,9 +319,20 @@ def shifted_softplus(x):
     return F.softplus(x) - 0.6931471805599453
 
 
+_smear_off_cache = {}
+
+
 def gaussian_smearing(d):
-    off = torch.tensor(_SMEAR_OFF, dtype=torch.float32, device=d.device)
+    off = _smear_off_cache.get(d.device)
+    if off is None:
+        off = _smear_off_cache[d.device] = torch.tensor(_SMEAR_OFF, dtype=torch.float32, device=d.device)
     return torch.exp(-0.5 * (d.unsqueeze(-1) - off) ** 2)
+
+
+def rows(x, idx):
+    """x[idx] for a (possibly multi-dimensional) long index: index_select, whose backward is an atomic index_add (advanced
+    indexing would go through a sort-based index_put: dozens of small kernels per call)."""
+    return x.index_select(0, idx.reshape(-1)).view(*idx.shape, *x.shape[1:])
 
 
 class TrainForward:
@@ -392,8 +403,9 @@ class TrainForward:
             c = torch.bincount(idx, minlength=B).clamp(min=1).unsqueeze(-1).to(v.dtype)
             return torch.zeros(B, v.shape[1], dtype=v.dtype, device=v.device).index_add(0, idx, v) / c
         c_all = seg_mean(head('atom_mlp', hp_emb), batch_phore)
-        m = h_phore[:, self.ex_col] != 1
-        c_l = seg_mean(head('atom_mlp_1', hp_emb[m]), batch_phore[m])
+        m = (h_phore[:, self.ex_col] != 1).to(hp_emb.dtype).unsqueeze(-1)        # non-EX nodes (diffusion.py:152-155)
+        cnt = torch.zeros(B, 1, dtype=hp_emb.dtype, device=hp_emb.device).index_add(0, batch_phore, m).clamp(min=1)
+        c_l = torch.zeros(B, 1, dtype=hp_emb.dtype, device=hp_emb.device).index_add(0, batch_phore, head('atom_mlp_1', hp_emb) * m) / cnt
         return c_l, c_l + F.relu(c_all - c_l)
 
     def time_smearing(self, t):
@@ -422,7 +434,7 @@ class TrainForward:
         hip.check(lib.pg_knn_ctx(p.topo_ref, x0.data_ptr(), self.k, nbr.data_ptr(), deg.data_ptr(), _st()), 'pg_knn_ctx')
         slot_ok = torch.arange(self.k, device=dev).view(1, -1) < deg.view(-1, 1)
         nbr_safe = torch.where(slot_ok, nbr.long(), torch.arange(n, device=dev).view(-1, 1).expand(-1, self.k))
-        dist = (x.unsqueeze(1) - x[nbr_safe]).pow(2).sum(-1).clamp(min=1e-24).sqrt()
+        dist = (x.unsqueeze(1) - rows(x, nbr_safe)).pow(2).sum(-1).clamp(min=1e-24).sqrt()
         gp = 'denoiser.edge_pred_layer.net.'
         ew = torch.sigmoid(mlp(gaussian_smearing(dist.reshape(-1)), sd[gp + '0.weight'], sd[gp + '0.bias'], sd[gp + '1.weight'],
                                sd[gp + '1.bias'], sd[gp + '3.weight'], sd[gp + '3.bias'])).view(n, self.k)
@@ -438,10 +450,10 @@ class TrainForward:
             xc = x.detach().contiguous()
             hip.check(lib.pg_lig_nn3(p.topo_ref, xc.data_ptr(), nn3.data_ptr(), _st()), 'pg_lig_nn3')
             ok = (nn3 >= 0).to(x.dtype).unsqueeze(-1)
-            nsum = (x[nn3.clamp(min=0).long()] * ok).sum(1)
-            l_norm = nsum / ok.sum(1).clamp(min=1.0) - x[p.lig2ctx_long]
+            nsum = (rows(x, nn3.clamp(min=0).long()) * ok).sum(1)
+            l_norm = nsum / ok.sum(1).clamp(min=1.0) - x.index_select(0, p.lig2ctx_long)
             nrm = nrm_ph.index_copy(0, p.lig2ctx_long, l_norm)
-            G = gaussian_smearing((x[bsrc] - x[bdst]).pow(2).sum(-1).clamp(min=1e-24).sqrt())        # [E,20]
+            G = gaussian_smearing((x.index_select(0, bsrc) - x.index_select(0, bdst)).pow(2).sum(-1).clamp(min=1e-24).sqrt())   # [E,20]
 
             # first-layer blocks of the three feature sub-layers (15 x 128 columns of W_node1), one GEMM per consumer
             if os.environ.get('PG_WIDE_GEMM') == '1':      # A/B knob: one wide GEMM + column views (padded slice gradients)
