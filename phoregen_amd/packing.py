@@ -21,15 +21,27 @@ def _lane():
     return lane >> 4, lane & 15
 
 
+_index_cache = {}
+
+
+def _cached(key, device, build):
+    """Constant gather indices of the lane-fixed layouts, built once per device (the training path packs every step)."""
+    k = (key, str(device))
+    if k not in _index_cache:
+        _index_cache[k] = tuple(t.to(device) for t in build())
+    return _index_cache[k]
+
+
 def lane_fixed_w2(W2):
     """[128 (8h+d), 128 (c)] -> [64][64 lanes][4]: element n=i*4+j -> tau=n>>5, r=(n>>3)&3, d=n&7;
     lane=(g,h) holds W2[8h+d][16 tau + 4g + r]."""
-    g, h = _lane()
-    n = torch.arange(256)
-    tau, r, d = n >> 5, (n >> 3) & 3, n & 7
-    rows = 8 * h[None, :] + d[:, None]
-    cols = 16 * tau[:, None] + 4 * g[None, :] + r[:, None]
-    out = W2[rows.to(W2.device), cols.to(W2.device)]                # [256, 64]
+    def build():
+        g, h = _lane()
+        n = torch.arange(256)
+        tau, r, d = n >> 5, (n >> 3) & 3, n & 7
+        return 8 * h[None, :] + d[:, None], 16 * tau[:, None] + 4 * g[None, :] + r[:, None]
+    rows, cols = _cached('w2', W2.device, build)
+    out = W2[rows, cols]                                              # [256, 64]
     return out.view(64, 4, 64).permute(0, 2, 1).contiguous()
 
 
@@ -38,20 +50,25 @@ def lane_fixed_feat(Wfeat):
     F = Wfeat.shape[1]
     assert F % 4 == 0
     steps = F // 4
-    g, m = _lane()
-    c = (16 * torch.arange(8)[:, None] + m[None, :])[None].expand(steps, -1, -1)
-    f = (4 * torch.arange(steps)[:, None, None] + g[None, None, :]).expand(-1, 8, -1)
-    return Wfeat[c.to(Wfeat.device), f.to(Wfeat.device)].contiguous()
+
+    def build():
+        g, m = _lane()
+        c = (16 * torch.arange(8)[:, None] + m[None, :])[None].expand(steps, -1, -1)
+        f = (4 * torch.arange(steps)[:, None, None] + g[None, None, :]).expand(-1, 8, -1)
+        return c.contiguous(), f.contiguous()
+    c, f = _cached(('feat', steps), Wfeat.device, build)
+    return Wfeat[c, f].contiguous()
 
 
 def lane_fixed_xv(W2xv):
     """[16 (h), 128 (c)] -> [32 (tau*4+r)][64]: lane=(g,h) holds W2xv[h][16 tau + 4g + r]."""
-    g, h = _lane()
-    i = torch.arange(32)
-    tau, r = i >> 2, i & 3
-    cols = 16 * tau[:, None] + 4 * g[None, :] + r[:, None]
-    rows = h[None, :].expand(32, -1)
-    return W2xv[rows.to(W2xv.device), cols.to(W2xv.device)].contiguous()
+    def build():
+        g, h = _lane()
+        i = torch.arange(32)
+        tau, r = i >> 2, i & 3
+        return h[None, :].expand(32, -1).contiguous(), 16 * tau[:, None] + 4 * g[None, :] + r[:, None]
+    rows, cols = _cached('xv', W2xv.device, build)
+    return W2xv[rows, cols].contiguous()
 
 
 def _mlp(sd, p):
