@@ -25,6 +25,32 @@ from ..plan import BatchPlan, make_edge_data
 from ..utils.sample_utils import sample_from_interval
 
 
+class _LazyFloats(dict):
+    """dict of 0-dim device tensors that reads as a dict of python floats (each value is converted on first access)."""
+
+    def _conv(self, k):
+        v = dict.__getitem__(self, k)
+        if torch.is_tensor(v):
+            v = v.item()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def __getitem__(self, k):
+        return self._conv(k)
+
+    def get(self, k, default=None):
+        return self._conv(k) if k in self else default
+
+    def items(self):
+        return [(k, self._conv(k)) for k in self.keys()]
+
+    def values(self):
+        return [self._conv(k) for k in self.keys()]
+
+    def __repr__(self):
+        return repr(dict(self.items()))
+
+
 class PhoreDiff(nn.Module):
     def __init__(self, config, data_name, **kwargs):
         super().__init__()
@@ -198,10 +224,12 @@ class PhoreDiff(nn.Module):
         def acc(true_cls, logits, batch):                                                      # common.py:284-297
             bad = torch.zeros(B, device=dev).index_add(0, batch, (logits.argmax(-1) != true_cls).float())
             present = torch.zeros(B, device=dev).index_add(0, batch, torch.ones_like(batch, dtype=torch.float32)) > 0
-            return float(((bad == 0) & present).sum()) / max(int(present.sum()), 1)
-        info = {'loss': loss.item(), 'loss_pos': loss_pos.item(), 'loss_node': loss_node.item(),
-                'loss_count': loss_count.item(), 'loss_edge': loss_edge.item(),
-                'node_acc': acc(x_cls, pred_node.detach(), bn), 'edge_acc': acc(e_cls, pred_edge.detach(), be)}
+            return ((bad == 0) & present).sum().float() / present.sum().clamp(min=1).float()
+        # the reference returns python floats (`.item()` right here = a host sync between forward and backward);
+        # same values, converted when first read, so `loss.backward()` can be enqueued while the forward still runs
+        info = _LazyFloats({'loss': loss.detach(), 'loss_pos': loss_pos.detach(), 'loss_node': loss_node.detach(),
+                            'loss_count': loss_count.detach(), 'loss_edge': loss_edge.detach(),
+                            'node_acc': acc(x_cls, pred_node.detach(), bn), 'edge_acc': acc(e_cls, pred_edge.detach(), be)})
         return loss, info
 
     def compute_count_loss(self, true_norm, pred_count, a=0.05, s=160, nd=15, epsilon=1e-12):
