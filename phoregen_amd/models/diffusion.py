@@ -25,6 +25,21 @@ from ..plan import BatchPlan, make_edge_data
 from ..utils.sample_utils import sample_from_interval
 
 
+def _on_model_device(fn):
+    """Run `fn` with the model's GPU as the current device: the C-ABI launches go to torch's current stream of that device,
+    and HIP launches use the calling thread's current device (a model on cuda:1 must not be driven from device 0)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        dev = self._device()
+        if dev.type != 'cuda':
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class _LazyFloats(dict):
     """dict of 0-dim device tensors that reads as a dict of python floats (each value is converted on first access)."""
 
@@ -136,6 +151,7 @@ class PhoreDiff(nn.Module):
         return self._engine
 
     # ------------------------------------------------------------------ forward (diffusion.py:175-246)
+    @_on_model_device
     def forward(self, h_node_pert, pos_pert, batch_node, h_edge_pert, edge_index, batch_edge, time_step,
                 h_phore, pos_phore, phore_norm, batch_phore):
         self.packed()
@@ -154,6 +170,7 @@ class PhoreDiff(nn.Module):
         ts = torch.cat([ts, self.num_timesteps - ts - 1], dim=0)[:num_graphs]
         return ts, torch.ones_like(ts).float() / self.num_timesteps
 
+    @_on_model_device
     def compute_loss(self, data, draws=None):
         """Reference contract: (loss with grad, dict of floats).  The denoiser forward and its adjoint run in the HIP
         kernels (phoregen_amd/training.py); the noising, the posteriors and the loss terms are elementwise tensor ops
@@ -243,6 +260,7 @@ class PhoreDiff(nn.Module):
 
     # ------------------------------------------------------------------ atom-count sampling (diffusion.py:355-387)
     @torch.no_grad()
+    @_on_model_device
     def sample_nodes(self, data, batch_size, device, sample_mode='uniform', normal_scale=4.0):
         ph = data['phore']
         p = ph.x.size(0)
@@ -296,6 +314,7 @@ class PhoreDiff(nn.Module):
 
     # ---- sampler pieces (also used teacher-forced by the parity tests) ----
     @torch.no_grad()
+    @_on_model_device
     def begin_sampling(self, h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, rng='device', seed=0,
                        return_traj=True, num_steps=None, guidance_center=None):
         dev = self._device()
@@ -354,6 +373,7 @@ class PhoreDiff(nn.Module):
         return st
 
     @torch.no_grad()
+    @_on_model_device
     def reverse_step(self, st, i, step, pos_guidance_opt=None, draws=None):
         """One iteration of the loop at diffusion.py:432-517 on the state held in the engine workspace.
         `draws` = (u_node [N,12], u_edge [E,6], eps [N,3]) overrides the noise source (teacher-forced tests)."""
@@ -401,6 +421,7 @@ class PhoreDiff(nn.Module):
             w.in_pos.data_ptr(), tp(st.pos_traj), s), 'posterior(pos)')          # in place: x_t -> x_{t-1}
         st.cur = 1 - cur
 
+    @_on_model_device
     def finish_sampling(self, st):
         w, plan = st.eng.ws, st.plan
         return {'pred': [w.out_v.clone(), st.x0 + st.center_rows, w.out_bond.clone()],
