@@ -594,7 +594,8 @@ extern "C" int pg_attn_fold_query(const float* q, int ldq, const float* W2k_l, i
   if (n == 0) return PG_OK;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(fold_query_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_query_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) { set_error("pg_attn_fold_query: cannot reserve 64 KB of LDS: %s", hipGetErrorString(e)); return PG_ERR_HIP; }
     attr_set = true;
   }
   int blocks = (n + 3) / 4;
@@ -608,7 +609,8 @@ extern "C" int pg_attn_unfold_value(const float* S, const float* swn, const floa
   if (n == 0) return PG_OK;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(unfold_value_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(unfold_value_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) { set_error("pg_attn_unfold_value: cannot reserve 64 KB of LDS: %s", hipGetErrorString(e)); return PG_ERR_HIP; }
     attr_set = true;
   }
   int blocks = (n + 3) / 4;
@@ -618,7 +620,8 @@ extern "C" int pg_attn_unfold_value(const float* S, const float* swn, const floa
 }
 
 extern "C" int pg_selftest_mfma(int* d_result, void* stream) {
-  hipMemsetAsync(d_result, 0, sizeof(int), (hipStream_t)stream);
+  hipError_t e = hipMemsetAsync(d_result, 0, sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("pg_selftest_mfma: %s", hipGetErrorString(e)); return PG_ERR_HIP; }
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_result);
   return check_launch("pg_selftest_mfma");
 }
