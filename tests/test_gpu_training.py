@@ -239,3 +239,14 @@ def test_gradients_with_a_maximum_size_ligand(model):
         r = orc.sd[k].grad.double()
         err = float((params[k].grad.cpu().double() - r).norm() / r.norm())
         assert err < GRAD_TOL, (k, err)
+
+
+def test_validation_pass_without_grad(model):
+    """run/run.py evaluates with compute_loss under torch.no_grad(): same loss as the training-mode call, nothing retained."""
+    g = golden('g6_loss_a')
+    with torch.no_grad():
+        loss_ng, info_ng = model.compute_loss(_batch(g), draws=_draws(g))
+    loss, info = model.compute_loss(_batch(g), draws=_draws(g))
+    assert not loss_ng.requires_grad and loss.requires_grad
+    assert abs(loss_ng.item() - loss.item()) <= 1e-6 * abs(loss.item())
+    assert info_ng['loss_edge'] == pytest.approx(info['loss_edge'], rel=1e-6)
