@@ -80,6 +80,51 @@ def linear(X, W, b=None):
     return LinearFn.apply(X, W, b)
 
 
+class LinearGatherAddFn(torch.autograd.Function):
+    """Y[r] = X[r] W^T + A1[i1[r]] (+ A2[i2[r]]): the per-edge half of a factored first layer plus the gathered per-node
+    halves, in pg_gemm's epilogue (no materialised gathers)."""
+
+    @staticmethod
+    def forward(ctx, X, W, A1, i1, A2, i2):
+        X, W, A1 = _rowmajor(X), _rowmajor(W), _rowmajor(A1)
+        A2 = _rowmajor(A2) if A2 is not None else None
+        M, K = X.shape
+        Y = torch.empty(M, W.shape[0], dtype=torch.float32, device=X.device)
+        g = hip.PgGemm()
+        g.X, g.ldx, g.K1 = X.data_ptr(), X.stride(0), K
+        g.W, g.ldw = W.data_ptr(), W.stride(0)
+        g.add1, g.ld_add1, g.idx1 = A1.data_ptr(), A1.stride(0), i1.data_ptr()
+        if A2 is not None:
+            g.add2, g.ld_add2, g.idx2 = A2.data_ptr(), A2.stride(0), i2.data_ptr()
+        g.out_scale, g.act = 1.0, hip.ACT_NONE
+        g.Y, g.ldy, g.M, g.N = Y.data_ptr(), Y.stride(0), M, W.shape[0]
+        if M:
+            hip.check(hip.lib().pg_gemm(C.byref(g), _st()), 'pg_gemm')
+        ctx.save_for_backward(X, W, i1, i2 if i2 is not None else i1)
+        ctx.shapes = (A1.shape, None if A2 is None else A2.shape)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        X, W, i1, i2 = ctx.saved_tensors
+        gY = _rowmajor(gY)
+        N, K = W.shape
+        gX = torch.empty_like(X)
+        if X.shape[0]:
+            _gemm_raw(gY, W.t().contiguous(), gX)
+        gW = torch.zeros_like(W)
+        hip.check(hip.lib().pg_gemm_wgrad(gY.data_ptr(), gY.stride(0), X.data_ptr(), X.stride(0), X.shape[0], N, K,
+                                          gW.data_ptr(), gW.stride(0), None, _st()), 'pg_gemm_wgrad')
+        s1, s2 = ctx.shapes
+        gA1 = torch.zeros(s1, dtype=torch.float32, device=gY.device).index_add_(0, i1.long(), gY)
+        gA2 = None if s2 is None else torch.zeros(s2, dtype=torch.float32, device=gY.device).index_add_(0, i2.long(), gY)
+        return gX, gW, gA1, None, gA2, None
+
+
+def linear_gather_add(X, W, A1, i1, A2=None, i2=None):
+    return LinearGatherAddFn.apply(X, W, A1, i1, A2, i2)
+
+
 class LnReluFn(torch.autograd.Function):
     """ReLU(LayerNorm_128(X) * gamma + beta)  (middle of models/common.py:99-119 MLP)."""
 
@@ -462,15 +507,15 @@ class TrainForward:
             else:
                 Y1 = lambda c0, c1: linear(h, L.W_node1[c0:c1], L.b_node1[c0:c1])
             aggE = self._attention(hip.SEG_KNN_NODE, L.NE, Y1, x, both, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
-            CsB = linear(hb, L.NB.W_hb) + Y1(7 * 128, 9 * 128).index_select(0, bsrc)
+            CsB = linear_gather_add(hb, L.NB.W_hb, Y1(7 * 128, 9 * 128), p.bond_src)
             aggB = self._attention(hip.SEG_BOND_NODE, L.NB, lambda c0, c1: Y1(640 + c0, 640 + c1), x, lig, Ysrc=CsB,
                                    max_rows=max_lig)
             # bond update over triplets (uni_denoiser.py:101-165)
             a = L.TB
-            P = (linear(torch.cat([hb, G], -1), a.W_hbg) + Y1(10 * 128, 12 * 128).index_select(0, bsrc)
-                 + Y1(12 * 128, 14 * 128).index_select(0, bdst))
+            P = linear_gather_add(torch.cat([hb, G], -1), a.W_hbg, Y1(10 * 128, 12 * 128), p.bond_src,
+                                  Y1(12 * 128, 14 * 128), p.bond_dst)
             Q = linear(G, torch.cat([a.Wg2_k.t(), a.Wg2_v.t()], 0))                    # smear(d_ji) columns, per segment
-            qhid = linear(hb, a.W_q_hb) + Y1(14 * 128, 15 * 128).index_select(0, bdst)
+            qhid = linear_gather_add(hb, a.W_q_hb, Y1(14 * 128, 15 * 128), p.bond_dst)
             qT = linear(LnReluFn.apply(qhid, a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
             U = FoldFn.apply(qT, a.W2k_l, None, E)
             cfg = dict(mode=hip.SEG_TRIPLET, n_seg=E, seg_ids=None, k=self.k, topo=p.topo_ref, n_out_rows=E,
@@ -488,7 +533,7 @@ class TrainForward:
             else:
                 Y2 = lambda c0, c1: linear(h_new, L.W_node2[c0:c1], L.b_node2[c0:c1])
             dxe = self._attention(hip.SEG_KNN_POS, L.PE, Y2, x, lig, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
-            CsB2 = linear(hb_new, L.PB.W_hb) + Y2(7 * 128, 9 * 128).index_select(0, bsrc)
+            CsB2 = linear_gather_add(hb_new, L.PB.W_hb, Y2(7 * 128, 9 * 128), p.bond_src)
             dxb = self._attention(hip.SEG_BOND_POS, L.PB, lambda c0, c1: Y2(640 + c0, 640 + c1), x, lig, Ysrc=CsB2,
                                   max_rows=max_lig)
             x = x + (dxe + dxb) * is_lig.to(x.dtype)
