@@ -217,3 +217,43 @@ def test_loss_dict_reads_as_python_floats():
     assert sorted(d.values()) == [0.25, 1.5, 3.0]
     assert 'loss' in repr(d) and 'tensor' not in repr(d)
     assert '%.3f' % d['loss'] == '1.500'
+
+
+def test_plan_and_partition_properties_random_sizes():
+    """Property checks over random batches (hypothesis): edge-id table, source-ordered triplet visiting order, chunk cover,
+    make_edge_data equals the oracle's reference-order construction, partition completeness."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import phoregen_oracle as po
+    from phoregen_amd.parallel import partition_graphs
+    from phoregen_amd.plan import make_edge_data
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=23), min_size=1, max_size=6),
+           st.lists(st.integers(min_value=1, max_value=9), min_size=6, max_size=6), st.integers(min_value=1, max_value=5))
+    def check(n_atoms, n_ph, world):
+        na = torch.tensor(n_atoms)
+        ei, be = make_edge_data(na)
+        ei_ref, be_ref = po.make_edge_data(na)
+        assert torch.equal(ei, ei_ref) and torch.equal(be, be_ref)
+        B = na.numel()
+        bn = torch.repeat_interleave(torch.arange(B), na)
+        bp = torch.repeat_interleave(torch.arange(B), torch.tensor(n_ph[:B]))
+        plan = BatchPlan(bn, bp, ei, be, B, 'cpu')
+        E = ei.size(1)
+        off = torch.zeros(B + 1, dtype=torch.long)
+        off[1:] = na.cumsum(0)
+        eo = plan.g_eid_off.long()
+        for e in range(0, E, max(1, E // 50)):          # eid[src, dst] is the edge id
+            g = int(be[e])
+            n = int(na[g])
+            ls, ld = int(ei[0, e] - off[g]), int(ei[1, e] - off[g])
+            assert int(plan.eid[eo[g] + ls * n + ld]) == e
+        order = plan.tri_order.long()
+        assert sorted(order.tolist()) == list(range(E))
+        src_sorted = ei[0][order]
+        assert bool((src_sorted[1:] >= src_sorted[:-1]).all()) if E > 1 else True
+        ch = plan.tri_chunks.long()
+        assert int(ch[0]) == 0 and int(ch[-1]) == E and bool((ch[1:] >= ch[:-1]).all())
+        parts = partition_graphs(na, world)
+        assert sorted(torch.cat(parts).tolist()) == list(range(B))
+    check()
