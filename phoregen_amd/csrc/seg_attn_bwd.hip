@@ -413,6 +413,29 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     for (int tile = 0; tile < ((ab & 64) ? 0 : n_tiles); ++tile) {
       const int row_m = tile * 16 + m;
       const RowInfo rk = row_info<MODE>(t, p, s, row_m);
+      // every global load of the tile is requested up front (the feature arithmetic runs while they are in flight)
+      f4 aD_raw = {0.f, 0.f, 0.f, 0.f}, aK_raw = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (OP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = tile * 16 + 4 * g + r;
+          if (row < n_rows) aD_raw[r] = arow[row * 16 + m];
+        }
+        if (row_m < n_rows) aK_raw = *reinterpret_cast<const f4*>(arow + row_m * 16 + 4 * g);
+      }
+      // the Csrc rows of BOTH paths are requested here: with one wave per SIMD each dependent round trip is exposed
+      // (not in the knn forms: they are out of registers as it is)
+      constexpr bool PRE = !T::KNN;
+      f4 pre[2][PRE ? 8 : 1];
+      if constexpr (PRE) {
+        const float* pk = p.Csrc_k + (size_t)rk.csrc * p.ld_csrc + 4 * g;
+        const float* pv = p.Csrc_v + (size_t)rk.csrc * p.ld_csrc + 4 * g;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) {
+          pre[0][tq] = rk.valid ? *reinterpret_cast<const f4*>(pk + 16 * tq) : (f4){0.f, 0.f, 0.f, 0.f};
+          pre[1][tq] = rk.valid ? *reinterpret_cast<const f4*>(pv + 16 * tq) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
       float feat[NS];
       RowGeo<MODE> geo;
       row_features<MODE, NS>(t, p, rk, xd, nd, xj, g, feat, geo);
@@ -436,12 +459,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       // row-buffer values of this tile in one batch of loads: rows 4g + r at head m, and row m at heads 4g .. 4g+3
       f4 aD = {0.f, 0.f, 0.f, 0.f}, glD = {0.f, 0.f, 0.f, 0.f}, aK = {0.f, 0.f, 0.f, 0.f}, glK = {0.f, 0.f, 0.f, 0.f};
       if constexpr (OP) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = tile * 16 + 4 * g + r;
-          if (row < n_rows) aD[r] = arow[row * 16 + m];
-        }
-        if (row_m < n_rows) aK = *reinterpret_cast<const f4*>(arow + row_m * 16 + 4 * g);
+        aD = aD_raw;
+        aK = aK_raw;
         if constexpr (T::KNN) {            // the knn forward stores alpha x gate
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -469,7 +488,17 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         const float* wf = kp ? L.wf_k : L.wf_v;
         f4 hid[8];
         float rs, sg;
-        hidden_tile(kp ? p.Csrc_k : p.Csrc_v, kp ? cdk : cdv, wf, rk, feat, hid);
+        if constexpr (!PRE) {
+          hidden_tile(kp ? p.Csrc_k : p.Csrc_v, kp ? cdk : cdv, wf, rk, feat, hid);
+        } else {
+          const float* cd = kp ? cdk : cdv;
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) hid[tq] = pre[kp ? 0 : 1][tq] + *reinterpret_cast<const f4*>(cd + 16 * tq);
+#pragma unroll
+          for (int st = 0; st < NSTEP; ++st)
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf[(st * 8 + tq) * 64 + lane], feat[st], hid[tq]);
+        }
         ln_stats(hid, rs, sg);
         PROF(3);   // tile head: features, row buffer loads
         const f4 y = kp ? relu_project(hid, bp, sg, Ur) : relu_project(hid, bp, sg, Mr);   // unscaled, rows 4g+r, head m
