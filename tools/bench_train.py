@@ -45,7 +45,7 @@ def main():
     import torch.distributed as dist
     from phoregen_amd.parallel import allreduce_gradients
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)    # (a 2-rank dry run can share one GPU)
     if world > 1:       # data parallel: one process per GPU, each its own 256-pair batch, one flat gradient bucket over RCCL
         torch.cuda.set_device(local)
         dist.init_process_group(os.environ.get('PG_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
