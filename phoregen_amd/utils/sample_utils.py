@@ -59,3 +59,37 @@ def decode_data(pred_info, edge_index, include_bond=True, num_bond_types=5):
         ok = (bond_index >= 0).all(dim=0)
         out['bond_type'], out['bond_index'] = edge_type[is_bond][ok], bond_index[:, ok]
     return out
+
+
+def decode_batch(results, include_bond=True, num_bond_types=5):
+    """`[decode_data(unbatch_data(results)[g]) for g in graphs]` (sample_all.py:104-116) in one pass: argmax of all atom /
+    bond logits on the device the results live on, ONE device->host copy of the compact arrays (types as int8, final
+    coordinates, local edge ids), per-graph split by offsets on the host.  The logits and the trajectory stay where they are."""
+    import numpy as np
+    pred = results['pred']
+    num_atoms, edge_index = results['lig_info'][0], results['lig_info'][2]
+    na = np.asarray(num_atoms.tolist(), dtype=np.int64)
+    at = pred[0].argmax(-1).to(torch.int8)
+    et = pred[2].argmax(-1).to(torch.int8) if include_bond else None
+    at_h, pos_h = at.cpu().numpy(), pred[1].detach().cpu().numpy()
+    et_h = et.cpu().numpy() if include_bond else None
+    ei_h = edge_index.cpu().numpy() if include_bond else None
+    out, n0, e0 = [], 0, 0
+    for n in na.tolist():
+        e = n * (n - 1)
+        a = at_h[n0:n0 + n]
+        keep = a < len(ATOM_TYPES)
+        d = {'element': [ATOM_TYPES[i] for i in a[keep].tolist()], 'atom_pos': torch.from_numpy(pos_h[n0:n0 + n][keep]),
+             'bond_type': None, 'bond_index': None}
+        if include_bond:
+            remap = np.full(n, -1, dtype=np.int64)
+            remap[keep] = np.arange(int(keep.sum()))
+            t = et_h[e0:e0 + e]
+            is_bond = (t > 0) & (t < num_bond_types)
+            bi = remap[ei_h[:, e0:e0 + e][:, is_bond] - n0]
+            ok = (bi >= 0).all(axis=0)
+            d['bond_type'] = torch.from_numpy(t[is_bond][ok].astype(np.int64))
+            d['bond_index'] = torch.from_numpy(bi[:, ok])
+        out.append(d)
+        n0, e0 = n0 + n, e0 + e
+    return out

@@ -185,6 +185,13 @@ def test_unbatch_and_decode_match_reference():
         assert np.array_equal(d['atom_pos'].numpy(), g[f'g{gi}_atom_pos'])
         assert np.array_equal(d['bond_type'].numpy(), g[f'g{gi}_bond_type'])
         assert np.array_equal(d['bond_index'].numpy(), g[f'g{gi}_bond_index'])
+    # the one-pass batch decode gives the same molecules as the reference's per-graph unbatch + decode
+    from phoregen_amd.utils.sample_utils import decode_batch
+    for gi, d in enumerate(decode_batch(res)):
+        assert d['element'] == g[f'g{gi}_element'].tolist()
+        assert np.array_equal(d['atom_pos'].numpy(), g[f'g{gi}_atom_pos'])
+        assert np.array_equal(d['bond_type'].numpy(), g[f'g{gi}_bond_type'])
+        assert np.array_equal(d['bond_index'].numpy(), g[f'g{gi}_bond_index'])
 
 
 def test_ema_matches_reference_formula():
