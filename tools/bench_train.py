@@ -9,11 +9,11 @@ import torch
 from bench import ligphore_workload
 
 
-def train_workload(n_graphs=256, seed=4321):
+def train_workload(n_graphs=256, seed=4321, n_mean=25.0, n_std=5.0, n_max=60):
     from phoregen_amd.data import TrainBatch
     g = torch.Generator().manual_seed(seed)
     w = ligphore_workload(n_graphs, seed)
-    na = (25 + 5 * torch.randn(n_graphs, generator=g)).round().clamp(8, 60).long()
+    na = (n_mean + n_std * torch.randn(n_graphs, generator=g)).round().clamp(8, n_max).long()
     off = torch.cat([torch.zeros(1, dtype=torch.long), na.cumsum(0)])
     N = int(na.sum())
     srcs, dsts, attrs, eb = [], [], [], []
@@ -38,6 +38,8 @@ def main():
     ap.add_argument('--graphs', type=int, default=256)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--n-mean', type=float, default=25.0, help='mean ligand size (config 5: 25; the sampler headline shape: 40)')
+    ap.add_argument('--n-max', type=int, default=60)
     a = ap.parse_args()
     from phoregen_amd.config import default_model_config
     from phoregen_amd.models.diffusion import PhoreDiff
@@ -51,7 +53,7 @@ def main():
         dist.init_process_group(os.environ.get('PG_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
     dev = f'cuda:{local}'
     model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).to(dev)
-    batch, na = train_workload(a.graphs, seed=4321 + rank)
+    batch, na = train_workload(a.graphs, seed=4321 + rank, n_mean=a.n_mean, n_std=a.n_mean / 5.0, n_max=a.n_max)
     batch.to(dev)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
     torch.manual_seed(0)
@@ -80,9 +82,9 @@ def main():
         if rank != 0:
             return
     e_bond = int((na * (na - 1)).sum()); e3 = int((na * (na - 1) * (na - 2)).sum())
-    print(json.dumps({'metric': 'train step (compute_loss forward + backward + Adam), batch=256', 'value': ms, 'unit': 'ms/step',
+    print(json.dumps({'metric': 'train step (compute_loss forward + backward + Adam), batch=%d' % a.graphs, 'value': ms, 'unit': 'ms/step',
                       'higher_is_better': False, 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'dtype': 'f32',
-                      'data': 'synthetic', 'config': {'workload': 'BASELINE.json configs[4]: 256 synthetic ligand-phore pairs, n~N(25,5)',
+                      'data': 'synthetic', 'config': {'workload': 'BASELINE.json configs[4] shape: %d synthetic ligand-phore pairs, n~N(%g,%g) clamp [8,%d]' % (a.graphs, a.n_mean, a.n_mean / 5.0, a.n_max),
                                                       'graphs': a.graphs, 'n_lig': int(na.sum()), 'e_bond': e_bond, 'e3': e3},
                       'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30, 'last_loss': info['loss']}))
 
