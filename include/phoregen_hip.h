@@ -30,6 +30,12 @@ int pg_abi_version(void);
 
 /* ---- MFMA lane-map self test (device writes 0 on success) -------------------------------- */
 int pg_selftest_mfma(int* d_result, void* stream);
+/* ---- raw words of the device generator (Philox4x32-10, Salmon et al. SC'11) for known-answer tests:
+ * ctr_key [n][6] = counter c0..c3, key k0 k1  ->  out [n][4].  The transition kernels call it with
+ * key = seed (lo, hi), counter = (element index lo, hi, step, stream_id). */
+int pg_selftest_philox(const uint32_t* ctr_key, int n, uint32_t* out, void* stream);
+/* test hook: route the node-target modes of pg_seg_attn through the generic one-pass kernel (returns the old setting) */
+int pg_debug_force_generic_seg(int on);
 
 /* ---- dense linear layers -------------------------------------------------------------------
  * Y[R, n] = out_scale * act( sum_k Xcat[R,k] * W[n,k] + bias[n] + add1[i1(r), n] + add2[i2(r), n] ),  R = rows ? rows[r] : r
@@ -58,6 +64,7 @@ int pg_gemm(const PgGemm* p, void* stream);
 typedef struct {
   int n_graphs, n_ctx, n_lig, n_phore, n_bond;
   int max_nlig;             /* largest ligand of the batch (selects the triplet kernel variant)           */
+  int max_gctx;             /* most context nodes (ligand + pharmacophore) of any graph; pg_knn_ctx holds <= 512 */
   const int* g_ctx_off;     /* [B+1] first ctx node of graph g                                   */
   const int* g_nph;         /* [B]   pharmacophore nodes of graph g (ctx rows g_ctx_off[g]..+nph) */
   const int* g_nlig;        /* [B]   ligand atoms of graph g (follow the phore nodes)             */

@@ -93,10 +93,10 @@ def g1_ops():
 # --------------------------------------------------------------------------------------------
 # shared: model + synthetic / real pharmacophores
 # --------------------------------------------------------------------------------------------
-def build_model(seed=0):
+def build_model(seed=0, profile='default'):
     cfg = ref_import.load_reference_config('train_lig-phore.yml')
     m = PhoreDiff(cfg.model, cfg.dataset.data_name)
-    init_deterministic_(m, seed)
+    init_deterministic_(m, seed, profile=profile)
     m.eval()
     return m, cfg
 
@@ -381,7 +381,22 @@ def g9_unbatch_decode():
     save('g9_unbatch_decode', **arr)
 
 
+def profile_fixtures(profile):
+    """Adversarial weight sets (phoregen_amd/weights.py PROFILES): the reference itself run with negative / tiny / zero
+    LayerNorm gammas and with trained-like scales -- forward + layer captures, a 3-step sampler head and one loss/gradient
+    fixture per profile (small graphs: the fixtures stay < 0.5 MB each)."""
+    model, _ = build_model(seed=0, profile=profile)
+    g23_forward(model, f'g3_forward_a_{profile}', seed=101, n_atoms=[5, 9], n_phore=[6, 11], t_values=[700, 30])
+    g5_sample(model, f'g5_sample_head3_{profile}', seed=2032, n_atoms=[6, 9], n_steps=3, t_total=1000)
+    g5_sample(model, f'g5_sample_tail4_{profile}', seed=2033, n_atoms=[7, 5, 8], n_steps=4, t_total=4)
+    g6_compute_loss(model, f'g6_loss_a_{profile}', seed=61, n_atoms=[6, 9], n_phore=[7, 12])
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'profiles':
+        for prof in ('gamma_signed', 'trained_like'):
+            profile_fixtures(prof)
+        sys.exit(0)
     g1_ops()
     g8_phore_parse()
     g9_unbatch_decode()
@@ -398,3 +413,5 @@ if __name__ == '__main__':
     g6_compute_loss(model, 'g6_loss_b', seed=64, n_atoms=[11, 4, 8], n_phore=[23, 9, 15])
     g5_sample(model, 'g5_sample_guid3', seed=2035, n_atoms=[6, 7], n_steps=3, t_total=3,
               guidance=[{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}])
+    for prof in ('gamma_signed', 'trained_like'):
+        profile_fixtures(prof)

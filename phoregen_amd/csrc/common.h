@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #define PG_OK 0
 #define PG_ERR_ARG 1
@@ -11,6 +12,21 @@
 namespace pg {
 
 void set_error(const char* fmt, ...);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remembers (kernel, device) pairs, so a
+// second model on cuda:1 in the same process gets its own reservation (defined in graph_ops.hip)
+int reserve_lds(const void* kernel, size_t bytes, const char* what);
+
+// timing-only ablation switches exist only in -DPG_ABLATE builds (tools/); the product kernels carry none
+#ifdef PG_ABLATE
+#define PG_ABL(bit) ((pg_ablate_mask & (bit)) != 0)
+#define PG_ABL_PARAM , int pg_ablate_mask
+#define PG_ABL_ARG(env) , pg::ablate_from_env(env)
+#else
+#define PG_ABL(bit) (false)
+#define PG_ABL_PARAM
+#define PG_ABL_ARG(env)
+#endif
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
@@ -51,5 +67,12 @@ __device__ __forceinline__ float smear(float d, int i) {
 }
 
 constexpr int kNumCU = 256;
+
+#ifdef PG_ABLATE
+inline int ablate_from_env(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+#endif
 
 }  // namespace pg

@@ -16,7 +16,7 @@ __device__ __forceinline__ float ssp(float v) {  // softplus(v) - ln 2, torch th
   return sp - 0.69314718055994530942f;
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
+__global__ __launch_bounds__(256) void gemm_kernel(PgGemm p PG_ABL_PARAM) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];   // staging tiles; reused by the epilogue
   float* const As = smem;
   float* const Bs = smem + BM * LDT;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
       const int grow = row0 + r;
       const int prow = (p.rows && grow < p.M) ? p.rows[grow] : grow;
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (grow < p.M && !(ablate & 1)) {
+      if (grow < p.M && !PG_ABL(1)) {
         if (fastX && kk + 3 < p.K1) {
           const float4 t = *reinterpret_cast<const float4*>(p.X + (size_t)prow * p.ldx + kk);
           v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
 
       const int gcol = col0 + r;
       float w[4] = {0.f, 0.f, 0.f, 0.f};
-      if (gcol < p.N && !(ablate & 1)) {
+      if (gcol < p.N && !PG_ABL(1)) {
         if (fastW && kk + 3 < K) {
           const float4 t = *reinterpret_cast<const float4*>(p.W + (size_t)gcol * p.ldw + kk);
           w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
     // ---- 16 k-steps of 2 ----
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll 4
-    for (int ks = 0; ks < ((ablate & 2) ? 1 : BK / 2); ++ks) {
+    for (int ks = 0; ks < (PG_ABL(2) ? 1 : BK / 2); ++ks) {
       const int k = ks * 2 + kh;
       const float a0 = As[(wr + l31) * LDT + k], a1 = As[(wr + 32 + l31) * LDT + k];
       const float b0 = Bs[(wc + l31) * LDT + k], b1 = Bs[(wc + 32 + l31) * LDT + k];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p, int ablate) {
       const int piece = it * 256 + tid;
       const int r = piece >> 5, c4 = (piece & 31) * 4;
       const int grow = row0 + half * 64 + r, gcol = col0 + c4;
-      if (grow >= p.M || gcol >= p.N || ((ablate & 4) && r != 0)) continue;
+      if (grow >= p.M || gcol >= p.N || (PG_ABL(4) && r != 0)) continue;
       f4 v = *reinterpret_cast<const f4*>(Cs + r * LDC + c4);
       const int prow = p.rows ? p.rows[grow] : grow;
       const int a1 = p.add1 ? (p.idx1 ? p.idx1[grow] : prow) : 0;
@@ -336,13 +336,7 @@ template <int KP>
 static int launch_ws(const PgGemm* p, hipStream_t st) {
   constexpr int ABUF = WS_BM * (KP > WS_LDC ? KP : WS_LDC);
   const size_t lds = (128 * KP + 2 * ABUF) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<KP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("pg_gemm(ws): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = true;
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_ws_kernel<KP>), lds, "pg_gemm(ws)")) return rc;
   const int n_tiles = (p->M + WS_BM - 1) / WS_BM, n_col = (p->N + BN - 1) / BN;
   int row_groups = kNumCU / n_col;
   if (row_groups < 1) row_groups = 1;
@@ -384,14 +378,12 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   const bool al = (p->ldx & 3) == 0 && ((size_t)p->X & 15) == 0 && (p->ldw & 3) == 0 && ((size_t)p->W & 15) == 0 &&
                   (p->K1 & 3) == 0 && (p->K2 & 3) == 0 && (!p->K2 || ((p->ldx2 & 3) == 0 && ((size_t)p->X2 & 15) == 0));
   // (measured, tools/bench_gemm.py: a clear win for the LayerNorm-on-load form, a wash or slightly worse otherwise)
-  if (p->M >= 32768 && al && p->N <= 256 && p->ln_gamma && !p->rows && !getenv("PG_GEMM_TILED")) {
+  if (p->M >= 32768 && al && p->N <= 256 && p->ln_gamma && !p->rows) {
     if (K == 128) return pg::launch_ws<129>(p, (hipStream_t)stream);
     if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
   }
   dim3 grid((p->M + pg::BM - 1) / pg::BM, (p->N + pg::BN - 1) / pg::BN);
-  static int ablate = -1;
-  if (ablate < 0) { const char* e = getenv("PG_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }   // timing-only knob
-  hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p, ablate);
+  hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p PG_ABL_ARG("PG_GEMM_ABLATE"));
   return pg::check_launch("pg_gemm");
 }
 

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "common.h"
 #include "../../include/phoregen_hip.h"
 
@@ -14,6 +16,32 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+int reserve_lds(const void* kernel, size_t bytes, const char* what) {
+  struct Ent { const void* fn; int dev; size_t bytes; };
+  static Ent tab[256];
+  static int n_ent = 0;
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("%s: hipGetDevice failed", what); return PG_ERR_HIP; }
+  std::lock_guard<std::mutex> lock(mu);
+  Ent* e = nullptr;
+  for (int i = 0; i < n_ent; ++i)
+    if (tab[i].fn == kernel && tab[i].dev == dev) { e = &tab[i]; break; }
+  if (e && e->bytes >= bytes) return PG_OK;
+  hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (rc != hipSuccess) {
+    set_error("%s: cannot reserve %zu B of LDS on device %d: %s", what, bytes, dev, hipGetErrorString(rc));
+    return PG_ERR_HIP;
+  }
+  if (!e) {
+    if (n_ent == 256) return PG_OK;          // table full: the attribute is set, it is just not remembered
+    e = &tab[n_ent++];
+    e->fn = kernel; e->dev = dev;
+  }
+  e->bytes = bytes;
+  return PG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,7 +302,7 @@ __global__ void atom_count_kernel(const float* s_all, const float* s_l, const ui
 using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
-extern "C" int pg_abi_version(void) { return 1; }
+extern "C" int pg_abi_version(void) { return 2; }
 
 extern "C" int pg_embed_ctx(const PgTopo* t, const float* h_node_pert, const float* pos_pert, const int64_t* time_step,
                             const float* W_node, const float* t_off, const float* t_coeff, const float* h_phore_emb,
@@ -295,14 +323,26 @@ extern "C" int pg_embed_bond(const PgTopo* t, const float* h_edge_pert, const in
   return check_launch("pg_embed_bond");
 }
 
+// wave_knn holds KNN_MAXC candidates per lane: a graph with more context nodes would silently lose its far candidates
+static int check_graph_size(const PgTopo* t, const char* what) {
+  if (t->max_gctx > 64 * KNN_MAXC) {
+    set_error("%s: a graph of this batch has %d context nodes (ligand + pharmacophore); the in-graph kNN holds at most %d",
+              what, t->max_gctx, 64 * KNN_MAXC);
+    return PG_ERR_ARG;
+  }
+  return PG_OK;
+}
+
 extern "C" int pg_knn_ctx(const PgTopo* t, const float* x_ctx, int k, int* nbr, int* deg, void* stream) {
-  if (k < 1 || k > 64) { set_error("pg_knn_ctx: k out of range"); return PG_ERR_ARG; }
+  if (k < 1 || k > 64) { set_error("pg_knn_ctx: k = %d out of range [1, 64]", k); return PG_ERR_ARG; }
+  if (int rc = check_graph_size(t, "pg_knn_ctx")) return rc;
   hipLaunchKernelGGL(knn_ctx_kernel, dim3((t->n_ctx + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, k, nbr, deg);
   return check_launch("pg_knn_ctx");
 }
 
 extern "C" int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* phore_norm, const int* phore2ctx,
                               float* nrm, void* stream) {
+  if (t->max_nlig > 64 * KNN_MAXC) { set_error("pg_lig_normals: ligand of %d atoms (limit %d)", t->max_nlig, 64 * KNN_MAXC); return PG_ERR_ARG; }
   const int n = t->n_lig + t->n_phore;
   hipLaunchKernelGGL(lig_normals_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, phore_norm,
                      phore2ctx, nrm);
@@ -311,6 +351,7 @@ extern "C" int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* 
 
 extern "C" int pg_lig_nn3(const PgTopo* t, const float* x_ctx, int* nn3, void* stream) {
   if (t->n_lig == 0) return PG_OK;
+  if (t->max_nlig > 64 * KNN_MAXC) { set_error("pg_lig_nn3: ligand of %d atoms (limit %d)", t->max_nlig, 64 * KNN_MAXC); return PG_ERR_ARG; }
   hipLaunchKernelGGL(lig_nn3_kernel, dim3((t->n_lig + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, nn3);
   return check_launch("pg_lig_nn3");
 }

@@ -357,13 +357,7 @@ template <bool KNN, bool POS, int MAXT, int THREADS>
 static int launch_na(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   constexpr int NSTEP = KNN ? 12 : 0;
   const size_t lds = (256 + 2 * NSTEP * 512 + (POS ? 2048 + 16 : 0)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("node_attn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = true;
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS>), lds, "node_attn")) return rc;
   const int per = THREADS / 64;
   int blocks = (p->n_seg + per - 1) / per;
   if (KNN && blocks > 3 * kNumCU) blocks = 3 * kNumCU;     // LDS-heavy: persistent-ish, the weights are loaded per block

@@ -21,6 +21,16 @@ struct Philox {
   __device__ float uniform(int i) const { return (float)(c[i] >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 };
 
+// raw generator words for known-answer tests: in [n][6] = counter c0..c3, key k0 k1 -> out [n][4]
+__global__ void philox_selftest_kernel(const uint32_t* in, int n, uint32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* v = in + (size_t)i * 6;
+  Philox ph((uint64_t)v[4] | ((uint64_t)v[5] << 32), (uint64_t)v[0] | ((uint64_t)v[1] << 32), v[2], v[3]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[(size_t)i * 4 + k] = ph.c[k];
+}
+
 template <int K>
 __global__ void posterior_cat_kernel(const float* logits, const float* log_vt_in, const int* row_graph,
                                      const int64_t* time_step, const float* q_mats, const float* q_onestep_T, int n_rows,
@@ -175,6 +185,12 @@ __global__ void guidance_grad_kernel(PgTopo t, const float* x_lig, const float* 
 }  // namespace pg
 
 using namespace pg;
+
+extern "C" int pg_selftest_philox(const uint32_t* ctr_key, int n, uint32_t* out, void* stream) {
+  if (n <= 0) return PG_OK;
+  hipLaunchKernelGGL(pg::philox_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctr_key, n, out);
+  return pg::check_launch("pg_selftest_philox");
+}
 
 extern "C" int pg_posterior_categorical(const float* logits, const float* log_vt_in, const int* row_graph,
                                         const int64_t* time_step, const float* q_mats, const float* q_onestep_T,

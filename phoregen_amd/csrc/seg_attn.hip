@@ -542,13 +542,7 @@ static int launch_seg(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   using T = ModeTraits<MODE>;
   const int threads = 256;
   const size_t lds = lds_floats<MODE>(threads / 64) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seg_attn_kernel<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("pg_seg_attn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = true;
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(seg_attn_kernel<MODE>), lds, "pg_seg_attn")) return rc;
   int blocks;
   if (T::TRI) blocks = kNumCU;
   else {
@@ -566,11 +560,18 @@ static int launch_seg(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
 
 using namespace pg;
 
+static int g_force_generic = 0;
+extern "C" int pg_debug_force_generic_seg(int on) {
+  const int old = g_force_generic;
+  g_force_generic = on;
+  return old;
+}
+
 extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
   if (!t || !p) { set_error("pg_seg_attn: null argument"); return PG_ERR_ARG; }
   if (p->n_seg == 0) return PG_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (p->mode <= PG_SEG_BOND_POS && !getenv("PG_GENERIC_SEG")) {   // two-pass kernels; env knob keeps the one-pass kernel testable
+  if (p->mode <= PG_SEG_BOND_POS && !g_force_generic) {   // two-pass kernels; pg_debug_force_generic_seg keeps the one-pass kernel testable
     const int rc = launch_node_attn(t, p, st);
     if (rc >= 0) return rc;
   }
@@ -592,12 +593,7 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
 
 extern "C" int pg_attn_fold_query(const float* q, int ldq, const float* W2k_l, int n, const int* ids, float* U, void* stream) {
   if (n == 0) return PG_OK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fold_query_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    if (e != hipSuccess) { set_error("pg_attn_fold_query: cannot reserve 64 KB of LDS: %s", hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = true;
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(fold_query_kernel), 65536, "pg_attn_fold_query")) return rc;
   int blocks = (n + 3) / 4;
   if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
   hipLaunchKernelGGL(fold_query_kernel, dim3(blocks), dim3(256), 65536, (hipStream_t)stream, q, ldq, W2k_l, n, ids, U);
@@ -607,12 +603,7 @@ extern "C" int pg_attn_fold_query(const float* q, int ldq, const float* W2k_l, i
 extern "C" int pg_attn_unfold_value(const float* S, const float* swn, const float* W2v_l, const float* b2v, int n,
                                     const int* ids, float* out, int ldo, void* stream) {
   if (n == 0) return PG_OK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(unfold_value_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    if (e != hipSuccess) { set_error("pg_attn_unfold_value: cannot reserve 64 KB of LDS: %s", hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = true;
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(unfold_value_kernel), 65536, "pg_attn_unfold_value")) return rc;
   int blocks = (n + 3) / 4;
   if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
   hipLaunchKernelGGL(unfold_value_kernel, dim3(blocks), dim3(256), 65536, (hipStream_t)stream, S, swn, W2v_l, b2v, n, ids, out, ldo);

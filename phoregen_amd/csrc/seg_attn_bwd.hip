@@ -157,7 +157,7 @@ struct BwdLds {
 }  // namespace
 
 template <int MODE, int NW, bool OP = false>   // OP: one pass, alpha / S of the forward given (triplet training form)
-__global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAttn p, PgSegAttnGrad gr, int ab) {
+__global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAttn p, PgSegAttnGrad gr PG_ABL_PARAM) {
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
   constexpr int FS = 16 * NF + 1;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     PROF_T0();
     PROF(0);   // segment setup
     // =============================== pass 1: logits and tv of every row ===============================
-    for (int tile = 0; tile < ((OP || (ab & 32)) ? 0 : n_tiles); ++tile) {
+    for (int tile = 0; tile < ((OP || PG_ABL(32)) ? 0 : n_tiles); ++tile) {
       const RowInfo rk = row_info<MODE>(t, p, s, tile * 16 + m);
       float feat[NS];
       RowGeo<MODE> geo;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     PROF(1);   // pass 1
 
     // =============================== softmax backward per head m (rows r = g, g+4, ...) ===============================
-    if (!OP && !(ab & 16)) {
+    if (!OP && !PG_ABL(16)) {
       float mx = NEG_BIG;
       for (int r = g; r < n_rows; r += 4) mx = fmaxf(mx, rb[r * ROWBUF + m]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     float gcd_k0 = 0.f, gcd_k1 = 0.f, gcd_v0 = 0.f, gcd_v1 = 0.f;
     float gxs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // d x_j, d x_i (triplet) / d x_dst, d nrm_dst (knn, pos) summed over the segment's rows: one atomic each
 
-    for (int tile = 0; tile < ((ab & 64) ? 0 : n_tiles); ++tile) {
+    for (int tile = 0; tile < (PG_ABL(64) ? 0 : n_tiles); ++tile) {
       const int row_m = tile * 16 + m;
       const RowInfo rk = row_info<MODE>(t, p, s, row_m);
       // every global load of the tile is requested up front (the feature arithmetic runs while they are in flight)
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       }
 
 #pragma unroll
-      for (int path = 0; path < ((ab & 8) ? 1 : 2); ++path) {
+      for (int path = 0; path < (PG_ABL(8) ? 1 : 2); ++path) {
         const bool kp = OP ? path == 1 : path == 0;
         const float* bp = kp ? L.bk : L.bv;
         const float* wf = kp ? L.wf_k : L.wf_v;
@@ -650,9 +650,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           }
         wave_lds_sync();
         PROF(8);   // LN adjoint, db', dhidden tile
-        if (NSTEP > 0 && !(ab & 4)) {
+        if (NSTEP > 0 && !PG_ABL(4)) {
           // d feat[row, f] += sum_c dhidden[c,row] * Wf[c,f]
-          if (!T::PH && !(ab & 256)) {
+          if (!T::PH && !PG_ABL(256)) {
             f4 gfp[NF][4];                         // independent chains per r, folded below
 #pragma unroll
             for (int ft = 0; ft < NF; ++ft)
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           }
           // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]
           // registers for the whole kernel (LDS ds_add_f32 accumulation measured ~700 cycles per instruction)
-          if (!(ab & 512))
+          if (!PG_ABL(512))
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {           // k-step outermost: consecutive MFMAs hit different accumulators
             float bf[NF];
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         }
         PROF(9);   // dfeat, dWf
         // d Csrc (scatter) and d Cdst (row sum): lane owns channels lane and lane + 64
-        if (!(ab & 2)) {
+        if (!PG_ABL(2)) {
           float* gsrc = kp ? gr.gCsrc_k : gr.gCsrc_v;
           float a0 = 0.f, a1 = 0.f;
           if constexpr (T::TRI) {
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           for (int r = 0; r < 4; ++r) L.sGF[(4 * g + r) * FS + 16 * ft + m] = gfeat[ft][r];
         wave_lds_sync();
       }
-      if (g == 0 && rk.valid && gr.gx && !(ab & 1)) {
+      if (g == 0 && rk.valid && gr.gx && !PG_ABL(1)) {
         const float* gf = L.sGF + m * FS;
         float grel[3] = {0.f, 0.f, 0.f};
         if constexpr (T::KNN) {
@@ -859,9 +859,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           s.ci = lig0 + il; s.cj = cj;
           s.eid_g = eid_g;
           process(s);
-        } else if (!(ab & 2)) {       // idle wave of this round: same barrier sequence, zero contribution
-          for (int tile = 0; tile < ((ab & 64) ? 0 : n_tiles_j); ++tile)
-            for (int path = 0; path < ((ab & 8) ? 1 : 2); ++path) {
+        } else if (!PG_ABL(2)) {       // idle wave of this round: same barrier sequence, zero contribution
+          for (int tile = 0; tile < (PG_ABL(64) ? 0 : n_tiles_j); ++tile)
+            for (int path = 0; path < (PG_ABL(8) ? 1 : 2); ++path) {
               for (int i = lane; i < 128 * 17; i += 64) L.sT[i] = 0.f;
               tri_merge(tile, OP ? path == 1 : path == 0);
             }
@@ -923,19 +923,11 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   const size_t lds = ((size_t)2 * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 259 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
                       (size_t)NW * PW) * sizeof(float);
   if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
-  static size_t attr_set = 0;
-  if (attr_set < lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW, OP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("pg_seg_attn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = lds;
-  }
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW, OP>), lds, "pg_seg_attn_bwd")) return rc;
   int blocks = T::TRI ? t->n_lig : (p->n_seg + NW - 1) / NW;
   if (blocks > gr->grid) blocks = gr->grid;
   if (blocks < 1) blocks = 1;
-  static int ablate = -1;
-  if (ablate < 0) { const char* e = getenv("PG_BWD_ABLATE"); ablate = e ? atoi(e) : 0; }   // timing experiments only
-  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW, OP>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr, ablate);
+  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW, OP>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr PG_ABL_ARG("PG_BWD_ABLATE"));
   return check_launch("pg_seg_attn_bwd");
 }
 

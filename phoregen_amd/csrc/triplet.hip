@@ -1,11 +1,10 @@
 // Bond-triplet attention (BondUpdateLayer, models/uni_denoiser.py:101-165) — the dominant kernel of a step.
 //
 // Occupancy-first restructuring of seg_attn.hip's TRIPLET mode:
-//   * 1024-thread persistent workgroups (16 waves, 4 per SIMD) share one LDS copy of the lane-fixed second-layer
-//     weights (2 x 64 KB), so MFMA phases of one wave overlap VALU / memory phases of its three SIMD partners;
+//   * 768-thread persistent workgroups (12 waves, 3 per SIMD, <= 168 VGPRs) share one LDS copy of the lane-fixed
+//     second-layer weights (2 x 64 KB), so MFMA phases of one wave overlap VALU / memory phases of its SIMD partners;
 //   * two passes over the row tiles of a segment (K path -> logits for all rows -> exact softmax -> V path),
-//     so the folded-key operand U (32 regs) and the value accumulator S^T (32 regs) are never live together
-//     and the kernel fits the 128-VGPR budget of 4 waves/SIMD;
+//     so the folded-key operand U (32 regs) and the value accumulator S^T (32 regs) are never live together;
 //   * the per-segment constant Q = Wg2 . smear(d_ji) lives in a per-wave LDS scratch and is read at use;
 //   * sin/cos of the angular code by a 2-constant Cody-Waite reduction + degree-9/8 polynomials (arguments are
 //     bounded by 3*pi), row sums inside a 16-lane row by DPP adds instead of LDS-crossbar shuffles;
@@ -58,7 +57,7 @@ __device__ __constant__ const float kTriFreq[12] = {0.f, 1.f, 2.f, 3.f, 0.5f, (f
                                                      (float)(1.0 / 3.0), 0.f};
 
 template <int TRI_THREADS, int TRI_MAX_TILES>
-__global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAttn p, int ablate) {
+__global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAttn p PG_ABL_PARAM) {
   constexpr int TRI_WAVES = TRI_THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const ln = lds;                      // gk bk gv bv
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
       float qk0 = 0.f, qk1 = 0.f, qv0 = 0.f, qv1 = 0.f;
       const float* Gs = p.G + (size_t)seg * 20;
 #pragma unroll 5
-      for (int i = 0; i < ((ablate & 16) ? 0 : 20); ++i) {
+      for (int i = 0; i < (PG_ABL(16) ? 0 : 20); ++i) {
         const float gv_ = Gs[i];
         qk0 = fmaf(p.Wg2_k[i * 128 + lane], gv_, qk0);
         qk1 = fmaf(p.Wg2_k[i * 128 + 64 + lane], gv_, qk1);
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     // =============================== pass A: logits of every row ===============================
     {
       f4 U[8];
-      if (ablate & 2) {
+      if PG_ABL(2) {
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq) U[tq] = (f4){0.01f * lane, 0.02f, 0.03f, 0.04f};
       } else {
@@ -163,13 +162,13 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
       for (int tile = 0; tile < TRI_MAX_TILES; ++tile) {
         lg[tile] = (f4){TRI_NEG, TRI_NEG, TRI_NEG, TRI_NEG};
         feat[tile][0] = feat[tile][1] = feat[tile][2] = 0.f;
-        if (tile < n_tiles && !(ablate & 64)) {
+        if (tile < n_tiles && !PG_ABL(64)) {
           const int k = tile * 16 + m;
           const bool valid = k < n && k != li && k != lj;
           const int e_kj = valid ? eid_g[k * n + lj] : 0;
           // angular features of row k for f = 4 step + g  (uni_denoiser.py:131-135, common.py:85)
           float theta = 0.f;
-          if (valid && !(ablate & 8)) {
+          if (valid && !PG_ABL(8)) {
             const int ck = lig0 + k;
             const float v0 = p.x[ck * 3] - xi0, v1 = p.x[ck * 3 + 1] - xi1, v2 = p.x[ck * 3 + 2] - xi2;
             const float a = u0 * v0 + u1 * v1 + u2 * v2;
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
 #pragma unroll
           for (int st = 0; st < 3; ++st) {
             const int f = 4 * st + g;
-            float v = (ablate & 8) ? 0.5f : sincos_sel(theta * kTriFreq[f], f >= 6);
+            float v = PG_ABL(8) ? 0.5f : sincos_sel(theta * kTriFreq[f], f >= 6);
             v = f == 0 ? theta : v;
             feat[tile][st] = f == 11 ? 1.0f : (valid ? v : 0.f);   // f = 11 carries the per-segment constant Q
           }
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) {
             f4 c = {0.f, 0.f, 0.f, 0.f};
-            if (valid && !(ablate & 1)) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+            if (valid && !PG_ABL(1)) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
             hid[tq] = c;
           }
 #pragma unroll
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     for (int tq = 0; tq < 8; ++tq) sT[tq] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tile = 0; tile < TRI_MAX_TILES; ++tile) {
-      if (tile < n_tiles && !(ablate & 32)) {
+      if (tile < n_tiles && !PG_ABL(32)) {
         f4 hv[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
           const int e_kj = valid ? eid_g[kr * n + lj] : 0;
           const float* pv = p.Csrc_v + (size_t)e_kj * p.ld_csrc + m;
 #pragma unroll
-          for (int tq = 0; tq < 8; ++tq) hv[tq][r] = (valid && !(ablate & 1)) ? pv[16 * tq] : 0.f;
+          for (int tq = 0; tq < 8; ++tq) hv[tq][r] = (valid && !PG_ABL(1)) ? pv[16 * tq] : 0.f;
         }
 #pragma unroll
         for (int st = 0; st < 3; ++st)
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
     }
     // =============================== epilogue: out = resid + W2v_h . S[:,h] / l + b2v ===============================
     float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (ablate & 4) {
+    if PG_ABL(4) {
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq) part[tq] = sT[tq][0] + sT[tq][1] + sT[tq][2] + sT[tq][3];
     } else
@@ -364,45 +363,21 @@ __global__ __launch_bounds__(TRI_THREADS) void triplet_kernel(PgTopo t, PgSegAtt
   }
 }
 
-static int g_ablate = 0;   // PG_TRI_ABLATE bit mask: timing-only ablations (results are wrong when non-zero)
-
 template <int THREADS, int MAXT>
 static int launch_tri(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   const size_t lds = (512 + 2 * 1536 + 2 * 16384 + 128 + (THREADS / 64) * 256) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(triplet_kernel<THREADS, MAXT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { set_error("triplet: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); return PG_ERR_HIP; }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((triplet_kernel<THREADS, MAXT>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p, g_ablate);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(triplet_kernel<THREADS, MAXT>), lds, "triplet")) return rc;
+  hipLaunchKernelGGL((triplet_kernel<THREADS, MAXT>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p PG_ABL_ARG("PG_TRI_ABLATE"));
   return check_launch("pg_seg_attn(triplet)");
 }
 
 // row tiles held in registers: 3 (ligands <= 48 atoms), 4 (<= 64), 5 (<= 80)
 int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
-  static int threads = 0;
-  if (!threads) {
-    const char* e = getenv("PG_TRI_THREADS");      // tuning knob: 512 / 768 / 1024 threads = 2 / 3 / 4 waves per SIMD (256 / 168 / 128 VGPRs)
-    threads = e ? atoi(e) : 768;
-    const char* a = getenv("PG_TRI_ABLATE");
-    g_ablate = a ? atoi(a) : 0;
-  }
+  // 768 threads = 3 waves per SIMD at <= 168 VGPRs (measured best of 512 / 768 / 1024)
   const int tiles = (t->max_nlig + 15) / 16;
-  if (threads == 768) {
-    if (tiles <= 3) return launch_tri<768, 3>(t, p, st);
-    if (tiles == 4) return launch_tri<768, 4>(t, p, st);
-    return launch_tri<768, 5>(t, p, st);
-  }
-  if (threads == 512) {
-    if (tiles <= 3) return launch_tri<512, 3>(t, p, st);
-    if (tiles == 4) return launch_tri<512, 4>(t, p, st);
-    return launch_tri<512, 5>(t, p, st);
-  }
-  if (tiles <= 3) return launch_tri<1024, 3>(t, p, st);
-  if (tiles == 4) return launch_tri<1024, 4>(t, p, st);
-  return launch_tri<1024, 5>(t, p, st);
+  if (tiles <= 3) return launch_tri<768, 3>(t, p, st);
+  if (tiles == 4) return launch_tri<768, 4>(t, p, st);
+  return launch_tri<768, 5>(t, p, st);
 }
 
 }  // namespace pg

@@ -28,7 +28,7 @@ class PgGemm(C.Structure):
 
 class PgTopo(C.Structure):
     _fields_ = [('n_graphs', C.c_int), ('n_ctx', C.c_int), ('n_lig', C.c_int), ('n_phore', C.c_int),
-                ('n_bond', C.c_int), ('max_nlig', C.c_int),
+                ('n_bond', C.c_int), ('max_nlig', C.c_int), ('max_gctx', C.c_int),
                 ('g_ctx_off', c_ip), ('g_nph', c_ip), ('g_nlig', c_ip), ('g_eid_off', c_ip), ('eid', c_ip),
                 ('ctx_graph', c_ip), ('ctx_is_lig', c_ip), ('lig2ctx', c_ip), ('bond_src', c_ip),
                 ('bond_dst', c_ip), ('bond_desc', c_ip)]
@@ -66,6 +66,8 @@ _PROTOS = {
     'pg_last_error': (C.c_char_p, []),
     'pg_abi_version': (C.c_int, []),
     'pg_selftest_mfma': (C.c_int, [c_ip, C.c_void_p]),
+    'pg_selftest_philox': (C.c_int, [c_ip, C.c_int, c_ip, C.c_void_p]),
+    'pg_debug_force_generic_seg': (C.c_int, [C.c_int]),
     'pg_gemm': (C.c_int, [C.POINTER(PgGemm), C.c_void_p]),
     'pg_embed_ctx': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 11 + [C.c_void_p]),
     'pg_embed_bond': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 7 + [C.c_void_p]),

@@ -73,6 +73,9 @@ class PhoreDiff(nn.Module):
         self.num_node_types = config.num_atom_classes
         self.num_edge_types = config.num_bond_classes
         self.bond_len_loss = config.bond_len_loss
+        if self.bond_len_loss:
+            raise NotImplementedError('phoregen_amd: bond_len_loss=True (the loss_len term of diffusion.py:286-290,333,341) is '
+                                      'not implemented; both shipped YAMLs set it to False')
         self.bond_diffusion = config.bond_diffusion
         self.bond_net_type = config.bond_net_type
         self.count_pred_type = config.count_pred_type
@@ -143,6 +146,22 @@ class PhoreDiff(nn.Module):
             self._pack_version = ver
             self._engine = None
         return self._pack
+
+    def invalidate_pack(self):
+        """Drop the kernel-layout weight cache.  `packed()` notices optimizer steps and `.to()` through the parameters'
+        version counters; writes through `param.data` (EMA swaps, weight surgery) do not bump them -- call this after such
+        a write.  `load_state_dict` and `_apply` (`.to`, `.cuda`, `.float`) call it themselves."""
+        self._pack = self._pack_version = self._engine = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_pack()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_pack()
+        return out
 
     def engine_for(self, plan):
         pack = self.packed()
@@ -281,13 +300,16 @@ class PhoreDiff(nn.Module):
         'traj': [node, pos, edge], 'lig_info': [num_atoms, batch, edge_index, edge_batch]}.
 
         rng='device': (default, like the reference on a GPU) counter-based Philox inside the transition kernels, no host
-                      traffic in the loop; `seed` defaults to torch.initial_seed(), so `seed_all(seed)` still controls it.
+                      traffic in the loop; `seed` = the Philox key, by default a fresh draw from torch's default generator
+                      per call (so consecutive calls differ and `seed_all(seed)` still controls the whole run).
         rng='cpu'   : noise is drawn from torch's default CPU generator in the reference's order, shape and dtype
                        and uploaded -> same seeds give the reference CPU path's draws.
         num_atoms   : optional LongTensor [n_graphs] overriding the atom-count draw (tests / benchmarks)."""
         ph = data['phore']
         if seed is None:
-            seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+            # a fresh key per call, drawn from torch's default generator: repeated sample() calls (sample_all.py's while loop)
+            # get different noise like the reference's global-RNG draws do, and `seed_all(seed)` still makes a run reproducible
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         if num_atoms is None:
             num_atoms = self.sample_nodes(data, n_graphs, device, sample_mode, normal_scale)
         p = ph.x.size(0)

@@ -14,6 +14,9 @@ import torch
 # queries are pre-scaled by 1/sqrt(head_dim) (np.sqrt(k.shape[-1]) = sqrt(8), uni_denoiser.py:62,158,204) and by
 # log2(e): the kernels' segment softmax runs in base 2 (one v_exp_f32 per weight), which is the same softmax
 HEAD_SCALE = math.log2(math.e) / math.sqrt(8.0)
+# LayerNorm channels with |gamma| below this are constant ReLU(beta) channels (see _kv_mlp): beta / 1e-25 is still far
+# inside the fp32 range for any |beta| < 1e12, and a channel that small contributes < 1e-25 * |x_hat| anyway
+DEAD_GAMMA = 1e-25
 
 
 def _lane():
@@ -85,14 +88,22 @@ def _kv_mlp(sd, p):
         |g| into the COLUMNS of the second Linear, and with sigma = 1/rstd
         ReLU(s*x_hat + b') = rstd * ReLU(s*x + b'*sigma), the per-row rstd is applied to the 16 logits /
         attention weights of the row instead of its 128 channels.
-    Returns W1', b1' (centred, sign-normalised), bp = b/|g|, W2' = W2 * |g| (columns), b2."""
+    Dead channels (gamma == 0, or |gamma| below DEAD_GAMMA where beta/|gamma| would leave the fp32 range): the channel's
+    activation is the constant ReLU(beta), so its column of the second Linear is zeroed and W2[:, c] * ReLU(beta_c)
+    moves into the second bias -- the exact reference result.  (The channel still takes part in the LayerNorm
+    statistics, which are computed before gamma.)  |gamma| = gamma * sign(gamma) keeps d|gamma|/dgamma = sign for training;
+    a dead channel gets no gradient through gamma (the kernels never see it).
+    Returns W1', b1' (centred, sign-normalised), bp = b/|g|, W2' = W2 * |g| (columns), b2' (b2 + dead-channel constants)."""
     m = _mlp(sd, p)
     W1c = m['W1'] - m['W1'].mean(0, keepdim=True)
     b1c = m['b1'] - m['b1'].mean()
     sgn = torch.where(m['g'] < 0, -torch.ones_like(m['g']), torch.ones_like(m['g']))
-    ag = m['g'].abs().clamp(min=1e-20)
-    return dict(W1=(sgn[:, None] * W1c).contiguous(), b1=(sgn * b1c).contiguous(), bp=(m['b'] / ag).contiguous(),
-                W2=(m['W2'] * ag[None, :]).contiguous(), b2=m['b2'])
+    dead = (m['g'].detach().abs() < DEAD_GAMMA)
+    ag = torch.where(dead, torch.ones_like(m['g']), m['g'] * sgn)
+    live = (~dead).to(m['g'].dtype)
+    b2 = m['b2'] + m['W2'] @ (torch.relu(m['b']) * (1.0 - live))
+    return dict(W1=(sgn[:, None] * W1c).contiguous(), b1=(sgn * b1c).contiguous(), bp=(m['b'] / ag * live).contiguous(),
+                W2=(m['W2'] * (ag * live)[None, :]).contiguous(), b2=b2)
 
 
 def _knn_feat(W1, W_dd, dst_is_lig):

@@ -73,6 +73,7 @@ class BatchPlan:
         t = hip.PgTopo()
         t.n_graphs, t.n_ctx, t.n_lig, t.n_phore, t.n_bond = B, self.n_ctx, self.n_lig, self.n_phore, self.n_bond
         t.max_nlig = int(nlig.max()) if B else 0
+        t.max_gctx = int(tot.max()) if B else 0
         # cost-balanced chunks of consecutive bond edges for the 256 persistent triplet workgroups:
         # cost(edge) ~ row tiles of its ligand + a fixed per-segment part (query fold / value unfold)
         # triplet segments are visited in source-atom order (edge j->i reads the rows P[k->j], shared by all i)

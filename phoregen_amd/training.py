@@ -257,7 +257,7 @@ class SegCoreFn(torch.autograd.Function):
             s.S, s.swn = out[0].data_ptr(), out[1].data_ptr()
         tf = cfg.get('tri_fwd')
         alpha = None
-        onepass = os.environ.get('PG_TRI_ONEPASS', '1') != '0' and not os.environ.get('PG_GENERIC_SEG')
+        onepass = os.environ.get('PG_TRI_ONEPASS', '1') != '0'
         if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_BOND_NODE) and onepass and \
                 (cfg['k'] <= 32 if cfg['mode'] == hip.SEG_KNN_NODE else cfg['max_rows'] <= 80):
             # the two-pass node kernels run (csrc/node_attn.hip): they can hand alpha x gate to a one-pass adjoint

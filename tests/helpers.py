@@ -38,7 +38,7 @@ def manifest():
     return out
 
 
-def oracle_state_dict(seed=0):
+def oracle_state_dict(seed=0, profile='default'):
     """state_dict built WITHOUT any model class: manifest shapes + weights.make_tensor + oracle tables."""
     from oracle import phoregen_oracle as po
     from phoregen_amd.weights import is_fixed, make_tensor
@@ -67,14 +67,14 @@ def oracle_state_dict(seed=0):
             sd[k] = -0.5 / torch.cat([d[:1], d]) ** 2
         else:
             assert not is_fixed(k), k
-            sd[k] = make_tensor(k, shape, seed)
+            sd[k] = make_tensor(k, shape, seed, profile=profile)
         assert tuple(sd[k].shape) == shape, (k, sd[k].shape, shape)
     return sd
 
 
-def make_oracle(seed=0):
+def make_oracle(seed=0, profile='default'):
     from oracle import phoregen_oracle as po
-    return po.Oracle(oracle_state_dict(seed), diff_cfg=DIFF_CFG)
+    return po.Oracle(oracle_state_dict(seed, profile), diff_cfg=DIFF_CFG)
 
 
 def t(a):

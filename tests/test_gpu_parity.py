@@ -32,6 +32,33 @@ def oracle():
     return make_oracle(0)
 
 
+PROFILES = ('gamma_signed', 'trained_like')      # adversarial weight sets, phoregen_amd/weights.py
+_CACHE = {}
+
+
+def _profile_of(name):
+    return next((p for p in PROFILES if name.endswith('_' + p)), 'default')
+
+
+def _model_for(name):
+    """HIP model with the weight profile the fixture `name` was recorded with (one model per profile per session)."""
+    from phoregen_amd.config import default_model_config
+    from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.weights import init_deterministic_
+    prof = _profile_of(name)
+    if ('m', prof) not in _CACHE:
+        _CACHE[('m', prof)] = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0, profile=prof).eval().to(DEV)
+    return _CACHE[('m', prof)]
+
+
+def _oracle_for(name):
+    prof = _profile_of(name)
+    if ('o', prof) not in _CACHE:
+        torch.set_num_threads(8)
+        _CACHE[('o', prof)] = make_oracle(0, prof)
+    return _CACHE[('o', prof)]
+
+
 def test_mfma_lane_maps():
     from phoregen_amd import hip
     lib = hip.lib()
@@ -81,9 +108,10 @@ def _fwd_inputs(g):
     return {k[3:]: t(g[k]) for k in g.files if k.startswith('in_')}
 
 
-@pytest.mark.parametrize('name', ['g3_forward_a', 'g3_forward_b'])
-def test_forward_against_reference_golden(model, name):
+@pytest.mark.parametrize('name', ['g3_forward_a', 'g3_forward_b', 'g3_forward_a_gamma_signed', 'g3_forward_a_trained_like'])
+def test_forward_against_reference_golden(name):
     g = golden(name)
+    model = _model_for(name)
     inp = {k: v.to(DEV) for k, v in _fwd_inputs(g).items()}
     with torch.no_grad():
         model(**inp)                                      # builds plan + engine
@@ -116,9 +144,12 @@ def test_forward_against_reference_golden(model, name):
     assert max(errs.values()) <= TOL, errs
 
 
-def test_forward_against_oracle_larger_graphs(model, oracle):
-    """Sizes the goldens do not cover: > 32 atoms (3+ row tiles), tiny graphs (degree < 32), n = 2 (empty triplet segments)."""
+@pytest.mark.parametrize('profile', ['default', 'gamma_signed', 'trained_like'])
+def test_forward_against_oracle_larger_graphs(profile):
+    """Sizes the goldens do not cover: > 32 atoms (3+ row tiles), tiny graphs (degree < 32), n = 2 (empty triplet segments),
+    under every weight profile (the oracle is pinned to the reference on each of them, tests/test_oracle_golden.py)."""
     from oracle.make_inputs import synthetic_batch
+    model, oracle = _model_for('x_' + profile), _oracle_for('x_' + profile)
     inp = synthetic_batch(7, [41, 2, 33, 17], [60, 9, 130, 25], [999, 0, 500, 250])
     with torch.no_grad():
         ref = oracle.forward(**inp)
@@ -145,7 +176,7 @@ def test_forward_row_tile_boundaries(model, oracle):
 
 def test_forward_max_size_ligand_and_generic_kernel_fallback(model, oracle):
     """78-atom ligand (the reference's max_atom: 5 row tiles in the triplet / bond kernels) next to a 4-atom one, and the
-    one-pass generic segment kernel (PG_GENERIC_SEG=1, the fallback for shapes the two-pass kernels do not hold)."""
+    one-pass generic segment kernel (pg_debug_force_generic_seg, the fallback for shapes the two-pass kernels do not hold)."""
     import os
     from oracle.make_inputs import synthetic_batch
     inp = synthetic_batch(11, [78, 4], [35, 23], [321, 77])
@@ -153,11 +184,12 @@ def test_forward_max_size_ligand_and_generic_kernel_fallback(model, oracle):
     with torch.no_grad():
         ref = oracle.forward(**inp)
         out = model(**dev_inp)
-        os.environ['PG_GENERIC_SEG'] = '1'
+        from phoregen_amd import hip
+        hip.lib().pg_debug_force_generic_seg(1)
         try:
             out_g = model(**dev_inp)
         finally:
-            del os.environ['PG_GENERIC_SEG']
+            hip.lib().pg_debug_force_generic_seg(0)
     for o in (out, out_g):
         errs = dict(v=rel_err(o[0].cpu(), ref[0]), x0=rel_err(o[1].cpu(), ref[1]), bond=rel_err(o[2].cpu(), ref[2]))
         assert max(errs.values()) <= TOL, errs
@@ -237,13 +269,14 @@ def _replay(model, g, name, closed_loop_steps=None):
     return res, recs, n_rec
 
 
-def test_sampler_closed_loop_matches_reference_trajectory(model):
+@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_head3_gamma_signed', 'g5_sample_head3_trained_like'])
+def test_sampler_closed_loop_matches_reference_trajectory(name):
     """Free-running sampler, same seeds (recorded CPU draws), t = 999..996: discrete types bit-exact, coordinates
     within tolerance.  (At small t a randomly initialised network amplifies a 1e-6 input perturbation several
     hundred-fold per step - measured on the oracle itself - so free-running comparisons are only meaningful
     where the dynamics are stable; every step of every fixture is covered teacher-forced below.)"""
-    g = golden('g5_sample_head3')
-    res, recs, n_rec = _replay(model, g, 'g5_sample_head3')
+    g = golden(name)
+    res, recs, n_rec = _replay(_model_for(name), g, name)
     traj_n, traj_p, traj_e = (a.cpu() for a in res['traj'])
     for s in range(n_rec):
         assert np.array_equal(traj_n[s].numpy(), g[f's{s}_h_node']), s
@@ -257,13 +290,16 @@ def test_sampler_closed_loop_matches_reference_trajectory(model):
         assert max(rel_err(v, g[f's{s}_out_v']), rel_err(x0, g[f's{s}_out_x0']), rel_err(bond, g[f's{s}_out_bond'])) <= 5 * TOL, s
 
 
-@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3'])
-def test_sampler_teacher_forced_every_step(model, oracle, name):
+@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3',
+                                  'g5_sample_head3_gamma_signed', 'g5_sample_tail4_gamma_signed',
+                                  'g5_sample_head3_trained_like', 'g5_sample_tail4_trained_like'])
+def test_sampler_teacher_forced_every_step(name):
     """Every recorded step of every fixture: load the reference's state, run ONE HIP step (forward + transition with
     the reference's recorded draws) and compare with the reference's next state.  Types bit-exact, positions <= 1e-4 RMSD."""
     import torch.nn.functional as F
     from phoregen_amd.data import PhoreGraph
     g = golden(name)
+    model, oracle = _model_for(name), _oracle_for(name)
     tape = _tape(g)
     n_rec = sum(1 for k in g.files if k.endswith('_out_v'))
     t_total = int(g['t_total'])

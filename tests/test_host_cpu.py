@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pg_abi_version() == 1
+    assert lib.pg_abi_version() == 2
     assert isinstance(lib.pg_last_error(), bytes)
 
 
@@ -156,6 +156,35 @@ def test_factored_first_layer_algebra(model):
     feat = torch.cat([torch.zeros(20, dtype=torch.float64), sm, dots, torch.tensor([0., 1., 0., 0., 0.], dtype=torch.float64)])
     mine = Wfe @ feat + W1[:, 93:221] @ hd + b1 + W1[:, 84:93] @ bd + W1[:, 221:349] @ hs
     assert torch.allclose(mine, ref, atol=1e-10)
+
+
+@pytest.mark.parametrize('profile', ['default', 'gamma_signed', 'trained_like'])
+def test_folded_layernorm_rewrite_is_exact_for_every_weight_profile(profile):
+    """packing._kv_mlp (centred first layer, sign fold, |gamma| into the second Linear, per-row rstd, dead channels) against
+    the plain MLP of models/common.py:99-119 (Linear -> LayerNorm -> ReLU -> Linear) in float64, on LayerNorms with negative,
+    tiny and exactly-zero gamma (`gamma_signed`) and on trained-like scales."""
+    from phoregen_amd.weights import make_tensor
+    p = 'denoiser.base_block.1.bond_layer.hv_func'
+    shapes = {'.net.0.weight': (128, 437), '.net.0.bias': (128,), '.net.1.weight': (128,), '.net.1.bias': (128,),
+              '.net.3.weight': (128, 128), '.net.3.bias': (128,)}
+    sd = {p + k: make_tensor(p + k, s, 0, profile=profile).double() for k, s in shapes.items()}
+    gam = sd[p + '.net.1.weight']
+    if profile == 'gamma_signed':
+        assert (gam == 0).sum() >= 3 and (gam < 0).sum() > 30 and (gam.abs() < 1e-5).sum() >= 6
+    x = torch.randn(50, 437, generator=torch.Generator().manual_seed(1), dtype=torch.float64) * 3
+    hid = x @ sd[p + '.net.0.weight'].t() + sd[p + '.net.0.bias']
+    ref = torch.relu(torch.nn.functional.layer_norm(hid, (128,), gam, sd[p + '.net.1.bias'])) @ sd[p + '.net.3.weight'].t() \
+        + sd[p + '.net.3.bias']
+    m = packing._kv_mlp(sd, p)
+    h = x @ m['W1'].t() + m['b1']                                   # centred, sign-normalised
+    sgn = torch.where(gam < 0, -1.0, 1.0).double()
+    assert float((h * sgn).mean(-1).abs().max()) < 1e-12        # centred before the sign fold: no mean pass in the kernels
+    var = (h * h).mean(-1, keepdim=True) + 1e-5
+    sigma, rstd = var.sqrt(), var.rsqrt()
+    z = torch.relu(h + m['bp'] * sigma)                             # what the kernels evaluate per element
+    mine = rstd * (z @ m['W2'].t()) + m['b2']
+    assert torch.isfinite(mine).all()
+    assert float((mine - ref).abs().max()) <= 1e-9 * float(ref.abs().max())
 
 
 def test_phore_parser_matches_reference(tmp_path):
@@ -264,3 +293,12 @@ def test_plan_and_partition_properties_random_sizes():
         parts = partition_graphs(na, world)
         assert sorted(torch.cat(parts).tolist()) == list(range(B))
     check()
+
+
+def test_philox_checker_reproduces_random123_known_answers():
+    """oracle/philox_ref.py (the checker of the device generator) against Random123's published philox4x32-10 vectors."""
+    from oracle import philox_ref as pr
+    for ctr, key, out in pr.KAT:
+        assert tuple(int(v) for v in pr.philox4x32([ctr], [key])[0]) == out
+    u = pr.uniform24(np.array([0, 0xffffffff, 0x80000000], dtype=np.uint32))
+    assert u[0] == 0.0 and u[1] < 1.0 and u[2] == 0.5

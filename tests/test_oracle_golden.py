@@ -16,6 +16,18 @@ def oracle():
     return make_oracle(0)
 
 
+_ORACLES = {}
+
+
+def _oracle_for(name):
+    """Fixtures named *_<profile> were recorded from the reference with that weight profile (phoregen_amd/weights.py)."""
+    prof = next((p for p in ('gamma_signed', 'trained_like') if name.endswith('_' + p)), 'default')
+    if prof not in _ORACLES:
+        torch.set_num_threads(4)
+        _ORACLES[prof] = make_oracle(0, prof)
+    return _ORACLES[prof]
+
+
 def test_g1_small_ops():
     g = golden('g1_ops')
     assert np.array_equal(po.gaussian_smearing(t(g['dist'])).numpy(), g['smear'])
@@ -73,9 +85,10 @@ def test_posterior_kats(oracle):
     assert np.allclose(prev.numpy(), g['pos_prev'], rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize('name', ['g3_forward_a', 'g3_forward_b'])
-def test_g23_forward_and_layers(oracle, name):
+@pytest.mark.parametrize('name', ['g3_forward_a', 'g3_forward_b', 'g3_forward_a_gamma_signed', 'g3_forward_a_trained_like'])
+def test_g23_forward_and_layers(name):
     g = golden(name)
+    oracle = _oracle_for(name)
     inp = {k[3:]: t(g[k]) for k in g.files if k.startswith('in_')}
     cap = {}
     with torch.no_grad():
@@ -101,9 +114,12 @@ def _tape(g):
     return [(k.split('_', 1)[1], g[k]) for k in keys]
 
 
-@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3'])
-def test_g5_sampler(oracle, name):
+@pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3',
+                                  'g5_sample_head3_gamma_signed', 'g5_sample_tail4_gamma_signed',
+                                  'g5_sample_head3_trained_like', 'g5_sample_tail4_trained_like'])
+def test_g5_sampler(name):
     g = golden(name)
+    oracle = _oracle_for(name)
     tape = _tape(g)
     assert tape[0][0] == 'randint'          # sample_from_interval draw (replaced by the forced atom counts)
     draws = [a for _, a in tape[1:]]
@@ -165,13 +181,13 @@ def _train_batch(g):
     return {k: t(g[k]) for k in keys}
 
 
-@pytest.mark.parametrize('name', ['g6_loss_a', 'g6_loss_b'])
+@pytest.mark.parametrize('name', ['g6_loss_a', 'g6_loss_b', 'g6_loss_a_gamma_signed', 'g6_loss_a_trained_like'])
 def test_compute_loss_and_gradients_match_reference(name):
     """G6: loss terms and every parameter-gradient norm of the reference's compute_loss + backward
     (diffusion.py:249-352), replaying its recorded draws through the oracle's autograd."""
     from oracle import phoregen_oracle as po
     g = golden(name)
-    orc = make_oracle()
+    orc = make_oracle(0, next((p for p in ('gamma_signed', 'trained_like') if name.endswith('_' + p)), 'default'))
     names = [str(k) for k in g['param_names']]
     for k in names:
         orc.sd[k].requires_grad_(True)
