@@ -52,6 +52,30 @@ def ligphore_workload(n_graphs=128, seed=1234, fixed_shape=False):
                 num_atoms=n_at, n_phore=n_ph)
 
 
+def config4_job(n_phores=1024, samples=100, seed=4321):
+    """BASELINE config 4: `n_phores` synthetic CpxPhore/DockPhore-shaped pharmacophores
+    (p ~ N(80,25^2) clamp [24,152]) x `samples` graphs each, n ~ N(40,6^2) clamp [20,60] atoms, as a SamplingJob."""
+    import torch.nn.functional as F
+    from phoregen_amd.parallel import SamplingJob
+    g = torch.Generator().manual_seed(seed)
+    n_ph = (80 + 25 * torch.randn(n_phores, generator=g)).round().clamp(24, 152).long()
+    phores = []
+    for p in n_ph.tolist():
+        is_ex = torch.rand(p, generator=g) < 0.9
+        is_ex[0] = False                                   # at least one feature point (the guidance centre needs one)
+        types = torch.where(is_ex, torch.full((p,), 12), torch.randint(0, 12, (p,), generator=g))
+        alpha = 0.5 + torch.rand(p, 1, generator=g)
+        has_norm = ((torch.rand(p, generator=g) < 0.3) & ~is_ex).long()
+        nrm = torch.randn(p, 3, generator=g)
+        nrm = nrm / nrm.norm(dim=-1, keepdim=True) * has_norm[:, None].float()
+        pos = 6.0 * torch.randn(p, 3, generator=g)
+        x = torch.cat([F.one_hot(types, 13).float(), alpha, F.one_hot(has_norm, 2).float(), F.one_hot(is_ex.long(), 2).float()], -1)
+        phores.append((x, pos - pos.mean(0, keepdim=True), nrm, torch.randn(3, generator=g)))
+    graph_phore = torch.repeat_interleave(torch.arange(n_phores), samples)
+    num_atoms = (40 + 6 * torch.randn(n_phores * samples, generator=g)).round().clamp(20, 60).long()
+    return SamplingJob(phores, graph_phore, num_atoms)
+
+
 def subset_workload(w, graph_ids):
     """The graphs `graph_ids` (ascending) of a workload, renumbered 0..len-1."""
     keep = torch.isin(w['batch_phore'], graph_ids)

@@ -180,22 +180,28 @@ int pg_atom_count(const float* s_all /*[n_phore]*/, const float* s_l /*[n_phore]
 
 /* ---- reverse-diffusion step (models/transition.py:44-63,285-315, models/common.py:425-431) ----
  * categorical: log_softmax(logits) -> q_v_posterior(v0_prob=True) -> Gumbel-argmax -> one-hot.
- * `uniform` != NULL replays given draws (parity mode); NULL -> counter-based Philox4x32-10 keyed by
- * (seed, stream_id, step). */
+ * `uniform` / `eps` != NULL replay given draws (parity mode); NULL -> counter-based Philox4x32-10 with key = seed and
+ * counter = (element, step, stream_id).  element = flat index of the batch when graph_row0 == NULL; otherwise the
+ * graph-keyed form (graph_key[g] << 32 | index of the element inside graph g), with graph_row0[g] = first row of graph g
+ * and graph_key[g] = a caller-chosen id (NULL: g): a graph then draws the same noise in whatever batch or shard it is
+ * sampled (per-graph sharding over GPUs reproduces the unsharded run). */
 int pg_posterior_categorical(const float* logits, const float* log_vt_in, const int* row_graph,
                              const int64_t* time_step, const float* q_mats, const float* q_onestep_T,
                              int n_rows, int K, const float* uniform, uint64_t seed, uint32_t stream_id,
-                             uint32_t step, float* log_vt_out, float* onehot_out, float* traj_out,
-                             void* stream);
+                             uint32_t step, const int* graph_row0, const int* graph_key, float* log_vt_out,
+                             float* onehot_out, float* traj_out, void* stream);
 int pg_posterior_position(const float* x_t, const float* x0, const int* row_graph, const int64_t* time_step,
                           const float* coef_x0, const float* coef_xt, const float* std_, const float* energy_grad,
                           const float* eps, uint64_t seed, uint32_t stream_id, uint32_t step, int n_rows,
-                          const float* center /*[3] or NULL*/, float* x_prev, float* traj_out, void* stream);
+                          const int* graph_row0, const int* graph_key, const float* center /*[B,3] per graph, added to traj_out only; or NULL*/,
+                          float* x_prev, float* traj_out, void* stream);
 
-/* closed-form guidance gradient (models/diffusion.py:476-502, utils/sample_utils.py:135-165) */
+/* closed-form guidance gradient (models/diffusion.py:476-502, utils/sample_utils.py:135-165).  phore_center [B,3]: per
+ * graph the mean position of its non-EX pharmacophore nodes.  Both energies are means over the graphs of the batch;
+ * mean_over_graphs = that divisor (<= 0: this batch's n_graphs; a shard of a larger logical batch passes the full count). */
 int pg_guidance_grad(const PgTopo* t, const float* x_lig /*[n_lig,3]*/, const float* h_edge_prev /*[n_bond,6]*/,
                      const int* lig_graph, const int* g_lig_off, int use_atom_prox, float min_d, float max_d,
-                     int use_center_prox, const float* phore_center /*[3]*/, float* cnt_ws /*[B]*/,
+                     int use_center_prox, const float* phore_center /*[B,3]*/, int mean_over_graphs, float* cnt_ws /*[B]*/,
                      float* mean_ws /*[B,3]*/, float* grad /*[n_lig,3]*/, void* stream);
 
 /* ---- training path: backward kernels (PhoreDiff.compute_loss, models/diffusion.py:249-352) -------------------

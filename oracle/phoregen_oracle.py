@@ -248,8 +248,10 @@ class Oracle:
     """Functional PhoreDiff over a plain state_dict (SURVEY.md Appendix C key names)."""
 
     def __init__(self, state_dict, n_heads=16, knn=32, num_timesteps=1000, num_layers=6,
-                 diff_cfg=None, data_name='zinc_300'):
-        self.sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu()
+                 diff_cfg=None, data_name='zinc_300', dtype=torch.float32):
+        """dtype=torch.float64 (with float64 inputs): the same dataflow in double precision, used by the tests to measure
+        how much of an fp32 discrepancy is conditioning of the network rather than an implementation difference."""
+        self.sd = {k: v.detach().to(dtype).cpu() if v.is_floating_point() else v.detach().cpu()
                    for k, v in state_dict.items()}
         self.H, self.k, self.T, self.L = n_heads, knn, num_timesteps, num_layers
         self.ex_col = 12 if data_name in ('zinc_300', 'pdbbind') else 10     # diffusion.py:152-155
@@ -392,9 +394,9 @@ class Oracle:
                 h_phore, pos_phore, phore_norm, batch_phore, capture=None):
         """diffusion.py:175-246."""
         B = int(time_step.numel())
-        t_node = time_smearing(time_step[batch_node].float(), self.T)
+        t_node = time_smearing(time_step[batch_node].to(pos_pert.dtype), self.T)
         h_node = torch.cat([self.lin('node_embedder', h_node_pert), t_node], -1)
-        t_edge = time_smearing(time_step[batch_edge].float(), self.T)
+        t_edge = time_smearing(time_step[batch_edge].to(pos_pert.dtype), self.T)
         hp = self.phore_encode(h_phore, pos_phore, batch_phore)
         h_all, pos_all, batch_all, mask_l, p_idx, l_idx = compose_context(hp, h_node, pos_phore, pos_pert,
                                                                           batch_phore, batch_node)

@@ -35,10 +35,16 @@ template <int K>
 __global__ void posterior_cat_kernel(const float* logits, const float* log_vt_in, const int* row_graph,
                                      const int64_t* time_step, const float* q_mats, const float* q_onestep_T, int n_rows,
                                      const float* uniform, uint64_t seed, uint32_t stream_id, uint32_t step,
+                                     const int* graph_row0, const int* graph_key,
                                      float* log_vt_out, float* onehot_out, float* traj_out) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_rows) return;
-  const int tb = (int)time_step[row_graph[row]];
+  const int gr = row_graph[row];
+  const int tb = (int)time_step[gr];
+  // counter of element (row, k): flat index of the batch, or -- graph-keyed form -- (graph key, index inside the graph), which
+  // makes a graph's noise independent of the batch / shard it is sampled in
+  const uint64_t e_hi = graph_row0 ? (uint64_t)(uint32_t)(graph_key ? graph_key[gr] : gr) << 32 : 0;
+  const size_t e0 = graph_row0 ? (size_t)(row - graph_row0[gr]) * K : (size_t)row * K;
   const int tm1 = tb > 0 ? tb - 1 : 0;
   // log_softmax (diffusion.py:453,462)
   float x[K], mx = -INFINITY;
@@ -81,8 +87,8 @@ __global__ void posterior_cat_kernel(const float* logits, const float* log_vt_in
     float u;
     if (uniform) u = uniform[(size_t)row * K + k];
     else {
-      const size_t e = (size_t)row * K + k;
-      Philox ph(seed, e >> 2, step, stream_id);
+      const size_t e = e0 + k;
+      Philox ph(seed, e_hi | (e >> 2), step, stream_id);
       u = ph.uniform((int)(e & 3));
     }
     const float gn = -logf(-logf(u + 1e-30f) + 1e-30f);
@@ -100,24 +106,28 @@ __global__ void posterior_cat_kernel(const float* logits, const float* log_vt_in
 __global__ void posterior_pos_kernel(const float* x_t, const float* x0, const int* row_graph, const int64_t* time_step,
                                      const float* coef_x0, const float* coef_xt, const float* std_, const float* grad,
                                      const float* eps, uint64_t seed, uint32_t stream_id, uint32_t step, int n_rows,
+                                     const int* graph_row0, const int* graph_key,
                                      const float* center, float* x_prev, float* traj_out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rows * 3) return;
   const int row = idx / 3;
-  const int tb = (int)time_step[row_graph[row]];
+  const int gr = row_graph[row];
+  const int tb = (int)time_step[gr];
   // transition.py:57-62
   float mu = coef_x0[tb] * x0[idx] + coef_xt[tb] * x_t[idx];
   if (grad) mu -= grad[idx];
   float e;
   if (eps) e = eps[idx];
   else {
-    Philox ph(seed, (uint64_t)idx, step, stream_id);
+    const uint64_t ctr = graph_row0 ? ((uint64_t)(uint32_t)(graph_key ? graph_key[gr] : gr) << 32) | (uint32_t)(idx - 3 * graph_row0[gr])
+                                    : (uint64_t)idx;
+    Philox ph(seed, ctr, step, stream_id);
     const float u1 = 1.0f - ph.uniform(0), u2 = ph.uniform(1);     // u1 in (0,1]
     e = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
   }
   const float v = tb == 0 ? mu : mu + std_[tb] * e;
   x_prev[idx] = v;
-  if (traj_out) traj_out[idx] = v + (center ? center[idx % 3] : 0.f);
+  if (traj_out) traj_out[idx] = v + (center ? center[gr * 3 + idx % 3] : 0.f);
 }
 
 // ---- guidance: closed-form gradient of the two energies (sample_utils.py:135-165) ----
@@ -146,11 +156,11 @@ __global__ void guidance_stats_kernel(PgTopo t, const float* x_lig, const float*
 
 __global__ void guidance_grad_kernel(PgTopo t, const float* x_lig, const float* h_edge_prev, const int* lig_graph,
                                      const int* g_lig_off, int use_atom, float min_d, float max_d, int use_center,
-                                     const float* pc, const float* cnt, const float* mean, float* grad) {
+                                     const float* pc, int mean_over, const float* cnt, const float* mean, float* grad) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= t.n_lig) return;
   const int g = lig_graph[a], n = t.g_nlig[g], a0 = g_lig_off[g], la = a - a0;
-  const float B = (float)t.n_graphs;
+  const float B = (float)mean_over;     // the energies are means over the graphs of the (logical) batch
   float gx = 0.f, gy = 0.f, gz = 0.f;
   const float xa = x_lig[a * 3], ya = x_lig[a * 3 + 1], za = x_lig[a * 3 + 2];
   if (use_atom && cnt[g] > 0.f) {
@@ -175,7 +185,7 @@ __global__ void guidance_grad_kernel(PgTopo t, const float* x_lig, const float* 
     }
   }
   if (use_center) {
-    const float dx = mean[g * 3] - pc[0], dy = mean[g * 3 + 1] - pc[1], dz = mean[g * 3 + 2] - pc[2];
+    const float dx = mean[g * 3] - pc[g * 3], dy = mean[g * 3 + 1] - pc[g * 3 + 1], dz = mean[g * 3 + 2] - pc[g * 3 + 2];
     const float nr = sqrtf(dx * dx + dy * dy + dz * dz), w = 1.f / ((float)n * B * nr);
     gx += dx * w; gy += dy * w; gz += dz * w;
   }
@@ -195,16 +205,18 @@ extern "C" int pg_selftest_philox(const uint32_t* ctr_key, int n, uint32_t* out,
 extern "C" int pg_posterior_categorical(const float* logits, const float* log_vt_in, const int* row_graph,
                                         const int64_t* time_step, const float* q_mats, const float* q_onestep_T,
                                         int n_rows, int K, const float* uniform, uint64_t seed, uint32_t stream_id,
-                                        uint32_t step, float* log_vt_out, float* onehot_out, float* traj_out,
-                                        void* stream) {
+                                        uint32_t step, const int* graph_row0, const int* graph_key, float* log_vt_out,
+                                        float* onehot_out, float* traj_out, void* stream) {
   if (n_rows == 0) return PG_OK;
   dim3 grid((n_rows + 255) / 256), block(256);
   if (K == 12)
     hipLaunchKernelGGL(posterior_cat_kernel<12>, grid, block, 0, (hipStream_t)stream, logits, log_vt_in, row_graph,
-                       time_step, q_mats, q_onestep_T, n_rows, uniform, seed, stream_id, step, log_vt_out, onehot_out, traj_out);
+                       time_step, q_mats, q_onestep_T, n_rows, uniform, seed, stream_id, step, graph_row0, graph_key, log_vt_out, onehot_out,
+                       traj_out);
   else if (K == 6)
     hipLaunchKernelGGL(posterior_cat_kernel<6>, grid, block, 0, (hipStream_t)stream, logits, log_vt_in, row_graph,
-                       time_step, q_mats, q_onestep_T, n_rows, uniform, seed, stream_id, step, log_vt_out, onehot_out, traj_out);
+                       time_step, q_mats, q_onestep_T, n_rows, uniform, seed, stream_id, step, graph_row0, graph_key, log_vt_out, onehot_out,
+                       traj_out);
   else { set_error("pg_posterior_categorical: K must be 12 or 6 (got %d)", K); return PG_ERR_ARG; }
   return check_launch("pg_posterior_categorical");
 }
@@ -212,22 +224,25 @@ extern "C" int pg_posterior_categorical(const float* logits, const float* log_vt
 extern "C" int pg_posterior_position(const float* x_t, const float* x0, const int* row_graph, const int64_t* time_step,
                                      const float* coef_x0, const float* coef_xt, const float* std_, const float* energy_grad,
                                      const float* eps, uint64_t seed, uint32_t stream_id, uint32_t step, int n_rows,
-                                     const float* center, float* x_prev, float* traj_out, void* stream) {
+                                     const int* graph_row0, const int* graph_key, const float* center, float* x_prev,
+                                     float* traj_out, void* stream) {
   if (n_rows == 0) return PG_OK;
   hipLaunchKernelGGL(posterior_pos_kernel, dim3((n_rows * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_t, x0,
-                     row_graph, time_step, coef_x0, coef_xt, std_, energy_grad, eps, seed, stream_id, step, n_rows, center,
-                     x_prev, traj_out);
+                     row_graph, time_step, coef_x0, coef_xt, std_, energy_grad, eps, seed, stream_id, step, n_rows, graph_row0,
+                     graph_key, center, x_prev, traj_out);
   return check_launch("pg_posterior_position");
 }
 
 extern "C" int pg_guidance_grad(const PgTopo* t, const float* x_lig, const float* h_edge_prev, const int* lig_graph,
                                 const int* g_lig_off, int use_atom_prox, float min_d, float max_d, int use_center_prox,
-                                const float* phore_center, float* cnt_ws, float* mean_ws, float* grad, void* stream) {
+                                const float* phore_center, int mean_over_graphs, float* cnt_ws, float* mean_ws, float* grad,
+                                void* stream) {
   if (t->n_lig == 0) return PG_OK;
+  if (mean_over_graphs <= 0) mean_over_graphs = t->n_graphs;
   hipLaunchKernelGGL(guidance_stats_kernel, dim3(t->n_graphs), dim3(64), 0, (hipStream_t)stream, *t, x_lig, h_edge_prev,
                      g_lig_off, cnt_ws, mean_ws);
   hipLaunchKernelGGL(guidance_grad_kernel, dim3((t->n_lig + 255) / 256), dim3(256), 0, (hipStream_t)stream, *t, x_lig,
-                     h_edge_prev, lig_graph, g_lig_off, use_atom_prox, min_d, max_d, use_center_prox, phore_center, cnt_ws,
-                     mean_ws, grad);
+                     h_edge_prev, lig_graph, g_lig_off, use_atom_prox, min_d, max_d, use_center_prox, phore_center,
+                     mean_over_graphs, cnt_ws, mean_ws, grad);
   return check_launch("pg_guidance_grad");
 }

@@ -85,9 +85,9 @@ _PROTOS = {
                                  C.c_void_p]),
     'pg_atom_count': (C.c_int, [c_fp, c_fp, c_ip, c_ip, C.c_int, C.c_int, c_fp, c_fp, C.c_void_p]),
     'pg_posterior_categorical': (C.c_int, [c_fp, c_fp, c_ip, c_ip, c_fp, c_fp, C.c_int, C.c_int, c_fp,
-                                           C.c_uint64, C.c_uint32, C.c_uint32, c_fp, c_fp, c_fp, C.c_void_p]),
+                                           C.c_uint64, C.c_uint32, C.c_uint32, c_ip, c_ip, c_fp, c_fp, c_fp, C.c_void_p]),
     'pg_posterior_position': (C.c_int, [c_fp, c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_uint64,
-                                        C.c_uint32, C.c_uint32, C.c_int, c_fp, c_fp, c_fp, C.c_void_p]),
+                                        C.c_uint32, C.c_uint32, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, C.c_void_p]),
     'pg_gemm_wgrad': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_void_p]),
     'pg_ln_relu': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, c_fp, C.c_int, C.c_void_p]),
     'pg_ln_relu_bwd': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp,
@@ -96,7 +96,7 @@ _PROTOS = {
     'pg_seg_attn_bwd': (C.c_int, [C.POINTER(PgTopo), C.POINTER(PgSegAttn), C.POINTER(PgSegAttnGrad), C.c_void_p]),
     'pg_attn_fold_wgrad': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_ip, c_fp, C.c_void_p]),
     'pg_guidance_grad': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_ip, c_ip, C.c_int, C.c_float, C.c_float,
-                                   C.c_int, c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
+                                   C.c_int, c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_void_p]),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -322,11 +322,19 @@ class PhoreDiff(nn.Module):
 
     @torch.no_grad()
     def sample_batch(self, h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, pos_guidance_opt=None,
-                     rng='device', seed=0, return_traj=True, guidance_center=None, num_steps=None, on_step=None):
+                     rng='device', seed=0, return_traj=True, guidance_center=None, num_steps=None, on_step=None,
+                     graph_ids=None, guidance_batch=None):
         """Sampler over a batch of (possibly different) pharmacophores: the multi-pharmacophore entry point
-        the reference lacks.  `centers` [B,3] are added back to coordinates as the reference does."""
+        the reference lacks.  `centers` [B,3] are added back to coordinates as the reference does.
+        graph_ids [B] (device RNG): the noise of graph g is keyed by (seed, graph_ids[g]) and by positions INSIDE the graph,
+            so a graph draws the same noise in any batch / shard (default: 0..B-1).
+        guidance_center [3] or [B,3]: target of the `center_prox` energy (default: per graph, the mean of its non-EX
+            pharmacophore nodes, diffusion.py:489-491).
+        guidance_batch: the number of graphs the guidance energies average over (default B, the reference's behaviour; a
+            shard of a larger logical batch passes the full batch size so that it reproduces the unsharded run)."""
         st = self.begin_sampling(h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, rng=rng, seed=seed,
-                                 return_traj=return_traj, num_steps=num_steps, guidance_center=guidance_center)
+                                 return_traj=return_traj, num_steps=num_steps, guidance_center=guidance_center,
+                                 graph_ids=graph_ids, guidance_batch=guidance_batch)
         T = self.num_timesteps
         for i, step in enumerate(range(T)[::-1][:st.n_steps]):
             self.reverse_step(st, i, step, pos_guidance_opt)
@@ -338,46 +346,65 @@ class PhoreDiff(nn.Module):
     @torch.no_grad()
     @_on_model_device
     def begin_sampling(self, h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, rng='device', seed=0,
-                       return_traj=True, num_steps=None, guidance_center=None):
+                       return_traj=True, num_steps=None, guidance_center=None, graph_ids=None, guidance_batch=None):
         dev = self._device()
-        hip.lib()
+        lib = hip.lib()
         B = int(num_atoms.numel())
         num_atoms = num_atoms.detach().cpu().long()
         batch_node = torch.repeat_interleave(torch.arange(B), num_atoms)
         edge_index, batch_edge = make_edge_data(num_atoms)
         plan = BatchPlan(batch_node, batch_phore, edge_index, batch_edge, B, dev)
         eng = self.engine_for(plan)
-        w = eng.ws
-        eng.encode_phore(h_phore.to(dev), pos_phore.to(dev), phore_norm.to(dev), self.ex_col)
+        w, pk = eng.ws, eng.pack
+        h_phore, pos_phore = h_phore.to(dev), pos_phore.to(dev)
+        eng.encode_phore(h_phore, pos_phore, phore_norm.to(dev), self.ex_col)
         N, E = plan.n_lig, plan.n_bond
         st = type('SamplerState', (), {})()
         st.eng, st.plan, st.num_atoms, st.N, st.E, st.B = eng, plan, num_atoms, N, E, B
         st.cpu, st.seed, st.return_traj = rng == 'cpu', seed, return_traj
         st.n_steps = self.num_timesteps if num_steps is None else num_steps
-        centers = centers.to(dev).float()
-        st.center_rows = centers[plan.batch_node]                                        # [N,3]
-        if return_traj and not bool((centers == centers[0:1]).all()):
-            raise NotImplementedError('phoregen_amd: return_traj needs one shared centre (the reference adds data.center)')
-        st.c0 = centers[0].contiguous()
+        st.centers = centers.to(dev).float().contiguous()                                # [B,3]
+        st.center_rows = st.centers[plan.batch_node]                                     # [N,3]
+        st.graph_key = (torch.arange(B) if graph_ids is None else graph_ids.detach().cpu()).to(torch.int32).to(dev)
+        st.guidance_batch = int(guidance_batch) if guidance_batch else B
 
         # ---- init state (diffusion.py:406-408, transition.py:65-69,331-339) ----
+        lp_n = torch.log(torch.from_numpy(self.node_transition.init_prob) + self.node_transition.eps).clamp_min(-32.)
+        lp_e = torch.log(torch.from_numpy(self.edge_transition.init_prob) + self.edge_transition.eps).clamp_min(-32.)
         if st.cpu:
             pos = torch.randn([N, 3]).to(dev) - st.center_rows
             u_n = torch.rand(N, 12, dtype=torch.float64)
             u_e = torch.rand(E, 6, dtype=torch.float64)
+
+            def init_types(lp, u):
+                gum = -torch.log(-torch.log(u + 1e-30) + 1e-30)
+                return (gum + lp.unsqueeze(0)).argmax(-1).to(dev)
+            h_node = F.one_hot(init_types(lp_n, u_n), 12).float()
+            h_edge = F.one_hot(init_types(lp_e, u_e), 6).float()
         else:
-            gen = torch.Generator(device=dev).manual_seed(seed)
-            pos = torch.randn([N, 3], device=dev, generator=gen) - st.center_rows
-            u_n = torch.rand(N, 12, dtype=torch.float64, device=dev, generator=gen)
-            u_e = torch.rand(E, 6, dtype=torch.float64, device=dev, generator=gen)
+            # the same draws by the transition kernels themselves: Gumbel-argmax of the (normalised) prior = the kernel's t = 0
+            # branch on logits = log prior; N(0,1) = the Gaussian posterior with mean 0 and sigma 1.  Counter step = T (never a
+            # real step), so the initial noise is one more graph-keyed Philox stream
+            s = hip.stream_ptr()
+            T = self.num_timesteps
+            t0, t1 = torch.zeros(B, dtype=torch.int64, device=dev), torch.ones(B, dtype=torch.int64, device=dev)
+            h_node, h_edge = torch.empty(N, 12, device=dev), torch.empty(E, 6, device=dev)
+            for lp, tab, rows, K, sid, rg, row0, oh in ((lp_n, pk.node_tab, N, 12, 0, plan.lig_graph, plan.g_lig_off, h_node),
+                                                        (lp_e, pk.edge_tab, E, 6, 1, plan.bond_graph, plan.g_bond_off, h_edge)):
+                logits = lp.float().to(dev).unsqueeze(0).expand(rows, K).contiguous()
+                scratch = torch.empty(rows, K, device=dev)
+                hip.check(lib.pg_posterior_categorical(
+                    logits.data_ptr(), logits.data_ptr(), rg.data_ptr(), t0.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(),
+                    rows, K, None, seed, sid, T, row0.data_ptr(), st.graph_key.data_ptr(), scratch.data_ptr(), oh.data_ptr(),
+                    None, s), 'init types')
+            ones, zx = torch.ones(2, device=dev), torch.zeros(N, 3, device=dev)
+            pos = torch.empty(N, 3, device=dev)
+            hip.check(lib.pg_posterior_position(
+                zx.data_ptr(), zx.data_ptr(), plan.lig_graph.data_ptr(), t1.data_ptr(), ones.data_ptr(), ones.data_ptr(),
+                ones.data_ptr(), None, None, seed, 2, T, N, plan.g_lig_off.data_ptr(), st.graph_key.data_ptr(), None,
+                pos.data_ptr(), None, s), 'init positions')
+            pos -= st.center_rows
 
-        def init_types(tr, u):
-            lp = torch.log(torch.from_numpy(tr.init_prob) + tr.eps).clamp_min(-32.).to(u.device)
-            gum = -torch.log(-torch.log(u + 1e-30) + 1e-30)
-            return (gum + lp.unsqueeze(0)).argmax(-1).to(dev)
-
-        node_t, edge_t = init_types(self.node_transition, u_n), init_types(self.edge_transition, u_e)
-        h_node, h_edge = F.one_hot(node_t, 12).float(), F.one_hot(edge_t, 6).float()
         st.log_node = [torch.log(h_node.clamp(min=1e-30)), torch.empty(N, 12, device=dev)]   # common.py:398-402
         st.log_edge = [torch.log(h_edge.clamp(min=1e-30)), torch.empty(E, 6, device=dev)]
         st.cur = 0
@@ -390,7 +417,16 @@ class PhoreDiff(nn.Module):
             st.node_traj[0], st.pos_traj[0], st.edge_traj[0] = h_node, pos, h_edge        # :424-426 (no +center)
         st.grad = torch.zeros(N, 3, device=dev)
         st.cnt_ws, st.mean_ws, st.gtmp = torch.zeros(B, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(N, 3, device=dev)
-        st.gc = guidance_center.to(dev).float().contiguous() if guidance_center is not None else None
+        # per-graph target of the center_prox energy: given, or the mean of the graph's non-EX pharmacophore nodes
+        if guidance_center is not None:
+            gc = guidance_center.to(dev).float()
+            st.gc = (gc.unsqueeze(0).expand(B, 3) if gc.dim() == 1 else gc).contiguous()
+        else:
+            keep = (h_phore[:, self.ex_col] != 1).float().unsqueeze(-1)
+            bp = plan.phore_graph.long()
+            sums = torch.zeros(B, 3, device=dev).index_add_(0, bp, pos_phore.float() * keep)
+            cnt = torch.zeros(B, 1, device=dev).index_add_(0, bp, keep)
+            st.gc = (sums / cnt).contiguous()              # (0/0 = nan for a pharmacophore of exclusion spheres only, as in the reference)
         st.x0 = None
         return st
 
@@ -415,10 +451,12 @@ class PhoreDiff(nn.Module):
         hip.check(lib.pg_posterior_categorical(
             w.out_v.data_ptr(), st.log_node[cur].data_ptr(), plan.lig_graph.data_ptr(), w.in_t.data_ptr(),
             pk.node_tab[0].data_ptr(), pk.node_tab[1].data_ptr(), N, 12, hip.ptr(un), st.seed, 0, step,
+            plan.g_lig_off.data_ptr(), st.graph_key.data_ptr(),
             st.log_node[1 - cur].data_ptr(), w.in_h_node.data_ptr(), tp(st.node_traj), s), 'posterior(node)')
         hip.check(lib.pg_posterior_categorical(
             w.out_bond.data_ptr(), st.log_edge[cur].data_ptr(), plan.bond_graph.data_ptr(), w.in_t.data_ptr(),
             pk.edge_tab[0].data_ptr(), pk.edge_tab[1].data_ptr(), E, 6, hip.ptr(ue), st.seed, 1, step,
+            plan.g_bond_off.data_ptr(), st.graph_key.data_ptr(),
             st.log_edge[1 - cur].data_ptr(), w.in_h_edge.data_ptr(), tp(st.edge_traj), s), 'posterior(edge)')
         grad = None
         if pos_guidance_opt:                                         # diffusion.py:476-502
@@ -431,7 +469,8 @@ class PhoreDiff(nn.Module):
                 hip.check(lib.pg_guidance_grad(
                     plan.topo_ref, w.in_pos.data_ptr(), w.in_h_edge.data_ptr(), plan.lig_graph.data_ptr(),
                     plan.g_lig_off.data_ptr(), int(atom), float(o.get('min_d', 1.2)), float(o.get('max_d', 2.8)),
-                    int(not atom), hip.ptr(st.gc), st.cnt_ws.data_ptr(), st.mean_ws.data_ptr(), st.gtmp.data_ptr(), s),
+                    int(not atom), hip.ptr(st.gc), st.guidance_batch, st.cnt_ws.data_ptr(), st.mean_ws.data_ptr(),
+                    st.gtmp.data_ptr(), s),
                     'guidance')
                 grad += st.gtmp
         if draws is None and st.cpu:
@@ -439,7 +478,8 @@ class PhoreDiff(nn.Module):
         hip.check(lib.pg_posterior_position(
             w.in_pos.data_ptr(), st.x0.data_ptr(), plan.lig_graph.data_ptr(), w.in_t.data_ptr(),
             pk.pos_tab[0].data_ptr(), pk.pos_tab[1].data_ptr(), pk.pos_tab[2].data_ptr(), hip.ptr(grad), hip.ptr(eps),
-            st.seed, 2, step, N, st.c0.data_ptr() if st.return_traj else None,
+            st.seed, 2, step, N, plan.g_lig_off.data_ptr(), st.graph_key.data_ptr(),
+            st.centers.data_ptr() if st.return_traj else None,
             w.in_pos.data_ptr(), tp(st.pos_traj), s), 'posterior(pos)')          # in place: x_t -> x_{t-1}
         st.cur = 1 - cur
 

@@ -59,6 +59,59 @@ def gather_predictions(pred, num_atoms_local, graph_ids_local, group=None):
     return pred_global, torch.tensor([per_graph[g][3] for g in order])
 
 
+class SamplingJob:
+    """A multi-pharmacophore sampling job (BASELINE config 4: P pharmacophores x S samples): `phores` = list of
+    (x [p,18], pos [p,3], norm [p,3], center [3]); graph g samples pharmacophore graph_phore[g] with num_atoms[g] atoms.
+    The reference serves such a job with a serial loop over pharmacophores (sample_all.py:69-175, one `model.sample` per
+    pharmacophore); here the graphs of all pharmacophores are one pool, partitioned over GPUs and cut into batches."""
+
+    def __init__(self, phores, graph_phore, num_atoms):
+        self.phores = phores
+        self.graph_phore = torch.as_tensor(graph_phore, dtype=torch.long)
+        self.num_atoms = torch.as_tensor(num_atoms, dtype=torch.long)
+        assert self.graph_phore.numel() == self.num_atoms.numel()
+
+    @property
+    def n_graphs(self):
+        return int(self.num_atoms.numel())
+
+    def batch_inputs(self, gids):
+        xs, ps, ns, cs, bp = [], [], [], [], []
+        for i, g in enumerate(gids.tolist()):
+            x, pos, norm, center = self.phores[int(self.graph_phore[g])]
+            xs.append(x), ps.append(pos), ns.append(norm), cs.append(center.view(1, 3))
+            bp.append(torch.full((x.size(0),), i, dtype=torch.long))
+        return torch.cat(xs), torch.cat(ps), torch.cat(ns), torch.cat(bp), self.num_atoms[gids], torch.cat(cs)
+
+
+def sample_job_shard(model, job, graph_ids, batch_size=128, seed=0, num_steps=None, pos_guidance_opt=None):
+    """Sample the graphs `graph_ids` (ascending) of `job` on this process's GPU in batches of <= batch_size.  Noise is keyed
+    by the GLOBAL graph id and the guidance energies are normalised by `batch_size`, so the result of a graph does not
+    depend on which shard or batch it lands in.  Returns pred = [logits_node, pos, logits_edge] in graph_ids order."""
+    parts = ([], [], [])
+    for b0 in range(0, int(graph_ids.numel()), batch_size):
+        gids = graph_ids[b0:b0 + batch_size]
+        hp, pp, pn, bp, na, centers = job.batch_inputs(gids)
+        res = model.sample_batch(hp, pp, pn, bp, na, centers, pos_guidance_opt=pos_guidance_opt, rng='device', seed=seed,
+                                 return_traj=False, num_steps=num_steps, graph_ids=gids, guidance_batch=batch_size)
+        for acc, t in zip(parts, res['pred']):
+            acc.append(t)
+    dev = next(model.parameters()).device
+    empty = (torch.zeros(0, 12, device=dev), torch.zeros(0, 3, device=dev), torch.zeros(0, 6, device=dev))
+    return [torch.cat(a) if a else e for a, e in zip(parts, empty)]
+
+
+def run_sampling_job(model, job, world=1, rank=0, batch_size=128, seed=0, num_steps=None, pos_guidance_opt=None, group=None):
+    """Config 4 end to end on one rank: n^3-balanced partition of ALL graphs of the job, this rank's shard in batches, then
+    the one collective of the path (gather of `pred`).  Returns (pred_global, num_atoms_global) in global graph order when
+    torch.distributed is initialised (every rank), else this rank's (pred, num_atoms) in its graph_ids order."""
+    mine = partition_graphs(job.num_atoms, world)[rank]
+    pred = sample_job_shard(model, job, mine, batch_size, seed, num_steps, pos_guidance_opt)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return gather_predictions(pred, job.num_atoms[mine], mine, group)
+    return pred, job.num_atoms[mine]
+
+
 def allreduce_gradients(params, group=None, average=True):
     """Data-parallel training step (reference harness run/run.py:160-311 is single-GPU): the gradients
     of all trainable parameters (20.8 MB of fp32 for PhoreDiff) travel as ONE flat bucket, one all-reduce per step.

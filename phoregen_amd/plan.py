@@ -68,6 +68,11 @@ class BatchPlan:
         self.bond_desc = i32(torch.stack([lig2ctx[ei[0]], ld + (ls << 16), nlig[be], g_eid_off[be]], 1).contiguous()) \
             if self.n_bond else torch.zeros(0, 4, dtype=torch.int32, device=device)
         self.g_lig_off = i32(lig_off)
+        bond_off = torch.zeros(B + 1, dtype=torch.long)
+        bond_off[1:] = torch.bincount(be, minlength=B).cumsum(0)
+        if self.n_bond and (be[1:] < be[:-1]).any():
+            raise ValueError('phoregen_amd: bond edges must be grouped by graph (batch_edge ascending)')
+        self.g_bond_off = i32(bond_off)                 # first bond row of each graph (graph-keyed device RNG)
         self.batch_node, self.batch_edge, self.edge_index = bn.to(device), be.to(device), ei.to(device)
 
         t = hip.PgTopo()

@@ -84,3 +84,23 @@ def t(a):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+class Oracle64:
+    """The oracle's dataflow in float64 (same fp32-generated weights, exactly converted): the "exact" result against which
+    the conditioning of a weight set is measured -- rel_err(oracle fp32, oracle fp64) is the error ANY fp32 implementation
+    of the reference's dataflow carries on that input, and bounds what can be asked of the HIP path there."""
+
+    def __init__(self, seed=0, profile='default'):
+        from oracle import phoregen_oracle as po
+        sd = oracle_state_dict(seed, profile)                 # drawn in float32 (default dtype), then widened
+        self.o = po.Oracle(sd, diff_cfg=DIFF_CFG, dtype=torch.float64)
+
+    def forward(self, **inp):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            with torch.no_grad():
+                return self.o.forward(**{k: (v.double() if v.is_floating_point() else v) for k, v in inp.items()})
+        finally:
+            torch.set_default_dtype(old)

@@ -147,17 +147,29 @@ def test_forward_against_reference_golden(name):
 @pytest.mark.parametrize('profile', ['default', 'gamma_signed', 'trained_like'])
 def test_forward_against_oracle_larger_graphs(profile):
     """Sizes the goldens do not cover: > 32 atoms (3+ row tiles), tiny graphs (degree < 32), n = 2 (empty triplet segments),
-    under every weight profile (the oracle is pinned to the reference on each of them, tests/test_oracle_golden.py)."""
+    under every weight profile (the oracle is pinned to the reference on each of them, tests/test_oracle_golden.py).
+    Tolerance: TOL against the fp32 oracle where the network is well conditioned; the `trained_like` weights amplify fp32
+    rounding ~100x on these inputs (the fp32 oracle itself is 1e-4 away from its own float64 evaluation), so there the HIP
+    result is held to the float64 oracle within 3x the fp32 oracle's own distance to it."""
+    from helpers import Oracle64
     from oracle.make_inputs import synthetic_batch
     model, oracle = _model_for('x_' + profile), _oracle_for('x_' + profile)
     inp = synthetic_batch(7, [41, 2, 33, 17], [60, 9, 130, 25], [999, 0, 500, 250])
     with torch.no_grad():
         ref = oracle.forward(**inp)
         out = model(**{k: v.to(DEV) for k, v in inp.items()})
-    errs = dict(v=rel_err(out[0].cpu(), ref[0]), x0=rel_err(out[1].cpu(), ref[1]), bond=rel_err(out[2].cpu(), ref[2]),
-                cl=rel_err(out[3][0].cpu(), ref[3][0]), cu=rel_err(out[3][1].cpu(), ref[3][1]))
-    print(errs)
-    assert max(errs.values()) <= TOL, errs
+    ref64 = Oracle64(0, profile).forward(**inp)
+    names = ('v', 'x0', 'bond')
+    floor = {n: rel_err(ref[i], ref64[i]) for i, n in enumerate(names)}
+    errs32 = {n: rel_err(out[i].cpu(), ref[i]) for i, n in enumerate(names)}
+    errs64 = {n: rel_err(out[i].cpu(), ref64[i]) for i, n in enumerate(names)}
+    errs32.update(cl=rel_err(out[3][0].cpu(), ref[3][0]), cu=rel_err(out[3][1].cpu(), ref[3][1]))
+    print(profile, 'vs fp32 oracle', errs32, '| vs fp64 oracle', errs64, '| fp32 oracle vs fp64', floor)
+    assert errs32['cl'] <= TOL and errs32['cu'] <= TOL
+    for n in names:
+        assert errs32[n] <= TOL or errs64[n] <= 3 * floor[n], (n, errs32[n], errs64[n], floor[n])
+    if profile != 'trained_like':
+        assert max(errs32.values()) <= TOL, errs32
 
 
 def test_forward_row_tile_boundaries(model, oracle):
@@ -207,14 +219,14 @@ def test_posterior_kats(model):
         out, oh = torch.empty_like(lv0), torch.empty_like(lv0)
         hip.check(lib.pg_posterior_categorical(lv0.data_ptr(), lvt.data_ptr(), rg.data_ptr(), tt.data_ptr(),
                                                tab[0].data_ptr(), tab[1].data_ptr(), lv0.size(0), K, u.data_ptr(), 0, 0, 0,
-                                               out.data_ptr(), oh.data_ptr(), None, hip.stream_ptr()))
+                                               None, None, out.data_ptr(), oh.data_ptr(), None, hip.stream_ptr()))
         assert np.allclose(out.cpu().numpy(), g[f'{tag}_post'], rtol=0, atol=2e-6)
         assert np.array_equal(oh.argmax(-1).cpu().numpy(), g[f'{tag}_sample'])
     xt, x0, eps = (t(g[n]).to(DEV).contiguous() for n in ('pos_xt', 'pos_x0', 'pos_eps'))
     prev = torch.empty_like(xt)
     hip.check(lib.pg_posterior_position(xt.data_ptr(), x0.data_ptr(), rg.data_ptr(), tt.data_ptr(), pk.pos_tab[0].data_ptr(),
                                         pk.pos_tab[1].data_ptr(), pk.pos_tab[2].data_ptr(), None, eps.data_ptr(), 0, 0, 0,
-                                        xt.size(0), None, prev.data_ptr(), None, hip.stream_ptr()))
+                                        xt.size(0), None, None, None, prev.data_ptr(), None, hip.stream_ptr()))
     assert np.allclose(prev.cpu().numpy(), g['pos_prev'], rtol=0, atol=1e-6)
 
 

@@ -65,8 +65,8 @@ def test_position_noise_is_standard_normal():
     for step in (999, 998):
         out = torch.empty(n, 3, device=DEV)
         hip.check(lib.pg_posterior_position(z.data_ptr(), z.data_ptr(), rg.data_ptr(), tt.data_ptr(), zero_tab.data_ptr(),
-                                            zero_tab.data_ptr(), one_tab.data_ptr(), None, None, 77, 2, step, n, None,
-                                            out.data_ptr(), None, hip.stream_ptr()), 'posterior(pos)')
+                                            zero_tab.data_ptr(), one_tab.data_ptr(), None, None, 77, 2, step, n, None, None,
+                                            None, out.data_ptr(), None, hip.stream_ptr()), 'posterior(pos)')
         outs.append(out.cpu().numpy().astype(np.float64).ravel())
     e = outs[0]
     assert np.isfinite(e).all()
@@ -94,8 +94,8 @@ def test_gumbel_argmax_frequencies_follow_the_posterior():
     tt = torch.full((1,), 400, dtype=torch.int64, device=DEV)
     post, onehot = torch.empty(n, K, device=DEV), torch.empty(n, K, device=DEV)
     hip.check(lib.pg_posterior_categorical(logits.data_ptr(), log_vt.data_ptr(), rg.data_ptr(), tt.data_ptr(), qm.data_ptr(),
-                                           qt.data_ptr(), n, K, None, 2024, 0, 400, post.data_ptr(), onehot.data_ptr(), None,
-                                           hip.stream_ptr()), 'posterior(node)')
+                                           qt.data_ptr(), n, K, None, 2024, 0, 400, None, None, post.data_ptr(), onehot.data_ptr(),
+                                           None, hip.stream_ptr()), 'posterior(node)')
     torch.cuda.synchronize()
     p = post[0].double().exp().cpu().numpy()
     assert abs(p.sum() - 1) < 1e-5 and (onehot.sum(-1) == 1).all()
