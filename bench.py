@@ -85,6 +85,11 @@ def subset_workload(w, graph_ids):
                 batch_phore=remap[w['batch_phore'][keep]], num_atoms=w['num_atoms'][graph_ids], n_phore=w['n_phore'][graph_ids])
 
 
+def triplet_tiles(n_at):
+    """16-row tiles the triplet kernel walks per segment of a ligand with n atoms (rows = the n atoms, 2 of them masked)."""
+    return (n_at + 15) // 16
+
+
 def algorithmic_counts(n_at, n_ph, knn=32, H=128):
     """Per-step algorithmic work: sizes, GEMM FLOPs of the factored form, compulsory HBM bytes."""
     n_all = int((n_at + n_ph).sum())
@@ -102,16 +107,19 @@ def algorithmic_counts(n_at, n_ph, knn=32, H=128):
     step_b = 6 * layer_b + 4 * (81 * n_lig + 36 * e_bond)
     # what the triplet kernel actually executes after folding the second key/value layers:
     # 112 MFMA 16x16x4 (2048 FLOP) per 16-row tile + per-segment fold/unfold (2 x 128x128 MACs) + Q (2 x 20x128 MACs)
-    tiles = int((((n_at + 15) // 16) * n_at * (n_at - 1)).sum())
+    tiles = int((triplet_tiles(n_at) * n_at * (n_at - 1)).sum())
     tri_exec = tiles * 112 * 2048 + e_bond * (2 * 2 * H * H + 2 * 2 * 20 * H)
     return dict(n_all=n_all, n_lig=n_lig, e_knn=e_knn, e_bond=e_bond, e3=e3, flops_step=6 * layer_f,
-                flops_triplet_kernel=tri_kernel, flops_triplet_executed=tri_exec, tri_tiles=tiles, bytes_step=step_b)
+                flops_triplet_kernel=tri_kernel, flops_triplet_executed=tri_exec, tri_tiles=tiles, bytes_step=step_b,
+                tri_useful_rows=e3, tri_padded_rows=16 * tiles)
 
 
 # ---------------------------------------------------------------------------- CPU baseline (oracle, bounded sample)
-def cpu_baseline(work, n_sample_graphs=4, n_steps=2, max_threads=16):
-    """Reference-dataflow CPU path (oracle/phoregen_oracle.py, pinned to the reference by tests/golden) timed on the
-    host cores for a few graphs of the same workload, scaled linearly in graphs to the 128-graph batch."""
+def cpu_baseline(work, n_sample_graphs=8, n_steps=3, max_threads=16):
+    """Reference-dataflow CPU path (oracle/phoregen_oracle.py: unfactored, materialised [E3,437] tensors, fp32; pinned to
+    the reference by tests/golden) timed on the host cores: SURVEY 8(d)'s K = 3 steps on a sub-batch, scaled linearly in
+    graphs to the 128-graph batch.  The sub-batch is bounded by TIME, not by RAM: 8 graphs x 3 steps is ~20-30 s of host
+    work, the budget a default bench run can afford (B = 32 would fit host RAM but takes minutes)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from helpers import make_oracle
     from oracle import phoregen_oracle as po
@@ -121,6 +129,7 @@ def cpu_baseline(work, n_sample_graphs=4, n_steps=2, max_threads=16):
     cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
     o = make_oracle(0)
+    n_sample_graphs = min(n_sample_graphs, int(work['num_atoms'].numel()))
     sel = torch.arange(n_sample_graphs)
     na = work['num_atoms'][sel]
     keep = work['batch_phore'] < n_sample_graphs
@@ -128,64 +137,102 @@ def cpu_baseline(work, n_sample_graphs=4, n_steps=2, max_threads=16):
     g = torch.Generator().manual_seed(7)
     bn = torch.repeat_interleave(torch.arange(n_sample_graphs), na)
     ei, be = po.make_edge_data(na)
-    hn = F.one_hot(torch.full((int(na.sum()),), 11), 12).float()
-    he = F.one_hot(torch.zeros(ei.size(1), dtype=torch.long), 6).float()
-    pos = torch.randn(int(na.sum()), 3, generator=g)
+    N, E = int(na.sum()), ei.size(1)
+    hn = F.one_hot(torch.full((N,), 11), 12).float()
+    he = F.one_hot(torch.zeros(E, dtype=torch.long), 6).float()
+    pos = torch.randn(N, 3, generator=g)
+    log_n, log_e = torch.log(hn.clamp(min=1e-30)), torch.log(he.clamp(min=1e-30))
     t0 = None
     with torch.no_grad():
-        for s in range(n_steps + 1):
+        for s in range(n_steps + 1):                       # one reverse step = forward + the three posteriors
             if s == 1:
                 t0 = time.perf_counter()
             tt = torch.full((n_sample_graphs,), 999 - s)
-            o.forward(hn, pos, bn, he, ei, be, tt, hp, pp, pn, bp)
+            v, x0, bond, _ = o.forward(hn, pos, bn, he, ei, be, tt, hp, pp, pn, bp)
+            log_n = po.q_v_posterior(o.tab_node, F.log_softmax(v, -1), log_n, tt, bn)
+            hn = F.one_hot(po.gumbel_argmax(log_n, torch.rand(N, 12, generator=g)), 12).float()
+            log_e = po.q_v_posterior(o.tab_edge, F.log_softmax(bond, -1), log_e, tt, be)
+            he = F.one_hot(po.gumbel_argmax(log_e, torch.rand(E, 6, generator=g)), 6).float()
+            pos = po.pos_prev_from_recon(o.tab_pos, pos, x0, tt, bn, torch.randn(N, 3, generator=g))
     dt = (time.perf_counter() - t0) / n_steps
     graph_steps = n_sample_graphs / dt
     return dict(value=graph_steps / 128.0, unit='denoise-steps/s (128-graph batch)', cores=cores, kind='port',
-                sample=f'{n_steps} timed forwards (+1 warm-up) of oracle/phoregen_oracle.py on the first {n_sample_graphs} graphs '
-                       f'({int(na.sum())} atoms) of the workload, {dt:.2f} s/forward, scaled linearly to 128 graphs')
+                sample=f'K = {n_steps} timed reverse steps (+1 warm-up) of oracle/phoregen_oracle.py on the first {n_sample_graphs} '
+                       f'graphs ({N} atoms, {E} bond edges) of the workload, {dt:.2f} s/step, scaled linearly to 128 graphs')
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child (one process per
+    GPU) from this still GPU-free parent and hand its exit code on.  Nothing here may initialise HIP."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _traffic_record(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc passes, gfx950 corrections
+    of MI355X_MICROARCH.md applied by tools/pmc_summary.py).  A bench run cannot read PMC counters itself, so the figure is
+    labelled with where it came from and dropped when it was recorded for another kernel."""
+    path = os.path.join(ROOT, 'profiles', 'triplet_traffic.json')
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None, None
+    if not str(rec.get('kernel', '')).startswith(kernel_prefix):
+        return None, {'file': 'profiles/triplet_traffic.json', 'note': f"recorded for {rec.get('kernel')!r}, not for the kernel timed here"}
+    src = {k: rec.get(k) for k in ('kernel', 'commit', 'workload', 'fetch_bytes_x2', 'write_bytes', 'method') if k in rec}
+    src['file'] = 'profiles/triplet_traffic.json'
+    return rec.get('hbm_bytes_per_launch'), src
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=3, help='timed blocks of --steps steps each; the median block is reported')
     ap.add_argument('--graphs', type=int, default=128)
     ap.add_argument('--fixed-shape', action='store_true', help='n=40, p=107 for every graph (closed-form counts)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--strong', action='store_true',
-                    help='strong scaling (SURVEY.md 8d): ONE batch of --graphs graphs partitioned over the ranks by n^3 cost')
+    ap.add_argument('--weak', action='store_true',
+                    help='weak scaling only: --graphs graphs PER GPU (default: strong scaling, SURVEY.md 8d: ONE batch of '
+                         '--graphs graphs partitioned over the ranks by n^3 cost; a weak-scaling figure is added for N > 1)')
+    ap.add_argument('--strong', action='store_true', help='(default) kept for compatibility')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(_spawn_ranks(args.gpus))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    local = local % max(torch.cuda.device_count(), 1)     # (a 2-rank gloo dry run can share one GPU)
+    n_dev = max(torch.cuda.device_count(), 1)
+    local = local % n_dev                                  # (a 2-rank gloo dry run can share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(os.environ.get('PG_DIST_BACKEND', 'nccl'))    # nccl == RCCL on ROCm
+        backend = os.environ.get('PG_DIST_BACKEND', 'nccl')                   # nccl == RCCL on ROCm
+        dist.init_process_group(backend)
 
     from phoregen_amd.config import default_model_config
     from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.parallel import gather_predictions, partition_graphs
     from phoregen_amd.weights import init_deterministic_
 
     model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to(dev)
-    total_graphs = args.graphs if args.strong else world * args.graphs
-    if args.strong and world > 1:
-        from phoregen_amd.parallel import partition_graphs
-        full = ligphore_workload(args.graphs, seed=1234, fixed_shape=args.fixed_shape)
-        mine = partition_graphs(full['num_atoms'], world)[rank]
-        work = subset_workload(full, mine)
-        args.graphs = int(mine.numel())
-    else:
-        work = ligphore_workload(args.graphs, seed=1234 + rank, fixed_shape=args.fixed_shape)   # each rank: its own graphs
-    counts = algorithmic_counts(work['num_atoms'], work['n_phore'])
-    K, W = args.steps, args.warmup
-    st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm'], work['batch_phore'],
-                              work['num_atoms'], torch.zeros(args.graphs, 3), rng='device', seed=rank, return_traj=True,
-                              num_steps=K + W)
+    K, W, R = args.steps, args.warmup, max(args.repeats, 1)
     T = model.num_timesteps
 
     def barrier():
@@ -194,72 +241,113 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(W):
-        model.reverse_step(st, i, T - 1 - i)
-    barrier()
-    st.eng.timers = {}
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        model.reverse_step(st, i, T - 1 - i)
-    barrier()
-    dt = time.perf_counter() - t0
-    tri_ms = st.eng.kernel_ms('triplet')
-    st.eng.timers = None
-    res = model.finish_sampling(st)
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device='cpu' if backend == 'gloo' else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run(work, gids, time_triplet):
+        """W warm-up steps, then R blocks of exactly K steps, each bracketed by barrier + synchronize; per-block wall time
+        is the MAX over ranks.  Returns (block times [R], triplet launch durations, final result dict)."""
+        st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm'], work['batch_phore'],
+                                  work['num_atoms'], torch.zeros(int(work['num_atoms'].numel()), 3), rng='device', seed=0,
+                                  return_traj=True, num_steps=W + R * K, graph_ids=gids)
+        for i in range(W):
+            model.reverse_step(st, i, T - 1 - i)
+        times, tri = [], []
+        i = W
+        for r in range(R):
+            barrier()
+            if time_triplet:
+                st.eng.timers = {}
+            t0 = time.perf_counter()
+            for _ in range(K):
+                model.reverse_step(st, i, T - 1 - i)
+                i += 1
+            barrier()
+            times.append(max_over_ranks(time.perf_counter() - t0))
+            if time_triplet:
+                tri += st.eng.kernel_ms('triplet')
+                st.eng.timers = None
+        return times, tri, model.finish_sampling(st)
+
+    # ---- strong scaling (headline): ONE batch of --graphs graphs, partitioned over the ranks by n^3 cost ----
+    full = ligphore_workload(args.graphs, seed=1234, fixed_shape=args.fixed_shape)
+    if args.weak:
+        work = ligphore_workload(args.graphs, seed=1234 + rank, fixed_shape=args.fixed_shape)   # each rank: its own graphs
+        mine = torch.arange(args.graphs) + rank * args.graphs
+        total_graphs = world * args.graphs
+    else:
+        mine = partition_graphs(full['num_atoms'], world)[rank]
+        work = subset_workload(full, mine) if world > 1 else full
+        total_graphs = args.graphs
+    counts = algorithmic_counts(work['num_atoms'], work['n_phore'])
+    times, tri_ms, res = run(work, mine, time_triplet=True)
+    order = sorted(range(R), key=lambda r: times[r])
+    dt = times[order[R // 2]]                              # median block
 
     # the one collective of the path: re-assemble `pred` of all ranks (phoregen_amd/parallel.py), after the timed loop
     gather_ms = None
     if world > 1:
-        from phoregen_amd.parallel import gather_predictions
         tg = time.perf_counter()
-        gids = mine if (args.strong and world > 1) else torch.arange(args.graphs) + rank * args.graphs
-        gather_predictions(res['pred'], work['num_atoms'], gids)
+        gather_predictions(res['pred'], work['num_atoms'], mine)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
-    tmax = torch.tensor([dt], device=dev if (world == 1 or dist.get_backend() != 'gloo') else 'cpu')
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+
+    # ---- secondary figure for N > 1: weak scaling, --graphs graphs per GPU ----
+    weak = None
+    if world > 1 and not args.weak:
+        wwork = ligphore_workload(args.graphs, seed=1234 + rank, fixed_shape=args.fixed_shape)
+        wt, _, _ = run(wwork, torch.arange(args.graphs) + rank * args.graphs, time_triplet=False)
+        wdt = sorted(wt)[R // 2]
+        weak = {'graphs_per_gpu': args.graphs, 'ms_per_step': wdt / K * 1e3, 'graph_steps_per_sec': K * world * args.graphs / wdt,
+                'batch_steps_per_sec': world * K / wdt}
 
     if rank == 0:
         peak_tf = 157.3                      # fp32 MFMA dense peak, MI355X_MICROARCH.md "Chip-level parameters"
         tri_avg_ms = sum(tri_ms) / max(len(tri_ms), 1)
-        achieved = counts['flops_triplet_kernel'] / (tri_avg_ms * 1e-3) / 1e12 if tri_ms else None
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'triplet_traffic.json')
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        exec_tf = counts['flops_triplet_executed'] / (tri_avg_ms * 1e-3) / 1e12 if tri_ms else None
+        alg_tf = counts['flops_triplet_kernel'] / (tri_avg_ms * 1e-3) / 1e12 if tri_ms else None
+        traffic, traffic_src = _traffic_record('pg::triplet')
+        scale = 1.0 if not args.weak else float(world)
         line = {
-            'metric': 'denoise-steps/sec (batch=128, ~40-atom graphs)', 'value': (1 if args.strong else world) * K / dt, 'unit': 'steps/s',
+            'metric': 'denoise-steps/sec (batch=128, ~40-atom graphs)', 'value': scale * K / dt, 'unit': 'steps/s',
             'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': dt / K * 1e3, 'higher_is_better': True,
-            'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[2]: 128 LigPhore-shaped graphs per GPU '
-                                   '(n~N(40,6) atoms, p~N(107,30) pharmacophore nodes), steps t=999.. of the 1000-step sampler, '
-                                   'device Philox noise, trajectory written',
-                       'graphs_per_gpu': args.graphs, 'fixed_shape': args.fixed_shape, 'n_ctx': counts['n_all'],
-                       'n_lig': counts['n_lig'], 'e_knn': counts['e_knn'], 'e_bond': counts['e_bond'], 'e3': counts['e3'],
-                       'parallelism': f'graph-sharded x{world}, final RCCL gather only'},
+            'scaling': 'weak' if args.weak else 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE.json configs[2]: ONE batch of {args.graphs} LigPhore-shaped graphs '
+                                   '(n~N(40,6) atoms, p~N(107,30) pharmacophore nodes)' +
+                                   (' per GPU' if args.weak else f', partitioned over {world} GPU(s) by n^3 cost') +
+                                   ', steps t=999.. of the 1000-step sampler, device Philox noise, trajectory written',
+                       'graphs_total': total_graphs, 'graphs_rank0': int(work['num_atoms'].numel()), 'fixed_shape': args.fixed_shape,
+                       'n_ctx': counts['n_all'], 'n_lig': counts['n_lig'], 'e_knn': counts['e_knn'], 'e_bond': counts['e_bond'],
+                       'e3': counts['e3'], 'parallelism': f'graph-sharded x{world}, final RCCL gather only'},
+            'repeats': R, 'repeats_ms_per_step': [t / K * 1e3 for t in times], 'statistic': 'median block of `repeats` blocks of `steps` steps',
             'graph_steps_per_sec': K * total_graphs / dt,
-            'roofline': {'kernel': 'triplet_kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 launches/step)', 'bound': 'mfma',
-                         'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
-                         'frac': (achieved / peak_tf) if achieved else None, 'traffic': traffic,
+            'ranks': world, 'distinct_devices': min(world, n_dev), 'dist_backend': backend,
+            'roofline': {'kernel': 'triplet kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 launches/step), rank 0',
+                         'bound': 'mfma', 'achieved': exec_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
+                         'frac': (exec_tf / peak_tf) if exec_tf else None, 'traffic': traffic, 'traffic_source': traffic_src,
                          'avg_launch_ms': tri_avg_ms, 'launches_timed': len(tri_ms),
-                         'algorithmic_flops_per_launch': counts['flops_triplet_kernel'],
-                         'note': 'achieved/frac use SURVEY 8d algorithmic FLOPs (unfolded second layers); the kernel executes '
-                                 'executed_flops_per_launch after folding them, see executed_frac',
-                         'executed_flops_per_launch': counts['flops_triplet_executed'],
-                         'executed_frac': (counts['flops_triplet_executed'] / (tri_avg_ms * 1e-3) / 1e12 / peak_tf) if tri_ms else None,
+                         'flops_per_launch': counts['flops_triplet_executed'],
+                         'note': 'achieved = fp32 FLOPs the kernel EXECUTES per launch (112 MFMA 16x16x4 per 16-row tile + query fold / '
+                                 'value unfold + Q, padding rows included) / mean launch duration (HIP events on the launch stream). '
+                                 'SURVEY 8d counts the unfolded second layers the kernel never runs: see survey_* (can exceed 1).',
+                         'useful_frac': (exec_tf / peak_tf * counts['tri_useful_rows'] / counts['tri_padded_rows']) if exec_tf else None,
+                         'survey_flops_per_launch': counts['flops_triplet_kernel'], 'survey_achieved': alg_tf,
+                         'survey_frac': (alg_tf / peak_tf) if alg_tf else None,
                          'share_of_step': (6 * tri_avg_ms) / (dt / K * 1e3) if tri_ms else None},
-            'step_roofline': {'flops_alg': counts['flops_step'], 'bytes_alg': counts['bytes_step'],
-                              'mfma_frac': counts['flops_step'] / (dt / K) / (peak_tf * 1e12),
-                              'hbm_frac': counts['bytes_step'] / (dt / K) / 8e12},
+            'step_roofline': {'flops_alg_survey': counts['flops_step'], 'bytes_alg': counts['bytes_step'],
+                              'survey_mfma_frac': counts['flops_step'] / (dt / K) / (peak_tf * 1e12),
+                              'hbm_frac': counts['bytes_step'] / (dt / K) / 8e12,
+                              'note': 'rank-0 share of the batch; survey_mfma_frac uses SURVEY 8d FLOPs (unfolded form) and is not a '
+                                      'utilisation; the step is fp32-issue-bound, not HBM-bound (AI ~ 3000 FLOP/B)'},
+            'weak_scaling': weak,
             'final_gather_ms': gather_ms,
         }
-        if not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(ligphore_workload(args.graphs, seed=1234, fixed_shape=args.fixed_shape))
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(full)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
