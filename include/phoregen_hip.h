@@ -156,6 +156,11 @@ typedef struct {
   float* dx;                 /* pos modes: [n_ctx,3]                                              */
   int accumulate_dx;         /* pos modes: dx += instead of =                                     */
   float* alpha; int alpha_rows; /* triplet S-form, optional: softmax weights out [n_bond][alpha_rows][16] (training)  */
+  /* PG_SEG_PHORE, optional: the scalar edge feature given explicitly instead of computed as |x_dst - x_src| (the standalone
+   * NodeUpdateLayer.forward(h, edge_feat, edge_index) of models/uni_denoiser.py:40-72 receives it from its caller):
+   * efeat[efeat_off[g] + src_local * p_g + dst_local] for graph g with p_g nodes = the order of
+   * fully_connect_two_graphs (models/common.py:329-356).  NULL: distances from `x`. */
+  const float* efeat; const int* efeat_off;
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 

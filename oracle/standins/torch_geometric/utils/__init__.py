@@ -8,3 +8,11 @@ def remove_self_loops(edge_index, edge_attr=None):
 
 def k_hop_subgraph(*a, **k):
     raise NotImplementedError
+
+
+def to_dense_adj(*a, **k):          # imported at module scope by datasets/phoregen.py (training dataset), never called here
+    raise NotImplementedError
+
+
+def dense_to_sparse(*a, **k):
+    raise NotImplementedError

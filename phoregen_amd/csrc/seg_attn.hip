@@ -276,8 +276,13 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
       } else if constexpr (T::PH) {
         float d = 0.f;
         if (rk.valid) {
-          const float r0 = xd[0] - p.x[rk.src * 3], r1 = xd[1] - p.x[rk.src * 3 + 1], r2 = xd[2] - p.x[rk.src * 3 + 2];
-          d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+          if (p.efeat) {
+            const int gi = t.ctx_graph[s.seg];
+            d = p.efeat[(size_t)p.efeat_off[gi] + (size_t)(rk.src - s.first) * s.n_rows + (s.seg - s.first)];
+          } else {
+            const float r0 = xd[0] - p.x[rk.src * 3], r1 = xd[1] - p.x[rk.src * 3 + 1], r2 = xd[2] - p.x[rk.src * 3 + 2];
+            d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+          }
         }
         feat[0] = g == 0 ? d : 0.f;
       }

@@ -26,7 +26,7 @@ def _f(*shape, device, zero=False):
 
 
 class Engine:
-    def __init__(self, pack: ModelPack, plan, knn_k=32, full=True):
+    def __init__(self, pack: ModelPack, plan, knn_k=32, full=True, phore_only=False):
         self.lib = hip.lib()
         self.pack, self.plan, self.k = pack, plan, knn_k
         self.dev = plan.device
@@ -48,7 +48,8 @@ class Engine:
         self._alloc()
         if full:
             self.prog_phore = self._build_phore_program()
-            self.prog_fwd = self._build_forward_program()
+            if not phore_only:                       # (sample_nodes: pharmacophore encoder + count heads only)
+                self.prog_fwd = self._build_forward_program()
 
     # ------------------------------------------------------------------ workspace
     def _alloc(self):
@@ -168,7 +169,7 @@ class Engine:
         self._keep += [s, seg_ids, a]
         self._call(prog, self.lib.pg_seg_attn, self.plan.topo_ref, C.byref(s))
 
-    def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None, buf=0):
+    def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None, buf=0, extra=None):
         """Shared tail of the four node-target sub-layers.  Y[:, col0 + 128*b] blocks: k_dst, v_dst, k_src, v_src, q_hid."""
         w, p, n = self.ws, self.plan, self.plan.n_ctx
         wq, wU, wS, wsw = w.q[buf], w.U[buf], w.S[buf], w.swn[buf]
@@ -196,6 +197,8 @@ class Engine:
                 kw.update(W2xv_l=a.W2xv_l, b2xv=a.b2xv, dx=dx, accumulate_dx=0)
             else:
                 kw.update(S=wS, swn=wsw)
+            if extra:
+                kw.update(extra)
             self._seg(prog, mode, n_seg, seg_ids, a, **kw)
             if not pos:
                 self._call(prog, self.lib.pg_attn_unfold_value, wS.data_ptr(), wsw.data_ptr(), a.W2v_l.data_ptr(),
@@ -406,6 +409,50 @@ def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, b
     if return_all:
         out.update(all_x=[x, out['x']], all_h=[h, out['h']], all_h_bond=[h_bond, out['h_bond']])
     return out
+
+
+def phore_encoder_standalone(module, h, edge_feat, edge_index, e_w=None):
+    """Entry used by models.uni_denoiser.NodeUpdateLayer.forward for the pharmacophore-encoder configuration
+    (models/__init__.py:29-35: edge_feat_dim = 1, no out_fc; called at models/diffusion.py:186-191 with the edges of
+    fully_connect_two_graphs and the distance as the edge feature).  Runs the PG_SEG_PHORE program on the given `h` with
+    the caller's edge feature (PgSegAttn.efeat)."""
+    from .packing import fuse_blocks, pack_phore
+    from .plan import BatchPlan
+    dev = h.device
+    if dev.type != 'cuda':
+        raise RuntimeError('phoregen_amd: NodeUpdateLayer.forward runs on the MI355X HIP path only (no CPU fallback)')
+    if e_w is not None or edge_feat.dim() != 2 or edge_feat.size(1) != 1:
+        raise NotImplementedError('phoregen_amd: NodeUpdateLayer.forward is callable in the pharmacophore-encoder form '
+                                  '(one scalar edge feature, no edge gate); inside the denoiser it is fused into the layer')
+    N = h.size(0)
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    # fully_connect_two_graphs(batch, batch): all (i, j) of equal graph id, row-major, self pairs kept (common.py:329-356)
+    first = torch.full((N,), N, dtype=torch.long, device=dev).scatter_reduce_(0, src, dst, 'amin')
+    deg = torch.zeros(N, dtype=torch.long, device=dev).index_add_(0, src, torch.ones_like(src))
+    starts = torch.unique_consecutive(first)
+    batch = torch.searchsorted(starts, first, right=True) - 1
+    sizes = torch.bincount(batch, minlength=starts.numel())
+    if int((sizes * sizes).sum()) != src.numel() or not torch.equal(deg, sizes[batch]) or \
+            not torch.equal(src, torch.repeat_interleave(torch.arange(N, device=dev), deg)):
+        raise NotImplementedError('phoregen_amd: NodeUpdateLayer.forward expects the edges of fully_connect_two_graphs '
+                                  '(every ordered pair of nodes of a graph, self pairs included, grouped by source)')
+    B = int(starts.numel())
+    z = torch.zeros(0, dtype=torch.long)
+    plan = BatchPlan(z, batch.cpu(), torch.zeros(2, 0, dtype=torch.long), z, B, dev)
+    eng = Engine(None, plan, full=False)
+    sd = {'phore_encoder.' + k: v.detach() for k, v in module.state_dict().items()}
+    PH, blocks = pack_phore(sd)
+    W_ph, b_ph = fuse_blocks(blocks)
+    w = eng.ws
+    off = torch.zeros(B + 1, dtype=torch.long, device=dev)
+    off[1:] = (sizes * sizes).cumsum(0)
+    efeat, efeat_off = edge_feat.detach().float().contiguous().view(-1), off.to(torch.int32)
+    prog = []
+    eng._gemm(prog, h.detach().float().contiguous(), 128, W_ph, w.Yp, N, 640, bias=b_ph)
+    eng._node_attention(prog, hip.SEG_PHORE, PH, w.Yp, 0, w.x_phore_ctx, [(plan.phore2ctx, plan.n_phore, False)],
+                        out=w.enc_ctx, extra=dict(efeat=efeat, efeat_off=efeat_off))
+    eng._run(prog)
+    return w.enc_ctx.clone()
 
 
 class _DenoiserOnlyPack(ModelPack):

@@ -44,7 +44,7 @@ class PgSegAttn(C.Structure):
                 ('U', c_fp), ('q', c_fp), ('W2k_l', c_fp), ('W2v_l', c_fp), ('b2v', c_fp),
                 ('W2xv_l', c_fp), ('b2xv', c_fp),
                 ('S', c_fp), ('swn', c_fp), ('resid', c_fp), ('out', c_fp), ('dx', c_fp),
-                ('accumulate_dx', C.c_int), ('alpha', c_fp), ('alpha_rows', C.c_int)]
+                ('accumulate_dx', C.c_int), ('alpha', c_fp), ('alpha_rows', C.c_int), ('efeat', c_fp), ('efeat_off', c_ip)]
 
 
 class PgSegAttnGrad(C.Structure):
@@ -107,7 +107,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get('PHOREGEN_HIP_LIB') or LIB_PATH       # (PHOREGEN_HIP_LIB: an experiment build, tools/)
     if not os.path.exists(path):
         raise RuntimeError(f'phoregen_amd: HIP extension not built: {path} is missing. '
                            f'Run `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '

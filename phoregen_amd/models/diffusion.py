@@ -116,6 +116,7 @@ class PhoreDiff(nn.Module):
         self._pack_version = None
         self._plan = None
         self._engine = None
+        self._count_engine = None
 
     # ------------------------------------------------------------------ engine plumbing
     def __deepcopy__(self, memo):
@@ -124,7 +125,7 @@ class PhoreDiff(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            object.__setattr__(new, k, None if k in ('_pack', '_pack_version', '_plan', '_engine') else copy.deepcopy(v, memo))
+            object.__setattr__(new, k, None if k in ('_pack', '_pack_version', '_plan', '_engine', '_count_engine') else copy.deepcopy(v, memo))
         return new
 
     @property
@@ -151,7 +152,7 @@ class PhoreDiff(nn.Module):
         """Drop the kernel-layout weight cache.  `packed()` notices optimizer steps and `.to()` through the parameters'
         version counters; writes through `param.data` (EMA swaps, weight surgery) do not bump them -- call this after such
         a write.  `load_state_dict` and `_apply` (`.to`, `.cuda`, `.float`) call it themselves."""
-        self._pack = self._pack_version = self._engine = None
+        self._pack = self._pack_version = self._engine = self._count_engine = None
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
@@ -283,9 +284,13 @@ class PhoreDiff(nn.Module):
     def sample_nodes(self, data, batch_size, device, sample_mode='uniform', normal_scale=4.0):
         ph = data['phore']
         p = ph.x.size(0)
-        z = torch.zeros(0, dtype=torch.long)
-        plan = BatchPlan(z, torch.zeros(p, dtype=torch.long), torch.zeros(2, 0, dtype=torch.long), z, 1, self._device())
-        eng = Engine(self.packed(), plan, knn_k=self.denoiser.k)
+        pack = self.packed()
+        eng = self._count_engine
+        if eng is None or eng.pack is not pack or eng.plan.n_phore != p:
+            # pharmacophore-only plan (no ligand yet); kept for the next call: sample_all.py draws counts once per batch
+            z = torch.zeros(0, dtype=torch.long)
+            plan = BatchPlan(z, torch.zeros(p, dtype=torch.long), torch.zeros(2, 0, dtype=torch.long), z, 1, self._device())
+            eng = self._count_engine = Engine(pack, plan, knn_k=self.denoiser.k, phore_only=True)
         eng.encode_phore(ph.x.to(self._device()), ph.pos.to(self._device()), ph.norm.to(self._device()), self.ex_col)
         span = self.max_atom - self.min_atom
         lo = int((eng.ws.count_l * span + self.min_atom).round().int().item())

@@ -22,6 +22,17 @@ class NodeUpdateLayer(nn.Module):
         self.hk_func = MLP(kv, output_dim, hidden_dim)
         self.hv_func = MLP(kv, output_dim, hidden_dim)
         self.hq_func = MLP(input_dim, output_dim, hidden_dim)
+        self.edge_feat_dim = edge_feat_dim
+
+    def forward(self, h, edge_feat, edge_index, e_w=None):
+        """uni_denoiser.py:40-72.  Callable in the configuration the reference calls on its own -- the pharmacophore
+        encoder (models/__init__.py:29-35, diffusion.py:186-191: fully connected graphs, scalar distance feature);
+        the instances inside the denoiser layers are fused into the layer kernels and are not callable alone."""
+        if self.edge_feat_dim != 1:
+            raise NotImplementedError('phoregen_amd: this NodeUpdateLayer is fused into the denoiser layer kernels; only the '
+                                      'pharmacophore-encoder form (edge_feat_dim=1) is callable on its own')
+        from ..engine import phore_encoder_standalone
+        return phore_encoder_standalone(self, h, edge_feat, edge_index, e_w)
 
 
 class BondUpdateLayer(nn.Module):

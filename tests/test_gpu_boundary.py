@@ -1,0 +1,132 @@
+"""-m gpu: the drop-in boundary as the reference's callers use it: the `sample_all.py:79-116` sequence
+(`sample()` with its own atom-count draw, `.cpu()`, `unbatch_data`, `decode_data`), the callable pharmacophore encoder,
+per-graph centres in the trajectory, and the out-of-memory message contract (`sample_all.py:95-99`)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, make_oracle, rel_err, t
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def model():
+    from phoregen_amd.config import default_model_config
+    from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.weights import init_deterministic_
+    return init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to(DEV)
+
+
+def test_sample_all_caller_sequence(model):
+    """sample_all.py:79-116 on tests/data/synthetic_test.phore: `model.sample(data, n_graphs, device, ...)` WITHOUT
+    num_atoms (sample_nodes + sample_from_interval draw, diffusion.py:356-387), everything `.cpu()`, unbatch_data ->
+    decode_data per graph; and decode_batch (device argmax + one copy) must give exactly those molecules."""
+    from phoregen_amd.data import parse_phore_file
+    from phoregen_amd.utils.sample_utils import decode_batch, decode_data, unbatch_data
+    data = parse_phore_file(os.path.join(ROOT, 'tests', 'data', 'synthetic_test.phore')).to(DEV)
+    n_graphs = 5
+    # the count heads against the oracle: the interval sample_nodes draws from
+    o = make_oracle(0)
+    ph = data['phore']
+    p = ph.x.size(0)
+    from oracle import phoregen_oracle as po
+    import torch.nn.functional as F
+    ei, be = po.make_edge_data(torch.tensor([2]))
+    with torch.no_grad():      # the count heads see only the pharmacophore (diffusion.py:148-163): any ligand will do
+        _, _, _, (cl, cu) = o.forward(F.one_hot(torch.tensor([0, 1]), 12).float(), torch.zeros(2, 3), torch.zeros(2, dtype=torch.long),
+                                      F.one_hot(torch.tensor([0, 0]), 6).float(), ei, be, torch.tensor([500]), ph.x.cpu(),
+                                      ph.pos.cpu(), ph.norm.cpu(), torch.zeros(p, dtype=torch.long))
+    torch.manual_seed(2032)                                            # seed_all(args.seed), sample_all.py:33
+    na_draw = model.sample_nodes(data, 64, DEV)
+    eng = model._count_engine
+    lo = int((eng.ws.count_l * 74 + 4).round().item())
+    hi = int((eng.ws.count_u * 74 + 4).round().item())
+    assert 4 <= lo <= hi <= 78 and int(na_draw.min()) >= lo and int(na_draw.max()) <= hi
+    assert model.sample_nodes(data, 3, DEV) is not None and model._count_engine is eng          # one engine, reused
+    assert abs(float(cl) - float(eng.ws.count_l)) <= 2e-5 and abs(float(cu) - float(eng.ws.count_u)) <= 2e-5
+    assert lo == int((cl * 74 + 4).round().item()) and hi == int((cu * 74 + 4).round().item())
+    torch.manual_seed(2032)
+    results = model.sample(data, n_graphs, DEV, pos_guidance_opt=None, sample_mode='uniform', normal_scale=4.0, num_steps=12)
+    assert set(results) == {'pred', 'traj', 'lig_info'}
+    na = results['lig_info'][0]
+    assert na.numel() == n_graphs and int(na.min()) >= lo and int(na.max()) <= hi
+    dev_mols = decode_batch(results, include_bond=True)                 # on the device tensors
+    results = {key: [v.cpu() for v in value if v is not None] for key, value in results.items()}     # sample_all.py:102
+    outs = unbatch_data(results, n_graphs, include_bond=True)
+    assert len(outs) == n_graphs
+    N = int(na.sum())
+    assert results['traj'][1].shape == (13, N, 3) and results['pred'][0].shape == (N, 12)
+    for o_g, n, dm in zip(outs, na.tolist(), dev_mols):
+        assert o_g['pred'][0].shape == (n, 12) and o_g['edge_index'].shape == (2, n * (n - 1))
+        assert int(o_g['edge_index'].min()) == 0 and int(o_g['edge_index'].max()) == n - 1
+        mol = decode_data(pred_info=o_g['pred'], edge_index=o_g['edge_index'], include_bond=True)   # sample_all.py:109-113
+        assert mol['element'] == dm['element']
+        assert torch.equal(mol['atom_pos'], dm['atom_pos'])
+        assert torch.equal(mol['bond_type'], dm['bond_type']) and torch.equal(mol['bond_index'], dm['bond_index'])
+        assert np.isfinite(mol['atom_pos'].numpy()).all()
+
+
+def test_phore_encoder_is_callable_like_the_reference(model):
+    """diffusion.py:185-191: `self.phore_encoder(h_phore_emb, dist_feat, f_edge_index_p)` with the edges of
+    fully_connect_two_graphs; result against the reference's recorded encoder output (G3 fixtures)."""
+    for name in ('g3_forward_a', 'g3_forward_b'):
+        g = golden(name)
+        h_phore, pos, bp = (t(g[k]).to(DEV) for k in ('in_h_phore', 'in_pos_phore', 'in_batch_phore'))
+        with torch.no_grad():
+            h_emb = model.phore_embedding(h_phore)
+            same = bp[:, None] == bp[None, :]
+            src, dst = same.nonzero(as_tuple=True)                     # fully_connect_two_graphs(batch, batch)
+            dist = torch.norm(pos[dst] - pos[src], p=2, dim=-1, keepdim=True)
+            out = model.phore_encoder(h_emb, dist, torch.stack([src, dst]))
+        assert out.shape == h_emb.shape
+        assert rel_err(out.cpu(), g['phore_enc']) <= 2e-5, name
+    with pytest.raises(NotImplementedError):
+        model.denoiser.base_block[0].node_layer_with_bond(h_emb, dist, torch.stack([src, dst]))
+
+
+def test_trajectory_with_per_graph_centres(model):
+    """Multi-pharmacophore batches (f-2) return trajectories: frame k of graph g = its ligand-frame state + centre g."""
+    from oracle.make_inputs import synthetic_phore
+    gen = torch.Generator().manual_seed(12)
+    phs = [synthetic_phore(gen, p) for p in (20, 31, 25)]
+    na = torch.tensor([7, 10, 6])
+    bp = torch.cat([torch.full((x.size(0),), i) for i, (x, _, _) in enumerate(phs)])
+    centers = torch.tensor([[1.0, -2.0, 3.0], [10.0, 0.5, -4.0], [-6.0, 6.0, 0.0]])
+    st = model.begin_sampling(torch.cat([x for x, _, _ in phs]), torch.cat([p for _, p, _ in phs]), torch.cat([n for _, _, n in phs]),
+                              bp, na, centers, rng='device', seed=5, return_traj=True, num_steps=4)
+    states = []
+    for i, step in enumerate((999, 998, 997, 996)):
+        model.reverse_step(st, i, step)
+        states.append(st.eng.ws.in_pos.clone())
+    res = model.finish_sampling(st)
+    rows = centers.to(DEV)[st.plan.batch_node]
+    for k, x in enumerate(states):
+        assert torch.allclose(res['traj'][1][k + 1], x + rows, atol=1e-6)
+    assert torch.allclose(res['pred'][1], st.x0 + rows, atol=1e-6)
+    assert torch.equal(res['traj'][1][0], st.pos_traj[0])                # frame 0: the initial state (no centre, diffusion.py:424-426)
+
+
+def test_out_of_memory_surfaces_with_the_reference_message_contract(model):
+    """sample_all.py:95-99 / run/run.py:144-151 branch on `'out of memory' in str(e)`: an allocation failure inside
+    `model.sample` must be an exception carrying that text, and the model must keep working afterwards."""
+    from oracle.make_inputs import synthetic_phore
+    from phoregen_amd.data import PhoreGraph
+    x, pos, norm = synthetic_phore(torch.Generator().manual_seed(3), 40)
+    data = PhoreGraph(x, pos, norm, torch.zeros(3)).to(DEV)
+    torch.cuda.empty_cache()
+    free, _total = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (48 << 20), 0), dtype=torch.uint8, device=DEV)       # leave 48 MB
+    try:
+        with pytest.raises(Exception) as ei:
+            model.sample(data, 24, DEV, num_atoms=torch.full((24,), 60), num_steps=2)   # needs ~0.5 GB of workspace
+        assert 'out of memory' in str(ei.value), str(ei.value)[:300]
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    res = model.sample(data, 2, DEV, num_atoms=torch.tensor([8, 9]), num_steps=2)
+    assert torch.isfinite(res['pred'][1]).all()

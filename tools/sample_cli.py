@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Thin sampling driver with sample_all.py's flags (the reference's script cannot travel to the GPU box and its
-RDKit/OpenBabel post-processing is out of scope): .phore files -> PhoreDiff.sample -> per-molecule tensors (.pt).
+RDKit/OpenBabel post-processing is out of scope): .phore files -> PhoreDiff.sample -> decode_batch -> per-molecule
+element / position / bond arrays (.pt), the input of the reference's reconstruct_from_generated_with_edges.
 
   python tools/sample_cli.py --phore_file_list files.json --num_samples 100 --batch_size 30 --outdir results/x
 """
@@ -17,19 +18,8 @@ sys.path.insert(0, ROOT)
 from phoregen_amd.config import default_model_config, load_config  # noqa: E402
 from phoregen_amd.data import parse_phore_file  # noqa: E402
 from phoregen_amd.models.diffusion import PhoreDiff  # noqa: E402
+from phoregen_amd.utils.sample_utils import decode_batch  # noqa: E402
 from phoregen_amd.weights import init_deterministic_  # noqa: E402
-
-
-def unbatch(results, n_graphs):
-    """Per-graph views of `pred` (+ final trajectory frame), the contract of utils/sample_utils.py:57-93."""
-    bn, ei, be = results['lig_info'][1], results['lig_info'][2], results['lig_info'][3]
-    out = []
-    for g in range(n_graphs):
-        mn, me = bn == g, be == g
-        first = int(mn.nonzero()[0])
-        out.append({'pred': [results['pred'][0][mn], results['pred'][1][mn], results['pred'][2][me]],
-                    'edge_index': ei[:, me] - first})
-    return out
 
 
 def main():
@@ -69,8 +59,9 @@ def main():
             n = min(args.batch_size, args.num_samples - len(done))
             res = model.sample(data, n, 'cuda', pos_guidance_opt=args.pos_guidance_opt, sample_mode=args.sample_nodes_mode,
                                normal_scale=args.normal_scale, rng=args.rng, return_traj=False)
-            res = {k: [v.cpu() if torch.is_tensor(v) else v for v in vals] for k, vals in res.items()}
-            done += unbatch(res, n)
+            # sample_all.py:104-116 (`.cpu()` of everything, unbatch_data, decode_data) in one pass: argmax on the device,
+            # one copy of the compact arrays
+            done += decode_batch(res, include_bond=True)
         torch.save(done, os.path.join(args.outdir, data.name + '.pt'))
         print(f'{data.name}: {len(done)} samples in {time.time() - t0:.1f} s')
 
