@@ -76,6 +76,11 @@ typedef struct {
   const int* bond_src;      /* [n_bond] ctx index of edge source (edge_index[0], diffusion.py:201) */
   const int* bond_dst;      /* [n_bond] ctx index of edge target                                  */
   const int* bond_desc;     /* [n_bond][4] {ctx j, local_i | local_j << 16, n_lig of the graph, eid offset of the graph} */
+  const int* g_bond_off;    /* [B+1] first bond row of graph g                                    */
+  const int* edge_ref;      /* [n_bond] or NULL: bond rows inside the library are in the host mirror's INTERNAL order (per graph
+                               target-major: the edges k -> i of one target i are contiguous, k ascending; phoregen_amd/plan.py);
+                               edge_ref[e] = row of internal edge e in the caller's edge arrays (h_edge_pert, h_edge_prev).
+                               NULL: the caller's order already is the internal one */
 } PgTopo;
 
 /* ---- embeddings (models/diffusion.py:180-183,205; models/common.py:34-55) -------------------- */
@@ -85,7 +90,7 @@ int pg_embed_ctx(const PgTopo* t, const float* h_node_pert /*[n_lig,12]*/, const
                  const float* h_phore_emb /*[n_phore,128]*/, const float* pos_phore /*[n_phore,3]*/,
                  const int* phore2ctx /*[n_phore]*/, float* h_ctx /*[n_ctx,128]*/, float* x_ctx /*[n_ctx,3]*/,
                  void* stream);
-int pg_embed_bond(const PgTopo* t, const float* h_edge_pert /*[n_bond,6]*/, const int* bond_graph,
+int pg_embed_bond(const PgTopo* t, const float* h_edge_pert /*[n_bond,6], caller's order (t->edge_ref)*/, const int* bond_graph,
                   const int64_t* time_step, const float* W_edge /*[118,6]*/, const float* t_offset,
                   const float* t_coeff, float* h_bond /*[n_bond,128]*/, void* stream);
 

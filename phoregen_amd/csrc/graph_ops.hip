@@ -79,8 +79,9 @@ __global__ void embed_ctx_kernel(PgTopo t, const float* h_node, const float* pos
   }
 }
 
-__global__ void embed_bond_kernel(int n_bond, const float* h_edge, const int* bond_graph, const int64_t* time_step,
-                                  const float* W_edge, const float* t_off, const float* t_coeff, float* h_bond) {
+__global__ void embed_bond_kernel(int n_bond, const int* edge_ref, const float* h_edge, const int* bond_graph,
+                                  const int64_t* time_step, const float* W_edge, const float* t_off, const float* t_coeff,
+                                  float* h_bond) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t e = idx >> 7;
   const int c = idx & 127;
@@ -88,8 +89,9 @@ __global__ void embed_bond_kernel(int n_bond, const float* h_edge, const int* bo
   float v;
   if (c < 118) {
     v = 0.f;
+    const size_t er = edge_ref ? (size_t)edge_ref[e] : e;        // the caller's row of internal edge e
 #pragma unroll
-    for (int k = 0; k < 6; ++k) v += h_edge[e * 6 + k] * W_edge[c * 6 + k];
+    for (int k = 0; k < 6; ++k) v += h_edge[er * 6 + k] * W_edge[c * 6 + k];
   } else {
     v = time_smear((float)time_step[bond_graph[e]], t_off, t_coeff, c - 118);
   }
@@ -318,7 +320,7 @@ extern "C" int pg_embed_bond(const PgTopo* t, const float* h_edge_pert, const in
                              const float* W_edge, const float* t_off, const float* t_coeff, float* h_bond, void* stream) {
   const long n = (long)t->n_bond * 128;
   if (n == 0) return PG_OK;
-  hipLaunchKernelGGL(embed_bond_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->n_bond,
+  hipLaunchKernelGGL(embed_bond_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->n_bond, t->edge_ref,
                      h_edge_pert, bond_graph, time_step, W_edge, t_off, t_coeff, h_bond);
   return check_launch("pg_embed_bond");
 }

@@ -140,7 +140,7 @@ __global__ void guidance_stats_kernel(PgTopo t, const float* x_lig, const float*
   for (int i = lane; i < n * n; i += 64) {
     const int e = eid[i];
     if (e >= 0) {
-      const float* h = h_edge_prev + (size_t)e * 6;
+      const float* h = h_edge_prev + (size_t)(t.edge_ref ? t.edge_ref[e] : e) * 6;
       bool none = true;                      // argmax > 0  <=>  some class k>0 strictly beats class 0 (first max wins)
       for (int k = 1; k < 6; ++k) none = none && !(h[k] > h[0]);
       c += none ? 0.f : 1.f;
@@ -171,7 +171,7 @@ __global__ void guidance_grad_kernel(PgTopo t, const float* x_lig, const float* 
       float mult = 0.f;
       const int e2[2] = {eid[la * n + b], eid[b * n + la]};
       for (int q = 0; q < 2; ++q) {
-        const float* h = h_edge_prev + (size_t)e2[q] * 6;
+        const float* h = h_edge_prev + (size_t)(t.edge_ref ? t.edge_ref[e2[q]] : e2[q]) * 6;
         bool none = true;
         for (int k = 1; k < 6; ++k) none = none && !(h[k] > h[0]);
         mult += none ? 0.f : 1.f;

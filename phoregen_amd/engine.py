@@ -254,8 +254,9 @@ class Engine:
                    p.lig2ctx.data_ptr(), w.out_v.data_ptr(), 12)
         W0, b0, W2, b2 = pk.b0
         self._gemm(prog, hb[cur], 128, W0, w.head_b, E, 128, bias=b0, act=hip.ACT_SSP)
-        self._call(prog, lib.pg_rows_linear, w.head_b.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 6, E, None,
-                   w.out_bond.data_ptr(), 6)
+        # out_bond in the caller's edge order: row r reads the internal row of caller edge r
+        self._call(prog, lib.pg_rows_linear, w.head_b.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 6, E,
+                   None if p.edge_identity else p.edge_int.data_ptr(), w.out_bond.data_ptr(), 6)
         return prog
 
     def _denoiser_program(self, prog, lig, both):
@@ -398,14 +399,15 @@ def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, b
     w = eng.ws
     w.h[0].copy_(h)
     w.x[0].copy_(x)
-    w.hb[0].copy_(h_bond)
+    w.hb[0].copy_(h_bond if plan.edge_identity else h_bond.index_select(0, plan.edge_ref_long))   # internal bond order
     w.phore_norm.copy_(phore_norm)
     prog = []
     eng._denoiser_program(prog, [(plan.lig2ctx, plan.n_lig, True)],
                           [(plan.lig2ctx, plan.n_lig, True), (plan.phore2ctx, plan.n_phore, False)])
     eng._run(prog)
     c = eng.final_idx
-    out = {'x': w.x[c].clone(), 'h': w.h[c].clone(), 'h_bond': w.hb[c].clone()}
+    out = {'x': w.x[c].clone(), 'h': w.h[c].clone(),
+           'h_bond': w.hb[c].clone() if plan.edge_identity else w.hb[c].index_select(0, plan.edge_int_long)}
     if return_all:
         out.update(all_x=[x, out['x']], all_h=[h, out['h']], all_h_bond=[h_bond, out['h_bond']])
     return out

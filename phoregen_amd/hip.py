@@ -31,7 +31,7 @@ class PgTopo(C.Structure):
                 ('n_bond', C.c_int), ('max_nlig', C.c_int), ('max_gctx', C.c_int),
                 ('g_ctx_off', c_ip), ('g_nph', c_ip), ('g_nlig', c_ip), ('g_eid_off', c_ip), ('eid', c_ip),
                 ('ctx_graph', c_ip), ('ctx_is_lig', c_ip), ('lig2ctx', c_ip), ('bond_src', c_ip),
-                ('bond_dst', c_ip), ('bond_desc', c_ip)]
+                ('bond_dst', c_ip), ('bond_desc', c_ip), ('g_bond_off', c_ip), ('edge_ref', c_ip)]
 
 
 class PgSegAttn(C.Structure):

@@ -45,11 +45,25 @@ class BatchPlan:
         is_lig[lig2ctx] = 1
         g_eid_off = torch.zeros(B + 1, dtype=torch.long)
         g_eid_off[1:] = (nlig * nlig).cumsum(0)
-        eid = torch.full((int(g_eid_off[-1]),), -1, dtype=torch.long)
         ls, ld = ei[0] - lig_off[be], ei[1] - lig_off[be]
         if self.n_bond and ((ls < 0).any() or (ld < 0).any() or (ls >= nlig[be]).any() or (ld >= nlig[be]).any()
                             or (bn[ei[0]] != be).any()):
             raise ValueError('phoregen_amd: edge_index / batch_edge inconsistent with batch_node')
+        if self.n_bond and (be[1:] < be[:-1]).any():
+            raise ValueError('phoregen_amd: bond edges must be grouped by graph (batch_edge ascending)')
+        # ---- internal bond order: per graph, TARGET-major (all edges k -> i of target i together, k ascending) ----
+        # Inside the engine h_bond and every bond-row tensor live in this order: the rows P[k -> j] that the triplets of a source
+        # atom j read (uni_denoiser.py:123-165) and the rows a target node's bond attention reads (:43-59) are then one
+        # contiguous block each.  The caller's order (make_edge_data's "all a<b, then all b<a", or FeaturizeLigandBond's,
+        # which already is target-major) only exists at the boundary: edge_ref[e_internal] = caller's row.
+        nmax = int(nlig.max()) + 1 if B else 1
+        order = torch.argsort((be * nmax + ld) * nmax + ls, stable=True) if self.n_bond else torch.zeros(0, dtype=torch.long)
+        self.edge_identity = bool(torch.equal(order, torch.arange(self.n_bond)))
+        ei_ref, ei = ei, ei[:, order]
+        ls, ld = ls[order], ld[order]
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(self.n_bond)
+        eid = torch.full((int(g_eid_off[-1]),), -1, dtype=torch.long)
         eid[g_eid_off[be] + ls * nlig[be] + ld] = torch.arange(self.n_bond)
         if int((eid >= 0).sum()) != self.n_bond:
             raise ValueError('phoregen_amd: duplicate bond edges')
@@ -70,10 +84,10 @@ class BatchPlan:
         self.g_lig_off = i32(lig_off)
         bond_off = torch.zeros(B + 1, dtype=torch.long)
         bond_off[1:] = torch.bincount(be, minlength=B).cumsum(0)
-        if self.n_bond and (be[1:] < be[:-1]).any():
-            raise ValueError('phoregen_amd: bond edges must be grouped by graph (batch_edge ascending)')
         self.g_bond_off = i32(bond_off)                 # first bond row of each graph (graph-keyed device RNG)
-        self.batch_node, self.batch_edge, self.edge_index = bn.to(device), be.to(device), ei.to(device)
+        self.batch_node, self.batch_edge, self.edge_index = bn.to(device), be.to(device), ei_ref.to(device)     # caller's order
+        self.edge_ref, self.edge_int = i32(order), i32(inv)            # internal -> caller's row, caller's -> internal row
+        self.edge_ref_long, self.edge_int_long = order.to(device), inv.to(device)
 
         t = hip.PgTopo()
         t.n_graphs, t.n_ctx, t.n_lig, t.n_phore, t.n_bond = B, self.n_ctx, self.n_lig, self.n_phore, self.n_bond
@@ -90,12 +104,13 @@ class BatchPlan:
         self.tri_chunks = i32(torch.searchsorted(csum, targets).clamp(max=self.n_bond))
         self.tri_chunks[0], self.tri_chunks[-1] = 0, self.n_bond
         for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
-                     'bond_src', 'bond_dst', 'bond_desc'):
+                     'bond_src', 'bond_dst', 'bond_desc', 'g_bond_off'):
             setattr(t, name, getattr(self, name).data_ptr())
+        t.edge_ref = None if self.edge_identity else self.edge_ref.data_ptr()
         self.topo = t
         self.topo_ref = C.byref(t)
         self.key = (bn.numel(), bp.numel(), ei.size(1), B)
-        self._cpu_sig = (bn, bp, ei)
+        self._cpu_sig = (bn, bp, ei_ref)
         self.ws = None   # engine workspace, attached lazily
 
     def matches(self, batch_node, batch_phore, edge_index):

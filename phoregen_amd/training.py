@@ -465,6 +465,8 @@ class TrainForward:
         # embeddings (diffusion.py:180-183,205) and the ctx order of compose_context (common.py:180-208)
         h_lig = torch.cat([linear(h_node_pert.float(), sd['node_embedder.weight']), self.time_smearing(time_step[p.batch_node])], -1)
         hb = torch.cat([linear(h_edge_pert.float(), sd['edge_embedder.weight']), self.time_smearing(time_step[p.batch_edge])], -1)
+        if not p.edge_identity:        # bond rows live in the plan's internal (target-major) order inside the network
+            hb = hb.index_select(0, p.edge_ref_long)
         h = torch.zeros(n, 128, dtype=torch.float32, device=dev).index_copy(0, p.lig2ctx_long, h_lig)
         h = h.index_copy(0, p.phore2ctx_long, hp_emb)
         x = torch.zeros(n, 3, dtype=torch.float32, device=dev).index_copy(0, p.lig2ctx_long, pos_pert.float())
@@ -542,4 +544,6 @@ class TrainForward:
         v0, b0 = pk.v0, pk.b0
         v = linear(shifted_softplus(linear(h.index_select(0, p.lig2ctx_long), v0[0], v0[1])), v0[2], v0[3])
         bond = linear(shifted_softplus(linear(hb, b0[0], b0[1])), b0[2], b0[3])
+        if not p.edge_identity:
+            bond = bond.index_select(0, p.edge_int_long)                    # back to the caller's edge order
         return v, x.index_select(0, p.lig2ctx_long), bond, counts

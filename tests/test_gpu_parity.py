@@ -131,12 +131,15 @@ def test_forward_against_reference_golden(name):
     ew_flat = torch.cat([ew[i, :deg[i]] for i in range(nbr.size(0))])
     errs = {'e_w': rel_err(ew_flat, g['L0_in_e_w'][:, 0]), 'phore_enc': rel_err(eng.ws.hp_emb.cpu(), g['phore_enc'])}
     hn, hbn, xn, aggE, aggB, dxe, dxb, nrm, hbc = (a.cpu() for a in dbg['L0'])
+    inv = plan.edge_int_long.cpu()                       # bond rows inside the engine are in the plan's internal order
+    hbn, hbc = hbn[inv], hbc[inv]
     errs.update(L0_node_edge=rel_err(aggE, g['L0_node_edge']), L0_node_bond=rel_err(aggB, g['L0_node_bond']),
                 L0_bond_upd=rel_err(hbn - hbc, g['L0_bond_upd']),
                 L0_pos_edge=rel_err(dxe[lig], g['L0_pos_edge'][lig.numpy()]),
                 L0_pos_bond=rel_err(dxb[lig], g['L0_pos_bond'][lig.numpy()]),
                 L0_h=rel_err(hn, g['L0_out_h']), L0_hb=rel_err(hbn, g['L0_out_h_bond']), L0_x=rel_err(xn, g['L0_out_x']))
     h5, hb5, x5 = (a.cpu() for a in dbg['L5'][:3])
+    hb5 = hb5[inv]
     errs.update(L5_h=rel_err(h5, g['L5_out_h']), L5_hb=rel_err(hb5, g['L5_out_h_bond']), L5_x=rel_err(x5, g['L5_out_x']),
                 v=rel_err(v.cpu(), g['out_v']), x0=rel_err(x0.cpu(), g['out_x0']), bond=rel_err(bond.cpu(), g['out_bond']),
                 cl=rel_err(cl.cpu(), g['out_count_l']), cu=rel_err(cu.cpu(), g['out_count_u']))
@@ -395,7 +398,10 @@ def test_sampler_teacher_forced_every_step(name):
         assert np.array_equal(w.in_h_edge.argmax(-1).cpu().numpy(), nxt_e), (name, s)        # bond types bit-exact
         rmsd = float(np.sqrt(((w.in_pos.cpu().numpy() - nxt_p) ** 2).sum(-1).mean()))
         # x_{t-1} = c0 x0 + ct x_t + sigma eps with c0 <= 1: an ill-conditioned state hands its x0 error on to the next position
-        rmsd_tol = max(1e-4, tol[1] * float(np.abs(g[f's{s}_out_x0']).max())) if tol[1] > 5 * TOL else 1e-4
+        # (and 1e-4 A is an absolute bound for coordinates of molecular size: the `trained_like` weights drive |x0| to 1e5..1e6 A
+        # at small t, where only the relative bound is meaningful)
+        x0_scale = float(np.abs(g[f's{s}_out_x0']).max())
+        rmsd_tol = max(1e-4, (tol[1] if tol[1] > 5 * TOL else TOL) * x0_scale) if (tol[1] > 5 * TOL or x0_scale > 100.) else 1e-4
         assert rmsd <= rmsd_tol, (name, s, rmsd, rmsd_tol)
         n_checked += 1
     assert n_checked >= 3

@@ -89,21 +89,32 @@ def test_plan_topology_matches_compose_context():
     plan = BatchPlan(bn, bp, ei, be, 3, torch.device('cpu'))
     assert np.array_equal(plan.ctx_is_lig.numpy().astype(bool), g['L0_in_mask_ligand'])
     assert np.array_equal(plan.ctx_graph.numpy(), g['L0_in_batch'])
-    assert np.array_equal(torch.stack([plan.bond_src, plan.bond_dst]).numpy(), g['L0_in_bond_index'])
+    # bond rows: the plan's internal order is target-major per graph; edge_ref / edge_int translate to the caller's rows
+    ref, inv = plan.edge_ref.long(), plan.edge_int.long()
+    assert torch.equal(ref[inv], torch.arange(plan.n_bond)) and not plan.edge_identity
+    assert np.array_equal(torch.stack([plan.bond_src, plan.bond_dst])[:, inv].numpy(), g['L0_in_bond_index'])
+    d, s_ = plan.bond_dst.long(), plan.bond_src.long()
+    key = (d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (s_[1:] > s_[:-1]))
+    assert bool(key.all())                                             # sorted by (target, source): one block per target
     # edge-id table enumerates exactly the reference triplets (uni_denoiser.py:101-121)
     i, j, k, kj, ji = po.triplets(torch.as_tensor(g['L0_in_bond_index']), plan.n_ctx)
     eid, off, nl = plan.eid.numpy(), plan.g_eid_off.numpy(), plan.g_nlig.numpy()
     lig0 = (plan.g_ctx_off[:-1] + plan.g_nph).numpy()
     gr = plan.ctx_graph.numpy()
     mine = []
-    for e in range(plan.n_bond):
+    for e_ref in range(plan.n_bond):                                  # segments in the caller's edge order, like the reference
+        e = int(inv[e_ref])
         cj, ci = int(plan.bond_src[e]), int(plan.bond_dst[e])
         gi = gr[cj]
         n, lj, li = nl[gi], cj - lig0[gi], ci - lig0[gi]
         for kk in range(n):
             if kk != lj and kk != li:
-                mine.append((lig0[gi] + kk, eid[off[gi] + kk * n + lj], e))
+                mine.append((lig0[gi] + kk, int(ref[eid[off[gi] + kk * n + lj]]), e_ref))
     assert mine == list(zip(k.tolist(), kj.tolist(), ji.tolist()))
+    # FeaturizeLigandBond's order (datasets/transform.py:488-501) already is the internal one
+    from oracle.make_inputs import synthetic_train_batch
+    tb = synthetic_train_batch(3, [5, 7], [6, 9])
+    assert BatchPlan(tb['ligand_batch'], tb['phore_batch'], tb['f_edge_index'], tb['f_edge_batch'], 2, torch.device('cpu')).edge_identity
     with pytest.raises(ValueError):
         BatchPlan(bn, bp, ei[:, :-1], be[:-1], 3, torch.device('cpu'))
 
@@ -279,14 +290,18 @@ def test_plan_and_partition_properties_random_sizes():
         off = torch.zeros(B + 1, dtype=torch.long)
         off[1:] = na.cumsum(0)
         eo = plan.g_eid_off.long()
-        for e in range(0, E, max(1, E // 50)):          # eid[src, dst] is the edge id
+        inv, ref = plan.edge_int.long(), plan.edge_ref.long()
+        assert sorted(inv.tolist()) == list(range(E)) and (E == 0 or torch.equal(ref[inv], torch.arange(E)))
+        for e in range(0, E, max(1, E // 50)):          # eid[src, dst] is the (internal) id of the caller's edge e
             g = int(be[e])
             n = int(na[g])
             ls, ld = int(ei[0, e] - off[g]), int(ei[1, e] - off[g])
-            assert int(plan.eid[eo[g] + ls * n + ld]) == e
+            assert int(plan.eid[eo[g] + ls * n + ld]) == int(inv[e])
+            # internal rows: per graph target-major, source ascending -> closed form
+            assert int(inv[e]) == int(plan.g_bond_off[g]) + ld * (n - 1) + (ls if ls < ld else ls - 1)
         order = plan.tri_order.long()
         assert sorted(order.tolist()) == list(range(E))
-        src_sorted = ei[0][order]
+        src_sorted = plan.bond_src.long()[order]
         assert bool((src_sorted[1:] >= src_sorted[:-1]).all()) if E > 1 else True
         ch = plan.tri_chunks.long()
         assert int(ch[0]) == 0 and int(ch[-1]) == E and bool((ch[1:] >= ch[:-1]).all())
