@@ -34,8 +34,10 @@ int pg_selftest_mfma(int* d_result, void* stream);
  * ctr_key [n][6] = counter c0..c3, key k0 k1  ->  out [n][4].  The transition kernels call it with
  * key = seed (lo, hi), counter = (element index lo, hi, step, stream_id). */
 int pg_selftest_philox(const uint32_t* ctr_key, int n, uint32_t* out, void* stream);
-/* test hook: route the node-target modes of pg_seg_attn through the generic one-pass kernel (returns the old setting) */
-int pg_debug_force_generic_seg(int on);
+/* test hook (returns the old setting): bit 0 routes the node-target modes of pg_seg_attn through the generic one-pass kernel,
+ * bit 1 keeps PG_SEG_TRIPLET on the gather kernel (csrc/triplet.hip) even when the staged one (csrc/triplet2.hip) applies,
+ * bit 2 runs the staged kernel with 12 instead of 8 waves per workgroup (tuning) */
+int pg_debug_force_generic_seg(int mask);
 
 /* ---- dense linear layers -------------------------------------------------------------------
  * Y[R, n] = out_scale * act( sum_k Xcat[R,k] * W[n,k] + bias[n] + add1[i1(r), n] + add2[i2(r), n] ),  R = rows ? rows[r] : r
@@ -166,6 +168,12 @@ typedef struct {
    * efeat[efeat_off[g] + src_local * p_g + dst_local] for graph g with p_g nodes = the order of
    * fully_connect_two_graphs (models/common.py:329-356).  NULL: distances from `x`. */
   const float* efeat; const int* efeat_off;
+  /* PG_SEG_TRIPLET, optional: source-atom groups for the LDS-staged kernel (csrc/triplet2.hip).  tri_iters [n_tri_iters][4] =
+   * {ctx index of the ligand's first atom, n | j0 << 8 | A << 16, first internal bond row of the graph, 0}: the A consecutive
+   * source atoms j0.. of an n-atom ligand, A*(n-1) <= 80, longest first; tri_counter: one int of scratch (the work queue head).
+   * Requires the target-major bond order of the host mirror, Csrc_k/Csrc_v = the two halves of one [n_bond,256] tensor and
+   * Cdst_k/Cdst_v [n_bond] rows = smear(d_ji) . Wg2 of the segment's own edge (as in the adjoint's contract). */
+  const int* tri_iters; int n_tri_iters; int* tri_counter;
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 

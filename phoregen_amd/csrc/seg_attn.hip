@@ -18,6 +18,7 @@
 namespace pg {
 
 int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st);     // triplet.hip
+int launch_triplet_staged(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // triplet2.hip (-1: not applicable)
 int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // node_attn.hip (-1: shape not covered)
 
 // Folded LayerNorm + ReLU (packing._kv_mlp: hidden is centred and sign-normalised, |gamma| lives in the next Linear):
@@ -566,9 +567,11 @@ static int launch_seg(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
 using namespace pg;
 
 static int g_force_generic = 0;
+namespace pg { extern int g_t2_waves; }
 extern "C" int pg_debug_force_generic_seg(int on) {
   const int old = g_force_generic;
   g_force_generic = on;
+  pg::g_t2_waves = (on & 4) ? 12 : 8;
   return old;
 }
 
@@ -576,7 +579,7 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
   if (!t || !p) { set_error("pg_seg_attn: null argument"); return PG_ERR_ARG; }
   if (p->n_seg == 0) return PG_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (p->mode <= PG_SEG_BOND_POS && !g_force_generic) {   // two-pass kernels; pg_debug_force_generic_seg keeps the one-pass kernel testable
+  if (p->mode <= PG_SEG_BOND_POS && !(g_force_generic & 1)) {   // two-pass kernels; pg_debug_force_generic_seg keeps the one-pass kernel testable
     const int rc = launch_node_attn(t, p, st);
     if (rc >= 0) return rc;
   }
@@ -586,6 +589,10 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
     case PG_SEG_BOND_NODE: return launch_seg<PG_SEG_BOND_NODE>(t, p, st);
     case PG_SEG_BOND_POS: return launch_seg<PG_SEG_BOND_POS>(t, p, st);
     case PG_SEG_TRIPLET:
+      if (!(g_force_generic & 2)) {        // source-atom rows staged in LDS (sampling form, target-major bond order)
+        const int rc = launch_triplet_staged(t, p, st);
+        if (rc >= 0) return rc;
+      }
       // the occupancy-tuned kernel holds the logits of <= 5 row tiles in registers (ligands of <= 80 atoms)
       // S / swn output (training): the tuned kernel when the query-side inputs are given too, else the generic form
       return (t->max_nlig <= 80 && (!p->S || (p->q && p->W2k_l && p->G))) ? launch_triplet(t, p, st)

@@ -1,0 +1,370 @@
+// Bond-triplet attention (BondUpdateLayer, models/uni_denoiser.py:101-165), sampling form, with the rows of a SOURCE ATOM
+// staged in LDS.
+//
+// The triplets of a bond edge j->i read the rows P[k->j] of every other atom k (uni_denoiser.py:123-135): all n-1 segments
+// j->i of one source atom j read the SAME n-1 rows.  With the host mirror's target-major bond order (phoregen_amd/plan.py)
+// those rows are one contiguous (n-1) x 1 KB block of P, so a workgroup
+//   * takes a group of consecutive source atoms of one ligand (as many as fit 80 staged rows),
+//   * streams their P blocks into LDS once (coalesced float4 copies, no edge-id lookups, no gathers),
+//   * lets its waves work off the A*(n-1) segments, each row tile's MFMA C-operand coming from LDS (ds_read_b128 in the
+//     key layout, ds_read_b32 in the value layout) instead of an L2 gather that was re-fetched ~39x,
+//   * and pulls the next group from a global counter (longest groups first).
+// LDS: lane-fixed W2k (64 KB, query fold), feature weights (12 KB), biases, the ligand's coordinates, 80 staged rows (81 KB).
+// The value unfold streams W2v through L2 (64 KB per segment, software-prefetched in batches of 16 float4 per lane): the two
+// 64 KB weight tables and the staged rows do not fit the 160 KB together, and the unfold has no data it must wait for.
+// Per-segment arithmetic is that of triplet.hip (two passes, folded LayerNorm, base-2 softmax); the per-segment constant
+// Q = Wg2 . smear(d_ji) reaches the MFMA's spare feature column through ds_bpermute instead of a per-wave LDS scratch.
+// Lane l = (g = l>>4, m = l&15); 16x16x4 maps as in seg_attn.hip.
+#include "common.h"
+#include "../../include/phoregen_hip.h"
+
+namespace pg {
+
+constexpr int T2_ROW = 260;          // floats per staged row: P_k[128] | P_v[128] | 4 (bank spread of the b128 key-layout reads)
+constexpr int T2_ROWS = 80;          // staged rows per workgroup
+constexpr int T2_XS = 96;            // ligand atoms whose coordinates are staged
+constexpr float T2_NEG = -1.0e30f;
+
+template <int CTRL>
+__device__ __forceinline__ float t2_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float t2_row16_sum(float v) {
+  v += t2_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += t2_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += t2_dpp<0x141>(v);   // row_half_mirror
+  v += t2_dpp<0x140>(v);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float t2_from_lane(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+// sin(w*theta) or cos(w*theta) for 0 <= arg <= ~10 (same reduction + polynomials as triplet.hip)
+__device__ __forceinline__ float t2_sincos(float arg, bool want_cos) {
+  const float kf = rintf(arg * 0.63661977236758134308f);
+  float r = fmaf(-kf, 1.57079637050628662109375f, arg);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  const int q = ((int)kf + (want_cos ? 1 : 0)) & 3;
+  const float s = r * r;
+  float ps = fmaf(s, 2.7557314297e-6f, -1.9841270114e-4f);
+  ps = fmaf(ps, s, 8.3333337680e-3f);
+  ps = fmaf(ps, s, -1.6666667163e-1f);
+  ps = fmaf(ps * s, r, r);
+  float pc = fmaf(s, 2.4801587642e-5f, -1.3888889225e-3f);
+  pc = fmaf(pc, s, 4.1666667908e-2f);
+  pc = fmaf(pc, s, -0.5f);
+  pc = fmaf(pc, s, 1.0f);
+  const float v = (q & 1) ? pc : ps;
+  return (q & 2) ? -v : v;
+}
+
+__device__ __constant__ const float kT2Freq[12] = {0.f, 1.f, 2.f, 3.f, 0.5f, (float)(1.0 / 3.0), 1.f, 2.f, 3.f, 0.5f,
+                                                    (float)(1.0 / 3.0), 0.f};
+
+constexpr size_t t2_lds_floats() { return 16384 + 2 * 1536 + 3 * 128 + 3 * T2_XS + 4 + (size_t)T2_ROWS * T2_ROW; }
+
+template <int THREADS, int MAXT>
+__global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p) {
+  constexpr int WAVES = THREADS / 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const w2k_l = lds;                     // [64][64][4]
+  float* const wf_k = w2k_l + 16384;            // [3][8][64]
+  float* const wf_v = wf_k + 1536;
+  float* const bk = wf_v + 1536;                // b' = beta/|gamma| of the key / value LayerNorm, value bias
+  float* const bv = bk + 128;
+  float* const b2v = bv + 128;
+  float* const xs = b2v + 128;                  // [T2_XS][3] coordinates of the current ligand
+  int* const ctrl = reinterpret_cast<int*>(xs + 3 * T2_XS);
+  float* const pbuf = xs + 3 * T2_XS + 4;       // [T2_ROWS][T2_ROW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, m = lane & 15;
+
+  for (int i = tid; i < 128; i += THREADS) { bk[i] = p.ln_bk[i]; bv[i] = p.ln_bv[i]; b2v[i] = p.b2v[i]; }
+  for (int i = tid; i < 1536; i += THREADS) { wf_k[i] = p.Wf_k[i]; wf_v[i] = p.Wf_v[i]; }
+  for (int i = tid; i < 4096; i += THREADS) reinterpret_cast<f4*>(w2k_l)[i] = reinterpret_cast<const f4*>(p.W2k_l)[i];
+  const f4* const w2v_g = reinterpret_cast<const f4*>(p.W2v_l);
+  const int4* const iters = reinterpret_cast<const int4*>(p.tri_iters);
+
+  for (;;) {
+    __syncthreads();                            // the previous group's rows / ctrl word are no longer read
+    if (tid == 0) ctrl[0] = atomicAdd(p.tri_counter, 1);
+    __syncthreads();
+    const int it = __builtin_amdgcn_readfirstlane(ctrl[0]);
+    if (it >= p.n_tri_iters) break;
+    const int4 d = iters[it];
+    const int lig0 = __builtin_amdgcn_readfirstlane(d.x);
+    const int n = __builtin_amdgcn_readfirstlane(d.y & 0xff), j0 = __builtin_amdgcn_readfirstlane((d.y >> 8) & 0xff);
+    const int A = __builtin_amdgcn_readfirstlane(d.y >> 16), bond_off = __builtin_amdgcn_readfirstlane(d.z);
+    const int nm1 = n - 1;
+    {   // stage the P blocks of source atoms j0 .. j0+A-1 (contiguous rows of the target-major bond order) and the coordinates
+      const f4* src = reinterpret_cast<const f4*>(p.Csrc_k + (size_t)(bond_off + j0 * nm1) * 256);
+      const int n4 = A * nm1 * 64;
+      for (int idx = tid; idx < n4; idx += THREADS)
+        *reinterpret_cast<f4*>(pbuf + (idx >> 6) * T2_ROW + (idx & 63) * 4) = src[idx];
+      for (int i = tid; i < n * 3; i += THREADS) xs[i] = p.x[(size_t)lig0 * 3 + i];
+    }
+    __syncthreads();
+    const int n_seg = A * nm1;
+    const int n_tiles = (nm1 + 15) >> 4;
+
+    for (int s = wave; s < n_seg; s += WAVES) {
+      const int a = s / nm1, ip = s - a * nm1;            // source atom of the group, target index among the other atoms
+      const int j = j0 + a, i = ip + (ip >= j ? 1 : 0);
+      const int seg = bond_off + i * nm1 + (j < i ? j : j - 1);          // internal id of edge j->i
+      const float* const prow = pbuf + a * nm1 * T2_ROW;
+
+      // ---- Q = Wg2 . smear(d_ji): lane l computes channels l and 64+l of both MLPs, the g==3 lanes (MFMA feature column 11)
+      //      collect channel 16 tq + m from lane 16 (tq & 3) + m ----
+      float wk2[8], wv2[8];
+      {
+        float qk0 = 0.f, qk1 = 0.f, qv0 = 0.f, qv1 = 0.f;
+        const float* Gs = p.G + (size_t)seg * 20;
+#pragma unroll 5
+        for (int q = 0; q < 20; ++q) {
+          const float gv_ = Gs[q];
+          qk0 = fmaf(p.Wg2_k[q * 128 + lane], gv_, qk0);
+          qk1 = fmaf(p.Wg2_k[q * 128 + 64 + lane], gv_, qk1);
+          qv0 = fmaf(p.Wg2_v[q * 128 + lane], gv_, qv0);
+          qv1 = fmaf(p.Wg2_v[q * 128 + 64 + lane], gv_, qv1);
+        }
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) {
+          const int sl = 16 * (tq & 3) + m;
+          const float ck = t2_from_lane(tq < 4 ? qk0 : qk1, sl), cv = t2_from_lane(tq < 4 ? qv0 : qv1, sl);
+          wk2[tq] = g == 3 ? ck : wf_k[(16 + tq) * 64 + lane];           // feature step 2: f = 8 + g, f = 11 carries Q
+          wv2[tq] = g == 3 ? cv : wf_v[(16 + tq) * 64 + lane];
+        }
+      }
+
+      const float xi0 = xs[i * 3], xi1 = xs[i * 3 + 1], xi2 = xs[i * 3 + 2];
+      const float u0 = xs[j * 3] - xi0, u1 = xs[j * 3 + 1] - xi1, u2 = xs[j * 3 + 2] - xi2;
+
+      float feat[MAXT][3];
+      f4 lg[MAXT];
+
+      // =============================== pass A: logits of every row ===============================
+      {
+        f4 U[8];
+        {
+          const float* qp = p.q + (size_t)seg * 128 + 8 * m;
+          const f4 qa = *reinterpret_cast<const f4*>(qp), qb = *reinterpret_cast<const f4*>(qp + 4);
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int w = (tq * 4 + r) * 2;
+              const f4 wa = *reinterpret_cast<const f4*>(w2k_l + ((size_t)w * 64 + lane) * 4);
+              const f4 wb = *reinterpret_cast<const f4*>(w2k_l + ((size_t)(w + 1) * 64 + lane) * 4);
+              U[tq][r] = (qa[0] * wa[0] + qa[1] * wa[1]) + (qa[2] * wa[2] + qa[3] * wa[3]) +
+                         (qb[0] * wb[0] + qb[1] * wb[1]) + (qb[2] * wb[2] + qb[3] * wb[3]);
+            }
+        }
+#pragma unroll
+        for (int tile = 0; tile < MAXT; ++tile) {
+          lg[tile] = (f4){T2_NEG, T2_NEG, T2_NEG, T2_NEG};
+          feat[tile][0] = feat[tile][1] = feat[tile][2] = 0.f;
+          if (tile < n_tiles) {
+            const int kp = tile * 16 + m;                                  // row = k-th OTHER atom of j
+            const bool valid = kp < nm1 && kp != ip;
+            // angular features of row kp for f = 4 step + g  (uni_denoiser.py:131-135, common.py:85)
+            float theta = 0.f;
+            if (valid) {
+              const int k = kp + (kp >= j ? 1 : 0);
+              const float v0 = xs[k * 3] - xi0, v1 = xs[k * 3 + 1] - xi1, v2 = xs[k * 3 + 2] - xi2;
+              const float dt = u0 * v0 + u1 * v1 + u2 * v2;
+              const float c0 = u1 * v2 - u2 * v1, c1 = u2 * v0 - u0 * v2, c2 = u0 * v1 - u1 * v0;
+              theta = atan2f(sqrtf(c0 * c0 + c1 * c1 + c2 * c2), dt);
+            }
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+              const int f = 4 * st + g;
+              float v = t2_sincos(theta * kT2Freq[f], f >= 6);
+              v = f == 0 ? theta : v;
+              feat[tile][st] = f == 11 ? 1.0f : (valid ? v : 0.f);        // f = 11 carries the per-segment constant Q
+            }
+            // hidden^T[c, row] = P_k[row][c] + Q_k[c] + Wf_k . feat
+            f4 hid[8];
+            const float* pk = prow + (valid ? kp : 0) * T2_ROW + 4 * g;
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              f4 c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+              hid[tq] = valid ? c : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+              for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf_k[(st * 8 + tq) * 64 + lane], feat[tile][st], hid[tq]);
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wk2[tq], feat[tile][2], hid[tq]);
+            // folded LayerNorm + ReLU (packing._kv_mlp): z = ReLU(hidden + b' * sigma); 1/sigma multiplies the 16 logits
+            float q2 = 0.f;
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) q2 = fmaf(hid[tq][r], hid[tq][r], q2);
+            q2 += __shfl_xor(q2, 16);
+            q2 += __shfl_xor(q2, 32);
+            const float var = q2 * (1.f / 128.f) + 1e-5f;
+            const float rs = __builtin_amdgcn_rsqf(var);
+            const float sigma = var * rs;
+            f4 acc4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[r] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              const f4 bt = *reinterpret_cast<const f4*>(bk + 16 * tq + 4 * g);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc4[r] = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), U[tq][r], acc4[r]);
+            }
+            f4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= __shfl(rs, 4 * g + r);     // rstd of row 4g+r lives in lane m = 4g+r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kr = tile * 16 + 4 * g + r;
+              lg[tile][r] = (kr < nm1 && kr != ip) ? acc[r] : T2_NEG;
+            }
+          }
+        }
+      }
+
+      // =============================== softmax over all rows, per head m ===============================
+      float mx = T2_NEG;
+#pragma unroll
+      for (int tile = 0; tile < MAXT; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, lg[tile][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int tile = 0; tile < MAXT; ++tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = lg[tile][r] > 0.5f * T2_NEG ? __builtin_amdgcn_exp2f(lg[tile][r] - mx) : 0.f;
+          lg[tile][r] = e;
+          l += e;
+        }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+
+      // =============================== pass B: S^T[c, h] = sum_rows z_v[row, c] * alpha[row, h] ===============================
+      f4 sT[8];
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq) sT[tq] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tile = 0; tile < MAXT; ++tile) {
+        if (tile < n_tiles) {
+          f4 hv[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kr = tile * 16 + 4 * g + r;
+            const bool valid = kr < nm1 && kr != ip;
+            const float* pv = prow + (valid ? kr : 0) * T2_ROW + 128 + m;
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) {
+              const float c = pv[16 * tq];
+              hv[tq][r] = valid ? c : 0.f;
+            }
+          }
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(feat[tile][st], wf_v[(st * 8 + tq) * 64 + lane], hv[tq]);
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(feat[tile][2], wv2[tq], hv[tq]);
+          // folded LayerNorm + ReLU per row r over c = (tau in-lane, m across the DPP row)
+          f4 q2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) q2 += hv[tq] * hv[tq];
+          f4 sg, aw;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float var = t2_row16_sum(q2[r]) * (1.f / 128.f) + 1e-5f;
+            const float rsq = __builtin_amdgcn_rsqf(var);
+            sg[r] = var * rsq;
+            aw[r] = lg[tile][r] * rsq;                                      // alpha * rstd of the row
+          }
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) {
+            const float bt = bv[16 * tq + m];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[tq][r] = fmaxf(fmaf(bt, sg[r], hv[tq][r]), 0.f);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)            // r outer: 8 independent accumulator chains
+#pragma unroll
+            for (int tq = 0; tq < 8; ++tq) sT[tq] = mfma16(hv[tq][r], aw[r], sT[tq]);
+        }
+      }
+
+      // =============================== epilogue: out = resid + W2v_h . S[:,h] / l + b2v ===============================
+      // W2v streams through L2 in four batches of 16 float4 per lane; the loads of a batch are in flight during the FMAs of
+      // the previous one
+      const size_t ro = (size_t)seg * 128 + 8 * m + 2 * g;
+      const float2 rsd = *reinterpret_cast<const float2*>(p.resid + ro);
+      float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f4 wcur[16], wnxt[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wcur[u] = w2v_g[(size_t)u * 64 + lane];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b < 3) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) wnxt[u] = w2v_g[(size_t)((b + 1) * 16 + u) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int w = b * 16 + u, tq = w >> 3, r = (w >> 1) & 3, hf = (w & 1) * 4;
+          const float sv = sT[tq][r];
+          part[hf + 0] = fmaf(wcur[u][0], sv, part[hf + 0]); part[hf + 1] = fmaf(wcur[u][1], sv, part[hf + 1]);
+          part[hf + 2] = fmaf(wcur[u][2], sv, part[hf + 2]); part[hf + 3] = fmaf(wcur[u][3], sv, part[hf + 3]);
+        }
+        if (b < 3) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) wcur[u] = wnxt[u];
+        }
+      }
+#pragma unroll
+      for (int dd = 0; dd < 8; ++dd) {
+        part[dd] += __shfl_xor(part[dd], 16);
+        part[dd] += __shfl_xor(part[dd], 32);
+      }
+      const float has = l > 0.f ? 1.f : 0.f;
+      const int o0 = 8 * m + 2 * g;
+      const float p0 = g == 0 ? part[0] : (g == 1 ? part[2] : (g == 2 ? part[4] : part[6]));
+      const float p1 = g == 0 ? part[1] : (g == 1 ? part[3] : (g == 2 ? part[5] : part[7]));
+      float2 o;
+      o.x = rsd.x + p0 * inv + b2v[o0] * has;
+      o.y = rsd.y + p1 * inv + b2v[o0 + 1] * has;
+      *reinterpret_cast<float2*>(p.out + ro) = o;
+    }
+  }
+}
+
+template <int THREADS, int MAXT>
+static int launch_t2(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  const size_t lds = t2_lds_floats() * sizeof(float);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(triplet2_kernel<THREADS, MAXT>), lds, "pg_seg_attn(triplet, staged)")) return rc;
+  hipError_t e = hipMemsetAsync(p->tri_counter, 0, sizeof(int), st);
+  if (e != hipSuccess) { set_error("pg_seg_attn(triplet, staged): %s", hipGetErrorString(e)); return PG_ERR_HIP; }
+  hipLaunchKernelGGL((triplet2_kernel<THREADS, MAXT>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p);
+  return check_launch("pg_seg_attn(triplet, staged)");
+}
+
+// usable when the caller provides the source-atom groups (PgSegAttn.tri_iters), asks for the sampling form (out = resid +
+// update, no S / alpha side outputs) and P is one [n_bond, 256] = [P_k | P_v] tensor; returns -1 otherwise
+int launch_triplet_staged(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  if (!p->tri_iters || !p->tri_counter || p->n_tri_iters <= 0 || p->S || p->alpha || !p->out || !p->resid) return -1;
+  if (p->Csrc_v != p->Csrc_k + 128 || p->ld_csrc != 256 || ((size_t)p->Csrc_k & 15)) return -1;
+  if (t->max_nlig - 1 > T2_ROWS || t->max_nlig > T2_XS) return -1;
+  const int tiles = (t->max_nlig - 1 + 15) / 16;
+  if (tiles <= 3) return launch_t2<512, 3>(t, p, st);
+  if (tiles == 4) return launch_t2<512, 4>(t, p, st);
+  return launch_t2<512, 5>(t, p, st);
+}
+
+}  // namespace pg

@@ -38,6 +38,7 @@ class Engine:
         # kernels of different chains interleave on the CUs, so one chain's load/store phases meet another's MFMA phases
         self.multi_stream = os.environ.get('PG_STREAMS', '1') != '0'
         self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
+        self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -80,6 +81,7 @@ class Engine:
         w.swn = [_f(n, 16, device=d) for _ in range(2)]
         w.aggE, w.aggB = _f(n, 128, device=d, zero=True), _f(n, 128, device=d, zero=True)
         w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)
+        w.Qd = _f(E, 256, device=d)                                    # triplet: per-segment constant smear(d_ji) . Wg2 (k | v)
         w.qhid, w.qT = _f(E, 128, device=d), _f(E, 128, device=d)
         w.dxe, w.dxb = _f(n, 3, device=d, zero=True), _f(n, 3, device=d, zero=True)
         w.head = _f(n, 128, device=d)
@@ -270,6 +272,7 @@ class Engine:
                    g['W0'].data_ptr(), g['b0'].data_ptr(), g['g'].data_ptr(), g['b'].data_ptr(), g['W3'].data_ptr(),
                    C.c_float(g['b3']), w.ew.data_ptr())
         cur = 0
+        staged = bool(p.n_tri_iters and self.staged_triplet)
         self._mark(prog, 'graph', w.nbr, w.deg, w.ew)
         for li, L in enumerate(pk.layers):
             nxt = 1 - cur
@@ -298,6 +301,8 @@ class Engine:
                        add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
                        add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)
             self._lane = 3                                                              # triplet queries [lane 3]
+            if staged:       # the per-segment constant of the triplet MLPs as rows (the gather kernel computes it in-kernel)
+                self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256)
             self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
             self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
                        scale=HEAD_SCALE)
@@ -308,7 +313,9 @@ class Engine:
             self.tri_calls.append(len(prog))
             self._seg(prog, hip.SEG_TRIPLET, E, p.tri_order, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
                       ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
-                      W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks)
+                      W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks,
+                      **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter,
+                              Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
             self._join(prog, (1, 2))
             # ---- h' = h + lin_node(aggE + aggB) (:288)

@@ -44,7 +44,8 @@ class PgSegAttn(C.Structure):
                 ('U', c_fp), ('q', c_fp), ('W2k_l', c_fp), ('W2v_l', c_fp), ('b2v', c_fp),
                 ('W2xv_l', c_fp), ('b2xv', c_fp),
                 ('S', c_fp), ('swn', c_fp), ('resid', c_fp), ('out', c_fp), ('dx', c_fp),
-                ('accumulate_dx', C.c_int), ('alpha', c_fp), ('alpha_rows', C.c_int), ('efeat', c_fp), ('efeat_off', c_ip)]
+                ('accumulate_dx', C.c_int), ('alpha', c_fp), ('alpha_rows', C.c_int), ('efeat', c_fp), ('efeat_off', c_ip),
+                ('tri_iters', c_ip), ('n_tri_iters', C.c_int), ('tri_counter', c_ip)]
 
 
 class PgSegAttnGrad(C.Structure):

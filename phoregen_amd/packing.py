@@ -174,6 +174,7 @@ def pack_triplet(sd, p):
     a.W_q_hb = q['W1'][:, 0:128].contiguous()
     a.Wg2_k = k['W1'][:, 148:168].t().contiguous()                                    # [20,128]
     a.Wg2_v = v['W1'][:, 148:168].t().contiguous()
+    a.W_g2 = torch.cat([k['W1'][:, 148:168], v['W1'][:, 148:168]], 0).contiguous()   # [256,20]: Q = smear(d_ji) . W_g2^T as one GEMM
     a.Wf_k = lane_fixed_feat(_tri_feat(k['W1']))
     a.Wf_v = lane_fixed_feat(_tri_feat(v['W1']))
     _common(a, k, v, q, pos=False)

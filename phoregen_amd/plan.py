@@ -103,6 +103,24 @@ class BatchPlan:
         targets = torch.linspace(0, float(csum[-1]), 257, dtype=torch.double)
         self.tri_chunks = i32(torch.searchsorted(csum, targets).clamp(max=self.n_bond))
         self.tri_chunks[0], self.tri_chunks[-1] = 0, self.n_bond
+        # source-atom groups of the LDS-staged triplet kernel (csrc/triplet2.hip): consecutive source atoms of one ligand whose
+        # P blocks ((n-1) rows each) fit the 80 staged rows; pulled from a queue, most expensive first
+        rows_cap, waves = 80, 8
+        its = []
+        for gi in range(B):
+            n = int(nlig[gi])
+            if n < 2 or n - 1 > rows_cap or n > 96:
+                continue
+            A = max(1, min(rows_cap // (n - 1), n))
+            tiles = (n - 1 + 15) // 16
+            for j0 in range(0, n, A):
+                a = min(A, n - j0)
+                rounds = (a * (n - 1) + waves - 1) // waves
+                its.append((rounds * (tiles + 1.0) + 0.5, int(lig2ctx[lig_off[gi]]), n | (j0 << 8) | (a << 16), int(bond_off[gi])))
+        its.sort(key=lambda r: -r[0])
+        self.tri_iters = torch.tensor([[r[1], r[2], r[3], 0] for r in its], dtype=torch.int32).reshape(-1, 4).to(device)
+        self.n_tri_iters = len(its) if (B and int(nlig.max()) - 1 <= rows_cap and int(nlig.max()) <= 96) else 0
+        self.tri_counter = torch.zeros(1, dtype=torch.int32, device=device)
         for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
                      'bond_src', 'bond_dst', 'bond_desc', 'g_bond_off'):
             setattr(t, name, getattr(self, name).data_ptr())

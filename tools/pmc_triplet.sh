@@ -10,4 +10,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${tag}/p$i -- python3 tools/bench_triplet.py 4 > gpurun_out/pmc_${tag}/log$i.txt 2>&1
 done
-python3 tools/pmc_summary.py gpurun_out/pmc_${tag} triplet_kernel
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag} ${2:-triplet}
