@@ -86,8 +86,9 @@ def subset_workload(w, graph_ids):
 
 
 def triplet_tiles(n_at):
-    """16-row tiles the triplet kernel walks per segment of a ligand with n atoms (rows = the n atoms, 2 of them masked)."""
-    return (n_at + 15) // 16
+    """16-row tiles the staged triplet kernel (csrc/triplet2.hip) walks per segment of a ligand with n atoms: its rows are
+    the n-1 OTHER atoms of the source atom (one of them, the target, masked)."""
+    return (n_at - 1 + 15) // 16
 
 
 def algorithmic_counts(n_at, n_ph, knn=32, H=128):
@@ -111,7 +112,7 @@ def algorithmic_counts(n_at, n_ph, knn=32, H=128):
     tri_exec = tiles * 112 * 2048 + e_bond * (2 * 2 * H * H + 2 * 2 * 20 * H)
     return dict(n_all=n_all, n_lig=n_lig, e_knn=e_knn, e_bond=e_bond, e3=e3, flops_step=6 * layer_f,
                 flops_triplet_kernel=tri_kernel, flops_triplet_executed=tri_exec, tri_tiles=tiles, bytes_step=step_b,
-                tri_useful_rows=e3, tri_padded_rows=16 * tiles)
+                tri_useful_rows=e3, tri_padded_rows=16 * tiles)      # (e3 = n(n-1)(n-2) useful rows)
 
 
 # ---------------------------------------------------------------------------- CPU baseline (oracle, bounded sample)

@@ -33,3 +33,4 @@ E, n = 203720, 18401
 run(E, 128, 128); run(E, 128, 128, gather=1); run(E, 128, 128, ln=True); run(E, 128, 128, act=1)
 run(E, 256, 128); run(E, 256, 128, gather=1); run(E, 256, 128, K2=20, gather=2)
 run(n, 1920, 128); run(n, 1280, 128); run(n, 128, 128, ln=True, ldx=1920); run(n, 128, 256)
+run(E, 256, 20)
