@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p PG_ABL_PARAM) {
   __shared__ float rstat[BM * 2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  // column tiles of one row block are adjacent in dispatch order: the A rows they share are read from HBM once, then from L2
+  const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
   const int K = p.K1 + p.K2;
   const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;  // wave sub-tile origin
   const bool ln = p.ln_gamma != nullptr;
@@ -382,7 +383,7 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
     if (K == 128) return pg::launch_ws<129>(p, (hipStream_t)stream);
     if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
   }
-  dim3 grid((p->M + pg::BM - 1) / pg::BM, (p->N + pg::BN - 1) / pg::BN);
+  dim3 grid((p->N + pg::BN - 1) / pg::BN, (p->M + pg::BM - 1) / pg::BM);
   hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p PG_ABL_ARG("PG_GEMM_ABLATE"));
   return pg::check_launch("pg_gemm");
 }

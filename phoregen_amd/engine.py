@@ -39,6 +39,7 @@ class Engine:
         self.multi_stream = os.environ.get('PG_STREAMS', '1') != '0'
         self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
         self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
+        self.fused_bond_rows = os.environ.get('PG_BOND_FUSED', '0') != '0'     # csrc/bondrow.hip; off: measured slower than the separate pg_gemm launches
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -159,6 +160,32 @@ class Engine:
         g.rows = hip.ptr(rows)
         self._keep += [g, X, W, Y, bias, X2, ln, add1, idx1, add2, idx2, rows]
         self._call(prog, self.lib.pg_gemm, C.byref(g))
+
+    def _bond_rows(self, prog, hb, G, jobs):
+        """One fused launch over the bond rows (csrc/bondrow.hip).  jobs: dicts with W, k0, K, N, Y and optional bias,
+        add1/idx1 ('src'|'dst'), add2/idx2, or for the query MLP: ln=(gamma, beta), W2, b2, scale2, Y2."""
+        p = self.plan
+        b = hip.PgBondRows()
+        b.hb, b.ld_hb, b.G = hb.data_ptr(), hb.stride(0), hip.ptr(G)
+        b.idx_a, b.idx_b, b.E, b.n_jobs = p.bond_src.data_ptr(), p.bond_dst.data_ptr(), p.n_bond, len(jobs)
+        for j, d in zip(b.jobs, jobs):
+            W = d['W']
+            j.W, j.ldw, j.k0, j.K, j.N = W.data_ptr(), W.stride(0), d['k0'], d['K'], d['N']
+            j.bias = hip.ptr(d.get('bias'))
+            for n in ('1', '2'):
+                t = d.get('add' + n)
+                if t is not None:
+                    setattr(j, 'add' + n, t.data_ptr())
+                    setattr(j, 'ld_add' + n, t.stride(0))
+                    setattr(j, f'idx{n}_is_b', int(d['idx' + n] == 'dst'))
+            if 'W2' in d:
+                j.ln_g, j.ln_b, j.W2, j.b2 = d['ln'][0].data_ptr(), d['ln'][1].data_ptr(), d['W2'].data_ptr(), hip.ptr(d.get('b2'))
+                j.N2, j.scale2, j.Y2, j.ldy2 = d['W2'].size(0), d.get('scale2', 1.0), d['Y2'].data_ptr(), d['Y2'].stride(0)
+            else:
+                j.Y, j.ldy = d['Y'].data_ptr(), d['Y'].stride(0)
+            self._keep += list(v for v in d.values() if torch.is_tensor(v)) + [d.get('ln')]
+        self._keep += [b, hb, G]
+        self._call(prog, self.lib.pg_bond_rows, C.byref(b))
 
     def _seg(self, prog, mode, n_seg, seg_ids, a, **kw):
         s = hip.PgSegAttn()
@@ -287,26 +314,38 @@ class Engine:
                 self._gemm(prog, hc, 128, L.W_node1[640:], w.Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
             else:
                 self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
+            if self.fused_bond_rows:
+                # every product over the OLD h_bond in one launch: bond-node k/v source halves, triplet P, the triplet's
+                # per-segment constant and the triplet query MLP (hidden layer kept on chip)
+                Y1b = lambda b0, b1: w.Y1[:, b0 * 128:b1 * 128]
+                self._bond_rows(prog, hbc, w.G, [
+                    dict(W=L.NB.W_hb, k0=0, K=128, N=256, Y=w.CsB, add1=Y1b(7, 9), idx1='src'),
+                    dict(W=L.TB.W_hbg, k0=0, K=148, N=256, Y=w.P, add1=Y1b(10, 12), idx1='src', add2=Y1b(12, 14), idx2='dst'),
+                    dict(W=L.TB.W_g2, k0=128, K=20, N=256, Y=w.Qd),
+                    dict(W=L.TB.W_q_hb, k0=0, K=128, N=128, add1=Y1b(14, 15), idx1='dst', ln=(L.TB.q_ln_g, L.TB.q_ln_b),
+                         W2=L.TB.W2q, b2=L.TB.b2q, scale2=HEAD_SCALE, Y2=w.qT)])
             self._fork(prog, (1, 2, 3))
             # ---- node update over knn edges (:281)                                    [lane 1]
             self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0)
             # ---- node update over bond edges (:284)                                   [lane 2]
             self._lane = 2
-            self._gemm(prog, hbc, 128, L.NB.W_hb, w.CsB, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            if not self.fused_bond_rows:
+                self._gemm(prog, hbc, 128, L.NB.W_hb, w.CsB, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
             self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB, buf=1)
             # ---- bond update over triplets (:285)                                     [lane 0]
             self._lane = 0
-            self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
-                       add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
-                       add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)
-            self._lane = 3                                                              # triplet queries [lane 3]
-            if staged:       # the per-segment constant of the triplet MLPs as rows (the gather kernel computes it in-kernel)
-                self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256)
-            self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
-            self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
-                       scale=HEAD_SCALE)
-            self._lane = 0
+            if not self.fused_bond_rows:
+                self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
+                           add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
+                           add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)
+                self._lane = 3                                                          # triplet queries [lane 3]
+                if staged:   # the per-segment constant of the triplet MLPs as rows (the gather kernel computes it in-kernel)
+                    self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256)
+                self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
+                self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
+                           scale=HEAD_SCALE)
+                self._lane = 0
             self._join(prog, (3,))
             a = L.TB
             self._event(prog, 'triplet', True)
@@ -333,7 +372,10 @@ class Engine:
             self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
-            self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            if self.fused_bond_rows:
+                self._bond_rows(prog, hbn, None, [dict(W=L.PB.W_hb, k0=0, K=128, N=256, Y=w.CsB, add1=w.Y2[:, 7 * 128:9 * 128], idx1='src')])
+            else:
+                self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
             self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1)
             self._join(prog, (1,))
             self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
