@@ -209,7 +209,14 @@ def main():
                     help='weak scaling only: --graphs graphs PER GPU (default: strong scaling, SURVEY.md 8d: ONE batch of '
                          '--graphs graphs partitioned over the ranks by n^3 cost; a weak-scaling figure is added for N > 1)')
     ap.add_argument('--strong', action='store_true', help='(default) kept for compatibility')
+    ap.add_argument('--train', action='store_true',
+                    help='BASELINE config 5 instead: one compute_loss forward + backward + Adam step on 256 synthetic pairs '
+                         '(tools/bench_train.py prints its own JSON line, ms/step)')
     args = ap.parse_args()
+    if args.train:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_train
+        return bench_train.main(['--steps', str(max(args.steps // 8, 3)), '--warmup', '2'])
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(_spawn_ranks(args.gpus))

@@ -140,3 +140,78 @@ def allreduce_gradients(params, group=None, average=True):
             p.grad.copy_(g)
         off += p.numel()
     return flat.numel()
+
+
+class GradientBuckets:
+    """Bucketed gradient all-reduce launched from gradient hooks (the reference's harness, run/run.py:160-311,
+    is single-GPU).  Parameters are grouped into ~`bucket_mb` MB buckets in reverse registration order (roughly the order their
+    gradients are produced); a `post_accumulate_grad` hook counts arrivals and, when a bucket is complete, packs it and starts
+    an ASYNCHRONOUS all-reduce (RCCL runs it on its own stream: the collective of bucket k travels over xGMI while the
+    backward of the earlier layers is still computing).  `finish()` -- before `optimizer.step()` -- reduces whatever did not
+    fire (parameters without a gradient contribute zeros), waits, averages and writes the results back into `.grad`.
+    A few-MB bucket is the size at which an xGMI ring (per-link bound, ~153 GB/s) is already bandwidth- rather than
+    latency-dominated; PhoreDiff's 20.8 MB of gradients make ~5 buckets."""
+
+    def __init__(self, params, bucket_mb=4.0, group=None, average=True):
+        self.group, self.average = group, average
+        params = [p for p in params if p.requires_grad]
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets, cur, n = [], [], 0
+        for p in reversed(params):
+            cur.append(p)
+            n += p.numel()
+            if n >= cap:
+                self.buckets.append(cur)
+                cur, n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.owner = {id(p): bi for bi, b in enumerate(self.buckets) for p in b}
+        self.flat = [None] * len(self.buckets)
+        self.work = [None] * len(self.buckets)
+        self.ready = [0] * len(self.buckets)
+        self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _on_grad(self, p):
+        bi = self.owner[id(p)]
+        self.ready[bi] += 1
+        if self.ready[bi] == len(self.buckets[bi]) and self.work[bi] is None:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+        self.flat[bi] = flat
+        self.work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self._active() else True
+
+    def finish(self):
+        """Wait for every bucket (launching the ones whose hooks did not all fire) and write the reduced gradients back."""
+        world = dist.get_world_size(self.group) if self._active() else 1
+        for bi, b in enumerate(self.buckets):
+            if self.work[bi] is None:
+                self._launch(bi)
+        n_elems = 0
+        for bi, b in enumerate(self.buckets):
+            if self.work[bi] is not True:
+                self.work[bi].wait()
+            flat = self.flat[bi]
+            if self.average and world > 1:
+                flat /= world
+            off = 0
+            for p in b:
+                g = flat[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
+            n_elems += off
+            self.flat[bi], self.work[bi], self.ready[bi] = None, None, 0
+        return n_elems
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []

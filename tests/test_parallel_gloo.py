@@ -115,3 +115,51 @@ def test_strong_scaling_partition_covers_the_workload():
         assert torch.equal(s['h_phore'][0], w['h_phore'][first])
         seen += ids.tolist()
     assert sorted(seen) == list(range(16))
+
+
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from phoregen_amd.parallel import GradientBuckets
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.ReLU(), torch.nn.Linear(300, 300), torch.nn.ReLU(), torch.nn.Linear(300, 7))
+    net[4].bias.requires_grad_(False)
+    extra = torch.nn.Parameter(torch.zeros(11))                 # never used: no gradient on any rank
+    params = list(net.parameters()) + [extra]
+    gb = GradientBuckets(params, bucket_mb=0.2)
+    assert len(gb.buckets) >= 2
+    x = torch.randn(16, 40, generator=torch.Generator().manual_seed(10 + rank))
+    out = {}
+    for it in range(2):                                          # two steps: counters reset correctly
+        for p in params:
+            p.grad = None
+        net(x).pow(2).sum().backward()
+        local = [p.grad.numpy().copy() if p.grad is not None else None for p in params]
+        n = gb.finish()
+        out[it] = (local, [p.grad.numpy().copy() if p.grad is not None else None for p in params], n)      # numpy: plain pickles
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_bucketed_hook_allreduce_world_size_2_gloo():
+    """GradientBuckets (f-4): hook-launched asynchronous bucket all-reduces == the mean of the ranks' local gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    for it in range(2):
+        l0, r0, n0 = res[0][it]
+        l1, r1, n1 = res[1][it]
+        import numpy as np
+        assert n0 == n1 == sum(t.size for t in r0 if t is not None)
+        for a, b, ra, rb in zip(l0, l1, r0, r1):
+            if ra is None:
+                continue
+            za = a if a is not None else np.zeros_like(ra)
+            zb = b if b is not None else np.zeros_like(rb)
+            assert np.allclose(ra, (za + zb) / 2, atol=1e-6) and np.array_equal(ra, rb)

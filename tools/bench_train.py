@@ -33,19 +33,19 @@ def train_workload(n_graphs=256, seed=4321, n_mean=25.0, n_std=5.0, n_max=60):
     return batch, na
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--graphs', type=int, default=256)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--n-mean', type=float, default=25.0, help='mean ligand size (config 5: 25; the sampler headline shape: 40)')
     ap.add_argument('--n-max', type=int, default=60)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from phoregen_amd.config import default_model_config
     from phoregen_amd.models.diffusion import PhoreDiff
     from phoregen_amd.weights import init_deterministic_
     import torch.distributed as dist
-    from phoregen_amd.parallel import allreduce_gradients
+    from phoregen_amd.parallel import GradientBuckets
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1)    # (a 2-rank dry run can share one GPU)
     if world > 1:       # data parallel: one process per GPU, each its own 256-pair batch, one flat gradient bucket over RCCL
@@ -56,14 +56,16 @@ def main():
     batch, na = train_workload(a.graphs, seed=4321 + rank, n_mean=a.n_mean, n_std=a.n_mean / 5.0, n_max=a.n_max)
     batch.to(dev)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    # data parallel: ~4 MB gradient buckets, all-reduced asynchronously from gradient hooks while the backward continues
+    buckets = GradientBuckets(model.parameters(), bucket_mb=4.0) if world > 1 else None
     torch.manual_seed(0)
 
     def step():
         opt.zero_grad(set_to_none=True)
         loss, info = model.compute_loss(batch)
         loss.backward()
-        if world > 1:
-            allreduce_gradients(model.parameters())
+        if buckets is not None:
+            buckets.finish()
         opt.step()
         return info
     for _ in range(a.warmup):
