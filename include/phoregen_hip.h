@@ -60,6 +60,9 @@ typedef struct {
   const int* rows;           /* optional [M]: logical row r reads X/X2 row rows[r] and writes Y row rows[r] (row subset) */
 } PgGemm;
 int pg_gemm(const PgGemm* p, void* stream);
+/* test / tuning hook (returns the old setting): 0 keeps the tall [h_bond | G] product on the tiled kernel instead of the
+ * wave-specialised one, 2 sends the K = 128 bond-row products there as well */
+int pg_debug_gemm_specialised(int on);
 
 /* ---- fused dense layers over the bond rows ---------------------------------------------------------------
  * Every job is Y_j[e, 0:N] = [h_bond | G][e, k0:k0+K] . W_j[0:N, 0:K]^T + bias_j + add1_j[idx(e)] + add2_j[idx'(e)] for all

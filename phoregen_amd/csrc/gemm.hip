@@ -347,6 +347,157 @@ static int launch_ws(const PgGemm* p, hipStream_t st) {
   return check_launch("pg_gemm(ws)");
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant for the tall bond-row products (M ~ 2e5, K = 128 or 128+20, N a multiple of 128, plain epilogue:
+// bias + up to two gathered row adds).  The tiled kernel above runs its load, MFMA and store phases in lockstep on all
+// co-resident workgroups, so their times add (26 + 45 + 28 us at N = 128).  Here a persistent 8-wave workgroup per CU splits
+// the roles:
+//   * waves 4-7 ("memory"): fetch the NEXT 64-row A tile (and the tile's gather indices) into the other LDS buffer;
+//   * waves 0-3 ("compute"): gathered epilogue operands -> registers (not touched until the MFMAs are done: waves issue in
+//     order), 64 x 32 output block per wave on v_mfma_f32_32x32x2_f32 with the 128 x K weight block resident in LDS,
+//     then bias / adds and stores straight from the accumulators;
+//   * one workgroup barrier per tile hands the buffers over.  HBM reads, MFMAs and stores of neighbouring tiles overlap by
+//     construction instead of by luck.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SP_THREADS = 512, SP_BM = 64;
+
+template <int KP /* odd LDS row stride >= K */>
+__global__ __launch_bounds__(SP_THREADS) void gemm_sp_kernel(PgGemm p PG_ABL_PARAM) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* const Ws = sm;                               // [128][KP]
+  float* const Ab = Ws + 128 * KP;                    // [2][64][KP]
+  int* const Ix = reinterpret_cast<int*>(Ab + 2 * SP_BM * KP);   // [2 buffers][2 index arrays][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool mem_role = wave >= 4;
+  constexpr int K = KP - 1, K4 = K >> 2;            // 128 or 148: compile-time, so the piece -> (row, k) maps cost no divisions
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n_tiles = (p.M + SP_BM - 1) / SP_BM;
+  const int n_cb = (p.N + 127) / 128;
+
+  // memory-role mapping: 256 lanes, 64 rows x K4 float4 pieces
+  const int mt = tid - 256;
+  auto fetch_store = [&](int tile, int buf) {
+    f4 ra[10];
+    constexpr int total = SP_BM * K4;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      int e = mt + i * 256;
+      e = e < total ? e : total - 1;
+      const int r = e / K4, k4 = e - r * K4;
+      int grow = tile * SP_BM + r;
+      grow = grow < p.M ? grow : p.M - 1;
+      const int kq = 4 * k4;
+      ra[i] = kq < p.K1 ? *reinterpret_cast<const f4*>(p.X + (size_t)grow * p.ldx + kq)
+                        : *reinterpret_cast<const f4*>(p.X2 + (size_t)grow * p.ldx2 + (kq - p.K1));
+    }
+    int iv = 0;
+    if (mt < 128) {
+      const int* src = mt < 64 ? p.idx1 : p.idx2;
+      int grow = tile * SP_BM + (mt & 63);
+      grow = grow < p.M ? grow : p.M - 1;
+      iv = src ? src[grow] : grow;
+    }
+    float* dst = Ab + buf * SP_BM * KP;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int e = mt + i * 256;
+      if (e < total) {
+        const int r = e / K4, k4 = e - r * K4;
+        float* d = dst + r * KP + 4 * k4;
+        d[0] = ra[i][0]; d[1] = ra[i][1]; d[2] = ra[i][2]; d[3] = ra[i][3];
+      }
+    }
+    if (mt < 128) Ix[buf * 128 + mt] = iv;
+  };
+
+  for (int cb = 0; cb < n_cb; ++cb) {
+    const int col0 = cb * 128;
+    __syncthreads();                                   // previous column block: nobody reads Ws / Ab any more
+    for (int i = tid; i < 128 * K4; i += SP_THREADS) { // the column block's weight rows
+      const int r = i / K4, kq = (i - r * K4) * 4;
+      f4 w = {0.f, 0.f, 0.f, 0.f};
+      if (col0 + r < p.N) w = *reinterpret_cast<const f4*>(p.W + (size_t)(col0 + r) * p.ldw + kq);
+      float* d = Ws + r * KP + kq;
+      d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+    }
+    if (mem_role && (int)blockIdx.x < n_tiles) fetch_store(blockIdx.x, 0);
+    __syncthreads();
+    int it = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++it) {
+      const int buf = it & 1;
+      if (mem_role) {
+        if (tile + (int)gridDim.x < n_tiles && !PG_ABL(1)) fetch_store(tile + gridDim.x, buf ^ 1);
+      } else {
+        const int gcol = col0 + 32 * wave + l31;
+        const bool col_ok = gcol < p.N;
+        const int row0 = tile * SP_BM;
+        // epilogue operands first (raw, consumed after the MFMAs)
+        f16v l1[2], l2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { l1[i][r] = 0.f; l2[i][r] = 0.f; }
+        const float bsv = (p.bias && col_ok) ? p.bias[gcol] : 0.f;
+        if (col_ok) {
+          const int* ix = Ix + buf * 128;
+          if (p.add1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                l1[i][r] = p.add1[(size_t)ix[32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh] * p.ld_add1 + gcol];
+          }
+          if (p.add2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                l2[i][r] = p.add2[(size_t)ix[64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh] * p.ld_add2 + gcol];
+          }
+        }
+        f16v acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const float* a0 = Ab + buf * SP_BM * KP + l31 * KP + lh;
+        const float* a1 = a0 + 32 * KP;
+        const float* bw = Ws + (32 * wave + l31) * KP + lh;
+        // fully unrolled (K is a compile-time constant): the scheduler spreads the 3 LDS operand reads of a k-step far ahead of
+        // their MFMAs; a 4-step rolled loop put a wait in front of every MFMA and ran at half the rate
+        constexpr int ksteps = K >> 1;
+#pragma unroll
+        for (int ks = 0; ks < ksteps; ++ks) {
+          if (PG_ABL(2) && ks > 0) break;
+          const float b = bw[2 * ks];
+          acc[0] = mfma32(a0[2 * ks], b, acc[0]);
+          acc[1] = mfma32(a1[2 * ks], b, acc[1]);
+        }
+        if (col_ok && !PG_ABL(4)) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int grow = row0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if (grow < p.M) p.Y[(size_t)grow * p.ldy + gcol] = ((acc[i][r] + bsv) + l1[i][r]) + l2[i][r];
+            }
+        }
+      }
+      __syncthreads();                                 // next tile landed, this tile's buffer is free
+    }
+  }
+}
+
+template <int KP>
+static int launch_sp(const PgGemm* p, hipStream_t st) {
+  const size_t lds = ((size_t)128 * KP + 2 * SP_BM * KP + 256) * sizeof(float);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(gemm_sp_kernel<KP>), lds, "pg_gemm(sp)")) return rc;
+  const int n_tiles = (p->M + SP_BM - 1) / SP_BM;
+  hipLaunchKernelGGL(gemm_sp_kernel<KP>, dim3(n_tiles < kNumCU ? n_tiles : kNumCU), dim3(SP_THREADS), lds, st, *p PG_ABL_ARG("PG_GEMM_ABLATE"));
+  return check_launch("pg_gemm(sp)");
+}
+
 // ---- small per-row linear (n_out <= 16): one wave per row ----------------------------------------
 __global__ __launch_bounds__(256) void rows_linear_kernel(const float* X, int ldx, int K, const float* W, const float* b,
                                                           int n_out, int M, const int* rows, float* Y, int ldy) {
@@ -369,6 +520,9 @@ __global__ __launch_bounds__(256) void rows_linear_kernel(const float* X, int ld
 
 }  // namespace pg
 
+static int g_gemm_sp = 1;
+extern "C" int pg_debug_gemm_specialised(int on) { const int old = g_gemm_sp; g_gemm_sp = on; return old; }
+
 extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   if (!p || !p->X || !p->W || !p->Y || p->M < 0 || p->N <= 0) { pg::set_error("pg_gemm: bad arguments"); return PG_ERR_ARG; }
   if (p->M == 0) return PG_OK;
@@ -382,6 +536,14 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   if (p->M >= 32768 && al && p->N <= 256 && p->ln_gamma && !p->rows) {
     if (K == 128) return pg::launch_ws<129>(p, (hipStream_t)stream);
     if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
+  }
+  // plain-epilogue bond-row products: wave-specialised persistent kernel (loads / MFMAs / stores of neighbouring tiles overlap)
+  // Measured (tools/bench_gemm.py, M = 203 720): K = 148 with two gathered adds 221 vs 295 us on the tiled kernel; at K = 128
+  // the specialised kernel is 5-10 % slower than the tiled one (118 vs 108 us: its per-tile barrier hand-over, not the MFMAs,
+  // sets the pace), so only the [h_bond | G] product takes this path unless pg_debug_gemm_specialised(2) forces it
+  if (g_gemm_sp && p->M >= 32768 && al && !p->ln_gamma && !p->rows && p->act == 0 && p->out_scale == 1.0f && p->K1 == 128 &&
+      (p->K2 == 20 || (p->K2 == 0 && g_gemm_sp == 2)) && (p->N & 127) == 0 && (!p->add1 || p->idx1) && (!p->add2 || p->idx2)) {
+    return p->K2 ? pg::launch_sp<149>(p, (hipStream_t)stream) : pg::launch_sp<129>(p, (hipStream_t)stream);
   }
   dim3 grid((p->N + pg::BN - 1) / pg::BN, (p->M + pg::BM - 1) / pg::BM);
   hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p PG_ABL_ARG("PG_GEMM_ABLATE"));

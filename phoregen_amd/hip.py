@@ -88,6 +88,7 @@ _PROTOS = {
     'pg_debug_force_generic_seg': (C.c_int, [C.c_int]),
     'pg_gemm': (C.c_int, [C.POINTER(PgGemm), C.c_void_p]),
     'pg_bond_rows': (C.c_int, [C.POINTER(PgBondRows), C.c_void_p]),
+    'pg_debug_gemm_specialised': (C.c_int, [C.c_int]),
     'pg_embed_ctx': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 11 + [C.c_void_p]),
     'pg_embed_bond': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 7 + [C.c_void_p]),
     'pg_knn_ctx': (C.c_int, [C.POINTER(PgTopo), c_fp, C.c_int, c_ip, c_ip, C.c_void_p]),
