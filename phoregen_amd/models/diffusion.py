@@ -313,8 +313,9 @@ class PhoreDiff(nn.Module):
         ph = data['phore']
         if seed is None:
             # a fresh key per call, drawn from torch's default generator: repeated sample() calls (sample_all.py's while loop)
-            # get different noise like the reference's global-RNG draws do, and `seed_all(seed)` still makes a run reproducible
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            # get different noise like the reference's global-RNG draws do, and `seed_all(seed)` still makes a run reproducible.
+            # rng='cpu' replays the reference's own CPU draws: nothing extra may be taken from that generator there.
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if rng == 'device' else 0
         if num_atoms is None:
             num_atoms = self.sample_nodes(data, n_graphs, device, sample_mode, normal_scale)
         p = ph.x.size(0)
