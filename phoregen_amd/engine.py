@@ -122,10 +122,10 @@ class Engine:
 
     def _event(self, prog, name, start):
         """Timing tap: when `self.timers` is a dict, record a HIP event on the launch stream around a kernel."""
-        def tap(_stream):
+        def tap(streams):
             if self.timers is not None:
                 ev = torch.cuda.Event(enable_timing=True)
-                ev.record()
+                ev.record(streams[0])
                 self.timers.setdefault(name, []).append((start, ev))
             return 0
         tap.__name__ = 'event_' + name
