@@ -68,6 +68,27 @@ __device__ __forceinline__ float t2_sincos(float arg, bool want_cos) {
   return (q & 2) ? -v : v;
 }
 
+// sin and cos of one argument (0 <= arg <= ~4) from ONE range reduction: k = rint(arg * 2/pi), r = arg - k pi/2 (two constants),
+// both polynomials on [-pi/4, pi/4], quadrant rotation
+__device__ __forceinline__ void t2_sincos_pair(float arg, float& sn, float& cs) {
+  const float kf = rintf(arg * 0.63661977236758134308f);
+  float r = fmaf(-kf, 1.57079637050628662109375f, arg);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  const int q = (int)kf;
+  const float s = r * r;
+  float ps = fmaf(s, 2.7557314297e-6f, -1.9841270114e-4f);
+  ps = fmaf(ps, s, 8.3333337680e-3f);
+  ps = fmaf(ps, s, -1.6666667163e-1f);
+  ps = fmaf(ps * s, r, r);
+  float pc = fmaf(s, 2.4801587642e-5f, -1.3888889225e-3f);
+  pc = fmaf(pc, s, 4.1666667908e-2f);
+  pc = fmaf(pc, s, -0.5f);
+  pc = fmaf(pc, s, 1.0f);
+  const float a = (q & 1) ? pc : ps, b = (q & 1) ? ps : pc;       // sin(arg) = +-a, cos(arg) = +-b
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
 __device__ __constant__ const float kT2Freq[12] = {0.f, 1.f, 2.f, 3.f, 0.5f, (float)(1.0 / 3.0), 1.f, 2.f, 3.f, 0.5f,
                                                     (float)(1.0 / 3.0), 0.f};
 
@@ -215,12 +236,17 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
             const int kc = kp < nm1 ? kp : 0;                              // rows past the ligand read row 0 (finite, masked below)
             const float theta = t2_from_lane(th_own[tile >> 2], 16 * (tile & 3) + m);
             // angular features of row kp for f = 4 step + g  (common.py:85); f = 11 carries the per-segment constant Q
-#pragma unroll
-            for (int st = 0; st < 3; ++st) {
-              const int f = 4 * st + g;
-              const float v = t2_sincos(theta * kT2Freq[f], f >= 6);
-              feat[tile][st] = f == 0 ? theta : (f == 11 ? 1.0f : v);
-            }
+            // the four lanes of a row share the work: lane g evaluates sin / cos of theta, theta/2, theta/3 (one range reduction
+            // each; g = 3 idles), three ds_bpermutes hand round what the others need, the multiples come from
+            // sin 2t = 2 s c, sin 3t = s (3 - 4 s^2), cos 2t = 1 - 2 s^2, cos 3t = c (4 c^2 - 3)
+            float sg, cg;
+            t2_sincos_pair(theta * (g == 0 ? 1.0f : (g == 1 ? 0.5f : (float)(1.0 / 3.0))), sg, cg);
+            const float s1 = t2_from_lane(sg, m), c1 = t2_from_lane(cg, m);
+            const float sx = t2_from_lane(sg, m + (g == 0 ? 16 : 32));      // g = 0: sin(theta/2), g = 1: sin(theta/3)
+            // f = 4 st + g: [theta, sin t, sin 2t, sin 3t | sin t/2, sin t/3, cos t, cos 2t | cos 3t, cos t/2, cos t/3, 1 (Q)]
+            feat[tile][0] = g == 0 ? theta : (g == 1 ? s1 : (g == 2 ? 2.0f * s1 * c1 : s1 * fmaf(-4.0f * s1, s1, 3.0f)));
+            feat[tile][1] = g < 2 ? sx : (g == 2 ? c1 : fmaf(-2.0f * s1, s1, 1.0f));
+            feat[tile][2] = g == 0 ? c1 * fmaf(4.0f * c1, c1, -3.0f) : (g == 3 ? 1.0f : cg);
             // hidden^T[c, row] = P_k[row][c] + Q_k[c] + Wf_k . feat   (the masked rows k = i and past-the-end rows are computed
             // like any other: their logits are replaced below, so no per-element selects are needed)
             f4 hid[8];
