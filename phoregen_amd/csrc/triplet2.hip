@@ -111,8 +111,14 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, m = lane & 15;
 
-  for (int i = tid; i < 128; i += THREADS) { bk[i] = p.ln_bk[i]; bv[i] = p.ln_bv[i]; b2v[i] = p.b2v[i]; }
-  for (int i = tid; i < 1536; i += THREADS) { wf_k[i] = p.Wf_k[i]; wf_v[i] = p.Wf_v[i]; }
+  // LDS copies are laid out for 16-byte reads: feature weights [step][half][lane][4] (a lane's 8 tq values = two ds_read_b128),
+  // the value LayerNorm shift [m][8] (channel 16 tq + m at m*8 + tq)
+  for (int i = tid; i < 128; i += THREADS) { bk[i] = p.ln_bk[i]; bv[(i & 15) * 8 + (i >> 4)] = p.ln_bv[i]; b2v[i] = p.b2v[i]; }
+  for (int i = tid; i < 1536; i += THREADS) {             // source index i = (st * 8 + tq) * 64 + lane
+    const int ln_ = i & 63, tq_ = (i >> 6) & 7, st_ = i >> 9;
+    const int d_ = ((st_ * 2 + (tq_ >> 2)) * 64 + ln_) * 4 + (tq_ & 3);
+    wf_k[d_] = p.Wf_k[i]; wf_v[d_] = p.Wf_v[i];
+  }
   for (int i = tid; i < 4096; i += THREADS) reinterpret_cast<f4*>(w2k_l)[i] = reinterpret_cast<const f4*>(p.W2k_l)[i];
   const f4* const w2v_g = reinterpret_cast<const f4*>(p.W2v_l);
   const int4* const iters = reinterpret_cast<const int4*>(p.tri_iters);
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       float wk2[8], wv2[8];
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq) {
-        wk2[tq] = g == 3 ? cQk[tq] : wf_k[(16 + tq) * 64 + lane];         // feature step 2: f = 8 + g, f = 11 carries Q
-        wv2[tq] = g == 3 ? cQv[tq] : wf_v[(16 + tq) * 64 + lane];
+        wk2[tq] = g == 3 ? cQk[tq] : wf_k[((4 + (tq >> 2)) * 64 + lane) * 4 + (tq & 3)];     // feature step 2: f = 8 + g, f = 11 carries Q
+        wv2[tq] = g == 3 ? cQv[tq] : wf_v[((4 + (tq >> 2)) * 64 + lane) * 4 + (tq & 3)];
       }
       T2_STAMP(2);                                // Q
       const float xi0 = xs[i * 3], xi1 = xs[i * 3 + 1], xi2 = xs[i * 3 + 2];
@@ -255,8 +261,14 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
             for (int tq = 0; tq < 8; ++tq) hid[tq] = *reinterpret_cast<const f4*>(pk + 16 * tq);
 #pragma unroll
             for (int st = 0; st < 2; ++st)
+              {
+                const f4 wa = *reinterpret_cast<const f4*>(wf_k + ((st * 2) * 64 + lane) * 4);
+                const f4 wb = *reinterpret_cast<const f4*>(wf_k + ((st * 2 + 1) * 64 + lane) * 4);
 #pragma unroll
-              for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wf_k[(st * 8 + tq) * 64 + lane], feat[tile][st], hid[tq]);
+                for (int tq = 0; tq < 4; ++tq) hid[tq] = mfma16(wa[tq], feat[tile][st], hid[tq]);
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) hid[4 + tq] = mfma16(wb[tq], feat[tile][st], hid[4 + tq]);
+              }
 #pragma unroll
             for (int tq = 0; tq < 8; ++tq) hid[tq] = mfma16(wk2[tq], feat[tile][2], hid[tq]);
             // folded LayerNorm + ReLU (packing._kv_mlp): z = ReLU(hidden + b' * sigma); 1/sigma multiplies the 16 logits
@@ -331,8 +343,14 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
           }
 #pragma unroll
           for (int st = 0; st < 2; ++st)
+            {
+              const f4 wa = *reinterpret_cast<const f4*>(wf_v + ((st * 2) * 64 + lane) * 4);
+              const f4 wb = *reinterpret_cast<const f4*>(wf_v + ((st * 2 + 1) * 64 + lane) * 4);
 #pragma unroll
-            for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(feat[tile][st], wf_v[(st * 8 + tq) * 64 + lane], hv[tq]);
+              for (int tq = 0; tq < 4; ++tq) hv[tq] = mfma16(feat[tile][st], wa[tq], hv[tq]);
+#pragma unroll
+              for (int tq = 0; tq < 4; ++tq) hv[4 + tq] = mfma16(feat[tile][st], wb[tq], hv[4 + tq]);
+            }
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) hv[tq] = mfma16(feat[tile][2], wv2[tq], hv[tq]);
           // folded LayerNorm + ReLU per row r over c = (tau in-lane, m across the DPP row)
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
           }
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) {
-            const float bt = bv[16 * tq + m];
+            const float bt = bv[m * 8 + tq];
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[tq][r] = fmaxf(fmaf(bt, sg[r], hv[tq][r]), 0.f);
           }
