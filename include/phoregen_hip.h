@@ -36,7 +36,7 @@ int pg_selftest_mfma(int* d_result, void* stream);
 int pg_selftest_philox(const uint32_t* ctr_key, int n, uint32_t* out, void* stream);
 /* test hook (returns the old setting): bit 0 routes the node-target modes of pg_seg_attn through the generic one-pass kernel,
  * bit 1 keeps PG_SEG_TRIPLET on the gather kernel (csrc/triplet.hip) even when the staged one (csrc/triplet2.hip) applies,
- * bit 2 runs the staged kernel with 12 instead of 8 waves per workgroup (tuning) */
+ * bit 2 runs the staged kernel with 8 instead of 12 waves per workgroup (tuning) */
 int pg_debug_force_generic_seg(int mask);
 
 /* ---- dense linear layers -------------------------------------------------------------------

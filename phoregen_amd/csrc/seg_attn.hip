@@ -571,7 +571,7 @@ namespace pg { extern int g_t2_waves; }
 extern "C" int pg_debug_force_generic_seg(int on) {
   const int old = g_force_generic;
   g_force_generic = on;
-  pg::g_t2_waves = (on & 4) ? 12 : 8;
+  pg::g_t2_waves = (on & 4) ? 8 : 12;
   return old;
 }
 

@@ -96,6 +96,7 @@ constexpr size_t t2_lds_floats() { return 16384 + 2 * 1536 + 3 * 128 + 3 * T2_XS
 
 template <int THREADS, int MAXT>
 __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p) {
+  constexpr bool PRE = THREADS <= 512;          // next-segment prefetch of the per-segment global inputs
   constexpr int WAVES = THREADS / 64;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const w2k_l = lds;                     // [64][64][4]
@@ -168,19 +169,20 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       nqb = *reinterpret_cast<const f4*>(qp_ + 4);                                                                     \
       nrs = *reinterpret_cast<const float2*>(p.resid + seg_ * 128 + 8 * m + 2 * g);                                    \
     }
-    if (wave < n_seg) T2_FETCH(wave)
+    if (PRE && wave < n_seg) T2_FETCH(wave)
 
     for (int s = wave; s < n_seg; s += WAVES) {
       const int a = s / nm1, ip = s - a * nm1;            // source atom of the group, target index among the other atoms
       const int j = j0 + a, i = ip + (ip >= j ? 1 : 0);
       const int seg = bond_off + i * nm1 + (j < i ? j : j - 1);          // internal id of edge j->i
       const float* const prow = pbuf + a * nm1 * T2_ROW;
+      if (!PRE) T2_FETCH(s)                               // (12-wave variant: no register room for the look-ahead)
       float cQk[8], cQv[8];
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq) { cQk[tq] = nQk[tq]; cQv[tq] = nQv[tq]; }
       const f4 qa = nqa, qb = nqb;
       const float2 rsd = nrs;
-      if (s + WAVES < n_seg) T2_FETCH(s + WAVES)
+      if (PRE && s + WAVES < n_seg) T2_FETCH(s + WAVES)
       // opaque copy of the lane id: global addresses built from it (20 rows of Wg2, 64 slices of W2v) are then not
       // loop-invariant, so the compiler cannot hoist ~150 address registers out of the segment loop and spill them
       int lz = lane;
@@ -427,7 +429,8 @@ static int launch_t2(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   return check_launch("pg_seg_attn(triplet, staged)");
 }
 
-int g_t2_waves = 8;   // waves per workgroup (8 or 12); set through pg_debug_force_generic_seg bit 2 for tuning runs
+int g_t2_waves = 12;  // waves per workgroup: 12 (3 per SIMD, no look-ahead prefetch; measured 1.98 ms) or 8 (with it, 2.07 ms);
+                      // pg_debug_force_generic_seg bit 2 selects 8
 
 // usable when the caller provides the source-atom groups (PgSegAttn.tri_iters), asks for the sampling form (out = resid +
 // update, no S / alpha side outputs) and P is one [n_bond, 256] = [P_k | P_v] tensor; returns -1 otherwise

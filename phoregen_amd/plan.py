@@ -105,7 +105,7 @@ class BatchPlan:
         self.tri_chunks[0], self.tri_chunks[-1] = 0, self.n_bond
         # source-atom groups of the LDS-staged triplet kernel (csrc/triplet2.hip): consecutive source atoms of one ligand whose
         # P blocks ((n-1) rows each) fit the 80 staged rows; pulled from a queue, most expensive first
-        rows_cap, waves = 80, 8
+        rows_cap, waves = 80, 12
         its = []
         for gi in range(B):
             n = int(nlig[gi])
