@@ -58,6 +58,8 @@ typedef struct {
   int   act;                 /* 0 none, 1 shifted softplus (models/common.py:58-64), 2 ReLU */
   float* Y; int ldy; int M; int N;
   const int* rows;           /* optional [M]: logical row r reads X/X2 row rows[r] and writes Y row rows[r] (row subset) */
+  int add_rows;              /* rows of add1 / add2 (upper bound of idx1 / idx2 values + 1); 0 = unknown.  Lets pg_gemm pick the
+                              * streaming kernel, which addresses the gathered rows with 32-bit byte offsets */
 } PgGemm;
 int pg_gemm(const PgGemm* p, void* stream);
 /* test / tuning hook (returns the old setting): 0 keeps the tall [h_bond | G] product on the tiled kernel instead of the

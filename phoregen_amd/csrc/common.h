@@ -17,6 +17,7 @@ void set_error(const char* fmt, ...);
 // second model on cuda:1 in the same process gets its own reservation (defined in graph_ops.hip)
 int reserve_lds(const void* kernel, size_t bytes, const char* what);
 
+
 // timing-only ablation switches exist only in -DPG_ABLATE builds (tools/); the product kernels carry none
 #ifdef PG_ABLATE
 #define PG_ABL(bit) ((pg_ablate_mask & (bit)) != 0)

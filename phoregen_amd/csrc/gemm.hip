@@ -520,7 +520,12 @@ __global__ __launch_bounds__(256) void rows_linear_kernel(const float* X, int ld
 
 }  // namespace pg
 
-static int g_gemm_sp = 1;
+namespace pg {   // gemm_stream.hip
+bool gemm_stream_eligible(const PgGemm* p);
+int launch_gemm_stream(const PgGemm* p, hipStream_t st);
+}
+
+static int g_gemm_sp = 1;      // 0: tiled kernel only; 1: default; 2: wave-specialised kernel also at K = 128; 4: no streaming kernel
 extern "C" int pg_debug_gemm_specialised(int on) { const int old = g_gemm_sp; g_gemm_sp = on; return old; }
 
 extern "C" int pg_gemm(const PgGemm* p, void* stream) {
@@ -537,6 +542,8 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
     if (K == 128) return pg::launch_ws<129>(p, (hipStream_t)stream);
     if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
   }
+  // K = 128 bond-row products with a plain epilogue: the streaming kernel (LDS-DMA, no vector-ALU work on the memory path)
+  if ((g_gemm_sp & 1) && pg::gemm_stream_eligible(p)) return pg::launch_gemm_stream(p, (hipStream_t)stream);
   // plain-epilogue bond-row products: wave-specialised persistent kernel (loads / MFMAs / stores of neighbouring tiles overlap)
   // Measured (tools/bench_gemm.py, M = 203 720): K = 148 with two gathered adds 221 vs 295 us on the tiled kernel; at K = 128
   // the specialised kernel is 5-10 % slower than the tiled one (118 vs 108 us: its per-tile barrier hand-over, not the MFMAs,

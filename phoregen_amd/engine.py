@@ -158,6 +158,7 @@ class Engine:
         g.out_scale, g.act = scale, act
         g.Y, g.ldy, g.M, g.N = Y.data_ptr(), Y.stride(0), M, N
         g.rows = hip.ptr(rows)
+        g.add_rows = add1.size(0) if add1 is not None else 0      # the gathered operands are whole [rows, ld] tensors
         self._keep += [g, X, W, Y, bias, X2, ln, add1, idx1, add2, idx2, rows]
         self._call(prog, self.lib.pg_gemm, C.byref(g))
 

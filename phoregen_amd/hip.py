@@ -23,7 +23,7 @@ class PgGemm(C.Structure):
                 ('add1', c_fp), ('ld_add1', C.c_int), ('idx1', c_ip),
                 ('add2', c_fp), ('ld_add2', C.c_int), ('idx2', c_ip),
                 ('out_scale', C.c_float), ('act', C.c_int),
-                ('Y', c_fp), ('ldy', C.c_int), ('M', C.c_int), ('N', C.c_int), ('rows', c_ip)]
+                ('Y', c_fp), ('ldy', C.c_int), ('M', C.c_int), ('N', C.c_int), ('rows', c_ip), ('add_rows', C.c_int)]
 
 
 class PgBondJob(C.Structure):

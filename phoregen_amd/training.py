@@ -94,8 +94,10 @@ class LinearGatherAddFn(torch.autograd.Function):
         g.X, g.ldx, g.K1 = X.data_ptr(), X.stride(0), K
         g.W, g.ldw = W.data_ptr(), W.stride(0)
         g.add1, g.ld_add1, g.idx1 = A1.data_ptr(), A1.stride(0), i1.data_ptr()
+        g.add_rows = A1.shape[0]
         if A2 is not None:
             g.add2, g.ld_add2, g.idx2 = A2.data_ptr(), A2.stride(0), i2.data_ptr()
+            g.add_rows = max(A1.shape[0], A2.shape[0])
         g.out_scale, g.act = 1.0, hip.ACT_NONE
         g.Y, g.ldy, g.M, g.N = Y.data_ptr(), Y.stride(0), M, W.shape[0]
         if M:

@@ -104,6 +104,48 @@ def test_gemm_against_torch(M, N, K1, K2):
         assert rel_err(Y.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,gather,bias', [(4096, 128, False, True), (4096 + 13, 128, True, False), (9001, 256, True, True),
+                                             (64 * 130 + 63, 256, False, False), (203720, 128, True, True)])
+def test_gemm_streaming_kernel_against_torch(M, N, gather, bias):
+    """The K = 128 streaming kernel (csrc/gemm_stream.hip: LDS-DMA tiles, swizzled image, stores from the accumulators, last tile
+    anchored at row M - 64) against float64 torch and against the tiled kernel; Y and the gathered operand are strided views."""
+    from phoregen_amd import hip
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.randn(M, 128, generator=g)
+    W, b = torch.randn(N, 128, generator=g) * 0.1, torch.randn(N, generator=g)
+    A = torch.randn(321, 1920, generator=g)
+    idx = torch.randint(0, 321, (M,), generator=g, dtype=torch.int32)
+    ref = X.double() @ W.double().t()
+    if bias:
+        ref = ref + b.double()
+    if gather:
+        ref = ref + A.double()[idx.long(), 256:256 + N]
+    Xd, Wd, bd, Ad, id_ = (v.to(DEV) for v in (X, W, b, A, idx))
+    outs = []
+    for mode in (1, 0):                                   # streaming kernel, then the tiled kernel
+        old = lib.pg_debug_gemm_specialised(mode)
+        try:
+            Yfull = torch.full((M, N + 64), float('nan'), device=DEV)
+            Y = Yfull[:, 32:32 + N]
+            p = hip.PgGemm()
+            p.X, p.ldx, p.K1 = Xd.data_ptr(), 128, 128
+            p.W, p.ldw = Wd.data_ptr(), 128
+            p.bias = bd.data_ptr() if bias else None
+            if gather:
+                p.add1, p.ld_add1, p.idx1, p.add_rows = Ad[:, 256:].data_ptr(), 1920, id_.data_ptr(), 321
+            p.out_scale, p.act = 1.0, hip.ACT_NONE
+            p.Y, p.ldy, p.M, p.N = Y.data_ptr(), Yfull.stride(0), M, N
+            hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
+            torch.cuda.synchronize()
+        finally:
+            lib.pg_debug_gemm_specialised(old)
+        assert torch.isnan(Yfull[:, :32]).all() and torch.isnan(Yfull[:, 32 + N:]).all()      # nothing outside the view
+        assert rel_err(Y.cpu(), ref) < 1e-5, mode
+        outs.append(Y.cpu())
+    assert rel_err(outs[0], outs[1].double()) < 2e-6
+
+
 @pytest.mark.parametrize('E', [1000, 128 * 7, 33])
 def test_bond_rows_fused_against_torch(E):
     """pg_bond_rows (csrc/bondrow.hip): four jobs over one staging of the h_bond tile -- plain, two gathered adds with the

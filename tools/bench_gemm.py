@@ -17,7 +17,7 @@ def run(M, N, K1, K2=0, ln=False, gather=0, act=0, reps=10, ldx=None):
     p.X2, p.ldx2, p.K2 = (X2.data_ptr(), X2.stride(0), K2) if K2 else (None, 0, 0)
     p.W, p.ldw, p.bias = W.data_ptr(), K1 + K2, b.data_ptr()
     if ln: p.ln_gamma, p.ln_beta = gam.data_ptr(), bet.data_ptr()
-    if gather >= 1: p.add1, p.ld_add1, p.idx1 = A.data_ptr(), 1920, idx.data_ptr()
+    if gather >= 1: p.add1, p.ld_add1, p.idx1, p.add_rows = A.data_ptr(), 1920, idx.data_ptr(), 20000
     if gather >= 2: p.add2, p.ld_add2, p.idx2 = A[:, 256:].data_ptr(), 1920, idx.data_ptr()
     p.out_scale, p.act = 1.0, act
     p.Y, p.ldy, p.M, p.N = Y.data_ptr(), N, M, N
