@@ -227,7 +227,7 @@ static int launch_stream_t(const PgGemm* p, hipStream_t st) {
 // eligible: K = 128 from X alone, no LayerNorm-on-load / row subset / activation / scale, N a multiple of 128, at most one gathered
 // add (with its index array), 16-byte aligned rows, everything addressable with 32-bit byte offsets
 bool gemm_stream_eligible(const PgGemm* p) {
-  if (p->K1 != 128 || p->K2 != 0 || p->ln_gamma || p->rows || p->act != 0 || (p->N & 127) || p->M < 4096 || p->out_scale != 1.0f) return false;
+  if (p->K1 != 128 || p->K2 != 0 || p->ln_gamma || p->rows || p->act != 0 || (p->N & 127) || p->M < ST_BM || p->out_scale != 1.0f) return false;   // (any M >= one tile: a row's result must not depend on the batch it is computed in)
   if ((p->ldx & 3) || ((size_t)p->X & 15) || (p->ldw & 1) || ((size_t)p->W & 7)) return false;
   if ((p->add1 && !p->idx1) || p->add2) return false;
   if (p->add1 && (p->add_rows <= 0 || (size_t)p->add_rows * p->ld_add1 * 4 >= 0xfffff000ull)) return false;

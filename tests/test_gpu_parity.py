@@ -104,7 +104,7 @@ def test_gemm_against_torch(M, N, K1, K2):
         assert rel_err(Y.cpu(), ref) < 1e-5
 
 
-@pytest.mark.parametrize('M,N,gather,bias', [(4096, 128, False, True), (4096 + 13, 128, True, False), (9001, 256, True, True),
+@pytest.mark.parametrize('M,N,gather,bias', [(64, 128, True, True), (100, 256, False, True), (4096 + 13, 128, True, False), (9001, 256, True, True),
                                              (64 * 130 + 63, 256, False, False), (203720, 128, True, True)])
 def test_gemm_streaming_kernel_against_torch(M, N, gather, bias):
     """The K = 128 streaming kernel (csrc/gemm_stream.hip: LDS-DMA tiles, swizzled image, stores from the accumulators, last tile
