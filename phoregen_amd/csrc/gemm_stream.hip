@@ -29,6 +29,7 @@
 namespace pg {
 
 typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
 
 constexpr int ST_BM = 64;                       // rows per tile
 constexpr int ST_STAGE = ST_BM * 128 * 4;       // 32 KB
@@ -49,7 +50,7 @@ __device__ __forceinline__ void st_dma(unsigned lds_dst, unsigned voff, i4v desc
                :: "s"(lds_dst), "v"(voff), "s"(desc), "s"(soff) : "memory");
 }
 
-template <int NW /* waves: 32 output columns each */, int NADD>
+template <int NW /* waves: 32 output columns each */, int NADD /* gathered adds: 0 | 1 */, int K1 /* 128 | 0 */, int K2 /* 0 | 20 */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(PgGemm p, int n_tiles) {
   extern __shared__ __attribute__((aligned(1024))) char st_lds[];     // the ONLY LDS object: stage s at byte s * 32 KB
   const int lane = threadIdx.x & 63;
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   const int col = colw + l31;
 
   // ---- the wave's W slice: 64 registers for the whole kernel ----
-  float Wr[64];
-  {
+  float Wr[K1 ? 64 : 1];
+  if constexpr (K1 > 0) {
     const float* wrow = p.W + (size_t)col * p.ldw + 2 * kh;
 #pragma unroll
     for (int kg = 0; kg < 32; ++kg) {
@@ -69,6 +70,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
       Wr[2 * kg + 1] = w.y;
     }
   }
+  // second operand [X | X2] (K2 = 20, the Gaussian smearing of the bond length): no LDS, the lane's ten values of a row
+  // (k = K1 + 10 kh + s) come straight from HBM one tile ahead; same split of k for the weights
+  float W2r[K2 ? 10 : 1];
+  if constexpr (K2 > 0) {
+#pragma unroll
+    for (int s2 = 0; s2 < 10; ++s2) W2r[s2] = p.W[(size_t)col * p.ldw + K1 + 10 * kh + s2];
+  }
+  const unsigned ldx2b = (unsigned)p.ldx2 * 4u;
+  const __amdgpu_buffer_rsrc_t descX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K2 ? p.X2 : nullptr), 0, (unsigned)p.M * ldx2b, 0x00020000);
+  const unsigned voffX2 = (unsigned)l31 * ldx2b + 40u * kh;
+  float xa[2][10], xb[2][10];               // this tile's / the next tile's X2 values, roles swap with the LDS stage
+  auto load_x2 = [&](unsigned row0, float (&x)[2][10]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const unsigned so = (row0 + 32u * b) * ldx2b;
+      const i4v v0 = __builtin_amdgcn_raw_buffer_load_b128(descX2, voffX2, so, 0);
+      const i4v v1 = __builtin_amdgcn_raw_buffer_load_b128(descX2, voffX2 + 16u, so, 0);
+      const i2v v2 = __builtin_amdgcn_raw_buffer_load_b64(descX2, voffX2 + 32u, so, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { x[b][e] = __builtin_bit_cast(float, (int)v0[e]); x[b][4 + e] = __builtin_bit_cast(float, (int)v1[e]); }
+      x[b][8] = __builtin_bit_cast(float, (int)v2[0]);
+      x[b][9] = __builtin_bit_cast(float, (int)v2[1]);
+    }
+  };
   const float bias = p.bias ? p.bias[col] : 0.f;
   f16v biasv;
 #pragma unroll
@@ -136,21 +161,27 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   };
 
   // ---- prologue: first tile's DMA and gathers ----
-  dma_tile(tile, 0);
+  if constexpr (K2 > 0) load_x2(tile_row0(tile), xa);
+  if constexpr (K1 > 0) dma_tile(tile, 0);
   if constexpr (NADD >= 1) { i4v ix[8]; load_idx(descI1, tile_row0(tile), ix); gather(descA1, ld1b, ix, g1); }
 
   auto body = [&](auto stage_c, auto first_c) {
     constexpr unsigned stage = decltype(stage_c)::value;
     constexpr bool first = decltype(first_c)::value;
     // this tile's DMA has landed (own pieces: counted wait; everybody's: barrier); the other stage is no longer read
-    if constexpr (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
+    if constexpr (K1 > 0) {
+      if constexpr (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
+    }
     const unsigned next = tile + tile_step;
+    float (&xc)[2][10] = stage ? xb : xa;
+    float (&xn)[2][10] = stage ? xa : xb;
     // VMEM order matters (one in-order counter): the index loads go out BEFORE the DMA and are consumed late in the tile, so
     // the wait the compiler puts in front of their use (it cannot see the DMA) finds the DMA long since landed
     i4v ix1[8];
     if constexpr (NADD >= 1) load_idx(descI1, tile_row0(next), ix1);
-    dma_tile(next, stage ^ 1u);                 // past the last tile: the clamped last tile once more, never consumed
+    if constexpr (K2 > 0) load_x2(tile_row0(next), xn);
+    if constexpr (K1 > 0) dma_tile(next, stage ^ 1u);   // past the last tile: the clamped last tile once more, never consumed
 
     // accumulator init: the gathered operand (+ bias) of this tile, fetched during the previous one; without a gathered operand
     // the bias vector is the C input of the tile's first MFMAs (no vector-ALU instruction at all in the steady state)
@@ -165,30 +196,41 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
       acc[1] = biasv;
     }
 
-    // operands one k-group ahead of their MFMAs (the compiler otherwise reads them right in front of the use)
-    auto frag = [&](int kg, int b) {
-      return *reinterpret_cast<const float2*>(st_lds + rd[kg & 7] + (stage * ST_STAGE + b * 16384u + (kg >> 3) * 1024u));
-    };
-    float2 aA0 = frag(0, 0), aA1 = frag(0, 1), aB0, aB1;
+    if constexpr (K2 > 0) {
 #pragma unroll
-    for (int kg = 0; kg < 32; kg += 2) {
-      if (kg == 24) {                           // last quarter: the next tile's gathered operand goes out
-        if constexpr (NADD >= 1) gather(descA1, ld1b, ix1, g1);
+      for (int s2 = 0; s2 < 10; ++s2) {
+        acc[0] = mfma32(xc[0][s2], W2r[s2], acc[0]);
+        acc[1] = mfma32(xc[1][s2], W2r[s2], acc[1]);
       }
-      aB0 = frag(kg + 1, 0); aB1 = frag(kg + 1, 1);
-      __builtin_amdgcn_sched_barrier(0);        // the read of k-group kg+1 stays in front of the MFMAs of k-group kg
-      acc[0] = mfma32(aA0.x, Wr[2 * kg], acc[0]);
-      acc[1] = mfma32(aA1.x, Wr[2 * kg], acc[1]);
-      acc[0] = mfma32(aA0.y, Wr[2 * kg + 1], acc[0]);
-      acc[1] = mfma32(aA1.y, Wr[2 * kg + 1], acc[1]);
-      if (kg + 2 < 32) { aA0 = frag(kg + 2, 0); aA1 = frag(kg + 2, 1); }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0] = mfma32(aB0.x, Wr[2 * kg + 2], acc[0]);
-      acc[1] = mfma32(aB1.x, Wr[2 * kg + 2], acc[1]);
-      acc[0] = mfma32(aB0.y, Wr[2 * kg + 3], acc[0]);
-      acc[1] = mfma32(aB1.y, Wr[2 * kg + 3], acc[1]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (K1 > 0) {
+      // operands one k-group ahead of their MFMAs (the compiler otherwise reads them right in front of the use)
+      auto frag = [&](int kg, int b) {
+        return *reinterpret_cast<const float2*>(st_lds + rd[kg & 7] + (stage * ST_STAGE + b * 16384u + (kg >> 3) * 1024u));
+      };
+      float2 aA0 = frag(0, 0), aA1 = frag(0, 1), aB0, aB1;
+#pragma unroll
+      for (int kg = 0; kg < 32; kg += 2) {
+        if (kg == 24) {                           // last quarter: the next tile's gathered operand goes out
+          if constexpr (NADD >= 1) gather(descA1, ld1b, ix1, g1);
+        }
+        aB0 = frag(kg + 1, 0); aB1 = frag(kg + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);        // the read of k-group kg+1 stays in front of the MFMAs of k-group kg
+        acc[0] = mfma32(aA0.x, Wr[2 * kg], acc[0]);
+        acc[1] = mfma32(aA1.x, Wr[2 * kg], acc[1]);
+        acc[0] = mfma32(aA0.y, Wr[2 * kg + 1], acc[0]);
+        acc[1] = mfma32(aA1.y, Wr[2 * kg + 1], acc[1]);
+        if (kg + 2 < 32) { aA0 = frag(kg + 2, 0); aA1 = frag(kg + 2, 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma32(aB0.x, Wr[2 * kg + 2], acc[0]);
+        acc[1] = mfma32(aB1.x, Wr[2 * kg + 2], acc[1]);
+        acc[0] = mfma32(aB0.y, Wr[2 * kg + 3], acc[0]);
+        acc[1] = mfma32(aB1.y, Wr[2 * kg + 3], acc[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if constexpr (NADD >= 1) gather(descA1, ld1b, ix1, g1);
+    }
 
     const unsigned row0 = tile_row0(tile);
 #pragma unroll
@@ -211,34 +253,49 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (out-of-range) DMA must not outlive the workgroup's LDS
 }
 
-template <int NW, int NADD>
+template <int NW, int NADD, int K1, int K2>
 static int launch_stream_t(const PgGemm* p, hipStream_t st) {
-  const void* k = reinterpret_cast<const void*>(gemm_stream_kernel<NW, NADD>);
-  const size_t lds = 2 * ST_STAGE;
-  if (int rc = reserve_lds(k, lds, "pg_gemm(stream)")) return rc;
+  const void* k = reinterpret_cast<const void*>(gemm_stream_kernel<NW, NADD, K1, K2>);
+  const size_t lds = K1 ? 2 * ST_STAGE : 0;
+  if (lds) if (int rc = reserve_lds(k, lds, "pg_gemm(stream)")) return rc;
   const int n_tiles = (p->M + ST_BM - 1) / ST_BM;
   const int n_cb = p->N / (NW * 32);
   int per_cb = (NW == 4 ? 2 : 1) * kNumCU / n_cb;
+  if (per_cb < 1) per_cb = 1;
   if (per_cb > n_tiles) per_cb = n_tiles;
-  hipLaunchKernelGGL((gemm_stream_kernel<NW, NADD>), dim3(per_cb, n_cb), dim3(NW * 64), lds, st, *p, n_tiles);
+  hipLaunchKernelGGL((gemm_stream_kernel<NW, NADD, K1, K2>), dim3(per_cb, n_cb), dim3(NW * 64), lds, st, *p, n_tiles);
   return check_launch("pg_gemm(stream)");
 }
 
-// eligible: K = 128 from X alone, no LayerNorm-on-load / row subset / activation / scale, N a multiple of 128, at most one gathered
-// add (with its index array), 16-byte aligned rows, everything addressable with 32-bit byte offsets
+// eligible: K = 128 from X (optionally + 20 from X2), or K = 20 alone; no LayerNorm-on-load / row subset / activation / scale;
+// N a multiple of 128; at most one gathered add (with its index array and row count); 16-byte aligned rows; everything
+// addressable with 32-bit byte offsets; at least one full tile of rows
 bool gemm_stream_eligible(const PgGemm* p) {
-  if (p->K1 != 128 || p->K2 != 0 || p->ln_gamma || p->rows || p->act != 0 || (p->N & 127) || p->M < ST_BM || p->out_scale != 1.0f) return false;   // (any M >= one tile: a row's result must not depend on the batch it is computed in)
+  const bool k128 = p->K1 == 128 && (p->K2 == 0 || p->K2 == 20), k20 = p->K1 == 20 && p->K2 == 0;
+  if (!(k128 || k20) || p->ln_gamma || p->rows || p->act != 0 || (p->N & 127) || p->M < ST_BM || p->out_scale != 1.0f) return false;
   if ((p->ldx & 3) || ((size_t)p->X & 15) || (p->ldw & 1) || ((size_t)p->W & 7)) return false;
+  if (p->K2 && ((p->ldx2 & 1) || ((size_t)p->X2 & 7))) return false;
+  if (k20 && (p->ldx & 1)) return false;
   if ((p->add1 && !p->idx1) || p->add2) return false;
   if (p->add1 && (p->add_rows <= 0 || (size_t)p->add_rows * p->ld_add1 * 4 >= 0xfffff000ull)) return false;
   if ((size_t)p->M * p->ldx * 4 >= 0xfffff000ull || (size_t)p->M * p->ldy * 4 >= 0xfffff000ull) return false;
   return true;
 }
 
-int launch_gemm_stream(const PgGemm* p, hipStream_t st) {
+template <int K1, int K2>
+static int launch_stream_k(const PgGemm* p, hipStream_t st) {
   const bool wide = (p->N & 255) == 0;           // 8 waves share one A tile for 256 columns
-  if (wide) return p->add1 ? launch_stream_t<8, 1>(p, st) : launch_stream_t<8, 0>(p, st);
-  return p->add1 ? launch_stream_t<4, 1>(p, st) : launch_stream_t<4, 0>(p, st);
+  if (wide) return p->add1 ? launch_stream_t<8, 1, K1, K2>(p, st) : launch_stream_t<8, 0, K1, K2>(p, st);
+  return p->add1 ? launch_stream_t<4, 1, K1, K2>(p, st) : launch_stream_t<4, 0, K1, K2>(p, st);
+}
+
+int launch_gemm_stream(const PgGemm* p, hipStream_t st) {
+  if (p->K1 == 20) {                             // K = 20 alone: the X operand takes the X2 (register) path
+    PgGemm q = *p;
+    q.X2 = p->X; q.ldx2 = p->ldx; q.K2 = 20; q.K1 = 0;
+    return launch_stream_k<0, 20>(&q, st);
+  }
+  return p->K2 ? launch_stream_k<128, 20>(p, st) : launch_stream_k<128, 0>(p, st);
 }
 
 }  // namespace pg

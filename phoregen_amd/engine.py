@@ -337,12 +337,15 @@ class Engine:
             # ---- bond update over triplets (:285)                                     [lane 0]
             self._lane = 0
             if not self.fused_bond_rows:
+                # P[k->j] = W.[h_bond | G] + (source half)[k] + (target half)[j].  Every row of the block a segment j->i reads has
+                # the same target j, so in the staged form that half rides on the segment's own row Q[j->i] instead (one gathered
+                # operand per product; the gather kernel builds Q in-kernel and keeps it on P)
                 self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
                            add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
-                           add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)
+                           **({} if staged else dict(add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)))
                 self._lane = 3                                                          # triplet queries [lane 3]
-                if staged:   # the per-segment constant of the triplet MLPs as rows (the gather kernel computes it in-kernel)
-                    self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256)
+                if staged:   # the per-segment constant of the triplet MLPs as rows: Wg2 . smear(d_ji) + (target half)[j]
+                    self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=w.Y1[:, 12 * 128:14 * 128], idx1=p.bond_src)
                 self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
                 self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
                            scale=HEAD_SCALE)

@@ -104,24 +104,27 @@ def test_gemm_against_torch(M, N, K1, K2):
         assert rel_err(Y.cpu(), ref) < 1e-5
 
 
-@pytest.mark.parametrize('M,N,gather,bias', [(64, 128, True, True), (100, 256, False, True), (4096 + 13, 128, True, False), (9001, 256, True, True),
-                                             (64 * 130 + 63, 256, False, False), (203720, 128, True, True)])
-def test_gemm_streaming_kernel_against_torch(M, N, gather, bias):
-    """The K = 128 streaming kernel (csrc/gemm_stream.hip: LDS-DMA tiles, swizzled image, stores from the accumulators, last tile
-    anchored at row M - 64) against float64 torch and against the tiled kernel; Y and the gathered operand are strided views."""
+@pytest.mark.parametrize('M,N,gather,bias,K1,K2', [
+    (64, 128, True, True, 128, 0), (100, 256, False, True, 128, 0), (4096 + 13, 128, True, False, 128, 0),
+    (9001, 256, True, True, 128, 0), (64 * 130 + 63, 256, False, False, 128, 0), (203720, 128, True, True, 128, 0),
+    (9001, 256, True, False, 128, 20), (777, 128, False, True, 128, 20), (9001, 256, True, False, 20, 0), (130, 128, False, False, 20, 0)])
+def test_gemm_streaming_kernel_against_torch(M, N, gather, bias, K1, K2):
+    """The streaming kernel (csrc/gemm_stream.hip: LDS-DMA tiles, swizzled image, stores from the accumulators, last tile anchored
+    at row M - 64; K = 128, 128 + 20 and 20) against float64 torch and against the tiled kernel; Y and the gathered operand are
+    strided views."""
     from phoregen_amd import hip
     lib = hip.lib()
-    g = torch.Generator().manual_seed(M + N)
-    X = torch.randn(M, 128, generator=g)
-    W, b = torch.randn(N, 128, generator=g) * 0.1, torch.randn(N, generator=g)
+    g = torch.Generator().manual_seed(M + N + K2)
+    X, X2 = torch.randn(M, K1, generator=g), torch.rand(M, 20, generator=g)
+    W, b = torch.randn(N, K1 + K2, generator=g) * 0.1, torch.randn(N, generator=g)
     A = torch.randn(321, 1920, generator=g)
     idx = torch.randint(0, 321, (M,), generator=g, dtype=torch.int32)
-    ref = X.double() @ W.double().t()
+    ref = (torch.cat([X, X2], 1) if K2 else X).double() @ W.double().t()
     if bias:
         ref = ref + b.double()
     if gather:
         ref = ref + A.double()[idx.long(), 256:256 + N]
-    Xd, Wd, bd, Ad, id_ = (v.to(DEV) for v in (X, W, b, A, idx))
+    Xd, X2d, Wd, bd, Ad, id_ = (v.to(DEV) for v in (X, X2, W, b, A, idx))
     outs = []
     for mode in (1, 0):                                   # streaming kernel, then the tiled kernel
         old = lib.pg_debug_gemm_specialised(mode)
@@ -129,8 +132,10 @@ def test_gemm_streaming_kernel_against_torch(M, N, gather, bias):
             Yfull = torch.full((M, N + 64), float('nan'), device=DEV)
             Y = Yfull[:, 32:32 + N]
             p = hip.PgGemm()
-            p.X, p.ldx, p.K1 = Xd.data_ptr(), 128, 128
-            p.W, p.ldw = Wd.data_ptr(), 128
+            p.X, p.ldx, p.K1 = Xd.data_ptr(), K1, K1
+            if K2:
+                p.X2, p.ldx2, p.K2 = X2d.data_ptr(), 20, K2
+            p.W, p.ldw = Wd.data_ptr(), K1 + K2
             p.bias = bd.data_ptr() if bias else None
             if gather:
                 p.add1, p.ld_add1, p.idx1, p.add_rows = Ad[:, 256:].data_ptr(), 1920, id_.data_ptr(), 321

@@ -32,6 +32,6 @@ def run(M, N, K1, K2=0, ln=False, gather=0, act=0, reps=10, ldx=None):
     print(f'M={M} N={N} K={K1}+{K2} ln={ln} gather={gather} act={act} ldx={ldx}: {ms*1e3:.1f} us  {2*M*N*(K1+K2)/ms/1e9:.1f} TF/s')
 E, n = 203720, 18401
 run(E, 128, 128); run(E, 128, 128, gather=1); run(E, 128, 128, ln=True); run(E, 128, 128, act=1)
-run(E, 256, 128); run(E, 256, 128, gather=1); run(E, 256, 128, K2=20, gather=2)
+run(E, 256, 128); run(E, 256, 128, gather=1); run(E, 256, 128, K2=20, gather=2); run(E, 256, 128, K2=20, gather=1)
 run(n, 1920, 128); run(n, 1280, 128); run(n, 128, 128, ln=True, ldx=1920); run(n, 128, 256)
-run(E, 256, 20)
+run(E, 256, 20); run(E, 256, 20, gather=1)
