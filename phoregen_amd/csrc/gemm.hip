@@ -537,13 +537,14 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   const int K = p->K1 + p->K2;
   const bool al = (p->ldx & 3) == 0 && ((size_t)p->X & 15) == 0 && (p->ldw & 3) == 0 && ((size_t)p->W & 15) == 0 &&
                   (p->K1 & 3) == 0 && (p->K2 & 3) == 0 && (!p->K2 || ((p->ldx2 & 3) == 0 && ((size_t)p->X2 & 15) == 0));
+  // K = 128 (+ 20) / K = 20 products with a plain epilogue or LayerNorm-on-load: the streaming kernel (LDS-DMA tiles, no vector-ALU
+  // work on the memory path; gemm_stream.hip)
+  if ((g_gemm_sp & 1) && pg::gemm_stream_eligible(p)) return pg::launch_gemm_stream(p, (hipStream_t)stream);
   // (measured, tools/bench_gemm.py: a clear win for the LayerNorm-on-load form, a wash or slightly worse otherwise)
   if (p->M >= 32768 && al && p->N <= 256 && p->ln_gamma && !p->rows) {
     if (K == 128) return pg::launch_ws<129>(p, (hipStream_t)stream);
     if (K == 148) return pg::launch_ws<149>(p, (hipStream_t)stream);
   }
-  // K = 128 bond-row products with a plain epilogue: the streaming kernel (LDS-DMA, no vector-ALU work on the memory path)
-  if ((g_gemm_sp & 1) && pg::gemm_stream_eligible(p)) return pg::launch_gemm_stream(p, (hipStream_t)stream);
   // plain-epilogue bond-row products: wave-specialised persistent kernel (loads / MFMAs / stores of neighbouring tiles overlap)
   // Measured (tools/bench_gemm.py, M = 203 720): K = 148 with two gathered adds 221 vs 295 us on the tiled kernel; at K = 128
   // the specialised kernel is 5-10 % slower than the tiled one (118 vs 108 us: its per-tile barrier hand-over, not the MFMAs,

@@ -50,7 +50,8 @@ __device__ __forceinline__ void st_dma(unsigned lds_dst, unsigned voff, i4v desc
                :: "s"(lds_dst), "v"(voff), "s"(desc), "s"(soff) : "memory");
 }
 
-template <int NW /* waves: 32 output columns each */, int NADD /* gathered adds: 0 | 1 */, int K1 /* 128 | 0 */, int K2 /* 0 | 20 */>
+template <int NW /* waves: 32 output columns each */, int NADD /* 0 | 1: rows add1[idx1[r]] | 2: rows add1[r] */, int K1 /* 128 | 0 */,
+          int K2 /* 0 | 20 */, bool LN /* LayerNorm(128) + ReLU on the X rows (K1 = 128, NW = 4) */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(PgGemm p, int n_tiles) {
   extern __shared__ __attribute__((aligned(1024))) char st_lds[];     // the ONLY LDS object: stage s at byte s * 32 KB
   const int lane = threadIdx.x & 63;
@@ -99,6 +100,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
 #pragma unroll
   for (int r = 0; r < 16; ++r) biasv[r] = bias;
 
+  // LayerNorm-on-load: gamma | beta behind the two stages (reached by ds instructions only, never by the DMA)
+  const f4* const lnt = reinterpret_cast<const f4*>(st_lds + 2 * ST_STAGE);
+  if constexpr (LN) {
+    float* t = reinterpret_cast<float*>(st_lds + 2 * ST_STAGE);
+    if (threadIdx.x < 128) { t[threadIdx.x] = p.ln_gamma[threadIdx.x]; t[128 + threadIdx.x] = p.ln_beta[threadIdx.x]; }
+    __syncthreads();                             // (no DMA in flight yet)
+  }
+
   // ---- lane-fixed offsets ----
   const unsigned ldxb = (unsigned)p.ldx * 4u, ldyb = (unsigned)p.ldy * 4u;
   const i4v descX = st_desc(p.X, (unsigned)p.M * ldxb);
@@ -142,6 +151,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
               float, __builtin_amdgcn_raw_buffer_load_b32(dA, (unsigned)ix[4 * b + q][t] * ldb + colb, 0, 0));
   };
 
+  // NADD == 2: the added rows are the output rows themselves (add1[r]): same addressing as the stores, no indices
+  unsigned voffA[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) voffA[t] = (unsigned)(4 * kh + t) * ld1b + colb;
+  auto gather_plain = [&](unsigned row0, f16v (&g)[2]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        g[b][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(descA1, voffA[r & 3], (row0 + 32u * b + 8u * (r >> 2)) * ld1b, 0));
+  };
+
   const unsigned tile_step = gridDim.x;
   unsigned tile = blockIdx.x;
 
@@ -163,7 +184,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   // ---- prologue: first tile's DMA and gathers ----
   if constexpr (K2 > 0) load_x2(tile_row0(tile), xa);
   if constexpr (K1 > 0) dma_tile(tile, 0);
-  if constexpr (NADD >= 1) { i4v ix[8]; load_idx(descI1, tile_row0(tile), ix); gather(descA1, ld1b, ix, g1); }
+  if constexpr (NADD == 1) { i4v ix[8]; load_idx(descI1, tile_row0(tile), ix); gather(descA1, ld1b, ix, g1); }
+  if constexpr (NADD == 2) gather_plain(tile_row0(tile), g1);
 
   auto body = [&](auto stage_c, auto first_c) {
     constexpr unsigned stage = decltype(stage_c)::value;
@@ -179,9 +201,46 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
     // VMEM order matters (one in-order counter): the index loads go out BEFORE the DMA and are consumed late in the tile, so
     // the wait the compiler puts in front of their use (it cannot see the DMA) finds the DMA long since landed
     i4v ix1[8];
-    if constexpr (NADD >= 1) load_idx(descI1, tile_row0(next), ix1);
+    if constexpr (NADD == 1) load_idx(descI1, tile_row0(next), ix1);
     if constexpr (K2 > 0) load_x2(tile_row0(next), xn);
     if constexpr (K1 > 0) dma_tile(next, stage ^ 1u);   // past the last tile: the clamped last tile once more, never consumed
+
+    if constexpr (LN) {
+      // normalise the landed tile in place: 4 threads per row, each its 128-byte piece row, read in k order (slot q ^ sw holds
+      // k-group q): a row's sums must not depend on where in a tile the row sits (rows of the anchored last tile are computed
+      // twice, and a graph alone must give the bits it gives inside a batch).  Same arithmetic as the tiled kernel's
+      // LayerNorm-on-load (two-pass variance, (x - mu) * rstd * gamma + beta, ReLU)
+      const unsigned row = threadIdx.x >> 2, jj = threadIdx.x & 3;
+      char* const base = st_lds + stage * ST_STAGE + ((row >> 3) * 4u + jj) * 1024u + (row & 7u) * 128u;
+      const unsigned sw = (row >> 1) & 7u;
+      f4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f4*>(base + 16 * (q ^ sw));   // v[q] = k-group 8 jj + q
+      float sm = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) sm += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+      sm += __shfl_xor(sm, 1);
+      sm += __shfl_xor(sm, 2);
+      const float mu = sm * (1.f / 128.f);
+      float qs = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[q][e] - mu; qs = fmaf(d, d, qs); }
+      qs += __shfl_xor(qs, 1);
+      qs += __shfl_xor(qs, 2);
+      const float rs = 1.0f / sqrtf(qs * (1.f / 128.f) + 1e-5f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned k4 = 8u * jj + (unsigned)q;
+        const f4 ga = lnt[k4], be = lnt[32 + k4];
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf((v[q][e] - mu) * rs * ga[e] + be[e], 0.f);
+        *reinterpret_cast<f4*>(base + 16 * (q ^ sw)) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (not __syncthreads: its vmcnt(0) would drain the DMA)
+    }
 
     // accumulator init: the gathered operand (+ bias) of this tile, fetched during the previous one; without a gathered operand
     // the bias vector is the C input of the tile's first MFMAs (no vector-ALU instruction at all in the steady state)
@@ -212,7 +271,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
 #pragma unroll
       for (int kg = 0; kg < 32; kg += 2) {
         if (kg == 24) {                           // last quarter: the next tile's gathered operand goes out
-          if constexpr (NADD >= 1) gather(descA1, ld1b, ix1, g1);
+          if constexpr (NADD == 1) gather(descA1, ld1b, ix1, g1);
+          if constexpr (NADD == 2) gather_plain(tile_row0(next), g1);
         }
         aB0 = frag(kg + 1, 0); aB1 = frag(kg + 1, 1);
         __builtin_amdgcn_sched_barrier(0);        // the read of k-group kg+1 stays in front of the MFMAs of k-group kg
@@ -229,7 +289,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
       }
       __builtin_amdgcn_sched_barrier(0);
     } else {
-      if constexpr (NADD >= 1) gather(descA1, ld1b, ix1, g1);
+      if constexpr (NADD == 1) gather(descA1, ld1b, ix1, g1);
+      if constexpr (NADD == 2) gather_plain(tile_row0(next), g1);
     }
 
     const unsigned row0 = tile_row0(tile);
@@ -238,7 +299,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned soff = (row0 + 32u * b + 8u * (r >> 2)) * ldyb + (unsigned)colw * 4u;
-        const float v = acc[b][r];        // (a named float: __builtin_bit_cast straight from the vector element read element 0)
+        float v = acc[b][r];              // (a named float: __builtin_bit_cast straight from the vector element read element 0)
+        if constexpr (LN) v *= p.out_scale;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), descY, voffY[r & 3], soff, 0);
       }
     tile = next;
@@ -253,31 +315,35 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (out-of-range) DMA must not outlive the workgroup's LDS
 }
 
-template <int NW, int NADD, int K1, int K2>
+template <int NW, int NADD, int K1, int K2, bool LN = false>
 static int launch_stream_t(const PgGemm* p, hipStream_t st) {
-  const void* k = reinterpret_cast<const void*>(gemm_stream_kernel<NW, NADD, K1, K2>);
-  const size_t lds = K1 ? 2 * ST_STAGE : 0;
+  const void* k = reinterpret_cast<const void*>(gemm_stream_kernel<NW, NADD, K1, K2, LN>);
+  const size_t lds = K1 ? 2 * ST_STAGE + (LN ? 1024 : 0) : 0;
   if (lds) if (int rc = reserve_lds(k, lds, "pg_gemm(stream)")) return rc;
   const int n_tiles = (p->M + ST_BM - 1) / ST_BM;
   const int n_cb = p->N / (NW * 32);
   int per_cb = (NW == 4 ? 2 : 1) * kNumCU / n_cb;
   if (per_cb < 1) per_cb = 1;
   if (per_cb > n_tiles) per_cb = n_tiles;
-  hipLaunchKernelGGL((gemm_stream_kernel<NW, NADD, K1, K2>), dim3(per_cb, n_cb), dim3(NW * 64), lds, st, *p, n_tiles);
+  hipLaunchKernelGGL((gemm_stream_kernel<NW, NADD, K1, K2, LN>), dim3(per_cb, n_cb), dim3(NW * 64), lds, st, *p, n_tiles);
   return check_launch("pg_gemm(stream)");
 }
 
-// eligible: K = 128 from X (optionally + 20 from X2), or K = 20 alone; no LayerNorm-on-load / row subset / activation / scale;
-// N a multiple of 128; at most one gathered add (with its index array and row count); 16-byte aligned rows; everything
-// addressable with 32-bit byte offsets; at least one full tile of rows
+// eligible: K = 128 from X (optionally + 20 from X2), or K = 20 alone; no row subset / activation; N a multiple of 128; at most
+// one added operand (rows add1[idx1[r]] with the operand's row count, or rows add1[r]); 16-byte aligned rows; everything
+// addressable with 32-bit byte offsets; at least one full tile of rows.  LayerNorm-on-load: K = 128, N = 128, no added operand
+// (the second layer of the query MLPs); out_scale only there
 bool gemm_stream_eligible(const PgGemm* p) {
   const bool k128 = p->K1 == 128 && (p->K2 == 0 || p->K2 == 20), k20 = p->K1 == 20 && p->K2 == 0;
-  if (!(k128 || k20) || p->ln_gamma || p->rows || p->act != 0 || (p->N & 127) || p->M < ST_BM || p->out_scale != 1.0f) return false;
+  if (!(k128 || k20) || p->rows || p->act != 0 || (p->N & 127) || p->M < ST_BM) return false;
+  if (p->ln_gamma) { if (p->K1 != 128 || p->K2 || p->N != 128 || p->add1 || p->add2) return false; }
+  else if (p->out_scale != 1.0f) return false;
   if ((p->ldx & 3) || ((size_t)p->X & 15) || (p->ldw & 1) || ((size_t)p->W & 7)) return false;
   if (p->K2 && ((p->ldx2 & 1) || ((size_t)p->X2 & 7))) return false;
   if (k20 && (p->ldx & 1)) return false;
-  if ((p->add1 && !p->idx1) || p->add2) return false;
-  if (p->add1 && (p->add_rows <= 0 || (size_t)p->add_rows * p->ld_add1 * 4 >= 0xfffff000ull)) return false;
+  if (p->add2) return false;
+  if (p->add1 && p->idx1 && (p->add_rows <= 0 || (size_t)p->add_rows * p->ld_add1 * 4 >= 0xfffff000ull)) return false;
+  if (p->add1 && !p->idx1 && ((size_t)p->M * p->ld_add1 * 4 >= 0xfffff000ull || p->add1 == p->Y)) return false;   // (in place: the last tile recomputes rows)
   if ((size_t)p->M * p->ldx * 4 >= 0xfffff000ull || (size_t)p->M * p->ldy * 4 >= 0xfffff000ull) return false;
   return true;
 }
@@ -285,11 +351,19 @@ bool gemm_stream_eligible(const PgGemm* p) {
 template <int K1, int K2>
 static int launch_stream_k(const PgGemm* p, hipStream_t st) {
   const bool wide = (p->N & 255) == 0;           // 8 waves share one A tile for 256 columns
-  if (wide) return p->add1 ? launch_stream_t<8, 1, K1, K2>(p, st) : launch_stream_t<8, 0, K1, K2>(p, st);
-  return p->add1 ? launch_stream_t<4, 1, K1, K2>(p, st) : launch_stream_t<4, 0, K1, K2>(p, st);
+  const int nadd = p->add1 ? (p->idx1 ? 1 : 2) : 0;
+  if (wide) {
+    if (nadd == 0) return launch_stream_t<8, 0, K1, K2>(p, st);
+    if (nadd == 1) return launch_stream_t<8, 1, K1, K2>(p, st);
+    return launch_stream_t<8, 2, K1, K2>(p, st);
+  }
+  if (nadd == 0) return launch_stream_t<4, 0, K1, K2>(p, st);
+  if (nadd == 1) return launch_stream_t<4, 1, K1, K2>(p, st);
+  return launch_stream_t<4, 2, K1, K2>(p, st);
 }
 
 int launch_gemm_stream(const PgGemm* p, hipStream_t st) {
+  if (p->ln_gamma) return launch_stream_t<4, 0, 128, 0, true>(p, st);
   if (p->K1 == 20) {                             // K = 20 alone: the X operand takes the X2 (register) path
     PgGemm q = *p;
     q.X2 = p->X; q.ldx2 = p->ldx; q.K2 = 20; q.K1 = 0;

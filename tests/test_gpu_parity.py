@@ -151,6 +151,75 @@ def test_gemm_streaming_kernel_against_torch(M, N, gather, bias, K1, K2):
     assert rel_err(outs[0], outs[1].double()) < 2e-6
 
 
+@pytest.mark.parametrize('M', [64, 1000, 23288])
+def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
+    """The streaming kernel's LayerNorm-on-load form (second layer of the query MLPs: LN(128) + ReLU on the rows, bias, scale) and
+    its plain added operand (rows add1[r]) against float64 torch and the tiled kernel."""
+    from phoregen_amd import hip
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(M)
+    X = torch.randn(M, 128, generator=g) * 3 + 0.5
+    W, b = torch.randn(128, 128, generator=g) * 0.1, torch.randn(128, generator=g)
+    gam, bet = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    A = torch.randn(M, 128, generator=g)
+    ref_ln = 0.37 * (torch.relu(torch.nn.functional.layer_norm(X.double(), (128,), gam.double(), bet.double())) @ W.double().t() + b.double())
+    ref_add = X.double() @ W.double().t() + b.double() + A.double()
+    Xd, Wd, bd, gd, btd, Ad = (v.to(DEV) for v in (X, W, b, gam, bet, A))
+    for ref, ln in ((ref_ln, True), (ref_add, False)):
+        outs = []
+        for mode in (1, 0):
+            old = lib.pg_debug_gemm_specialised(mode)
+            try:
+                Y = torch.full((M, 128), float('nan'), device=DEV)
+                p = hip.PgGemm()
+                p.X, p.ldx, p.K1 = Xd.data_ptr(), 128, 128
+                p.W, p.ldw, p.bias = Wd.data_ptr(), 128, bd.data_ptr()
+                if ln:
+                    p.ln_gamma, p.ln_beta, p.out_scale = gd.data_ptr(), btd.data_ptr(), 0.37
+                else:
+                    p.add1, p.ld_add1, p.out_scale = Ad.data_ptr(), 128, 1.0
+                p.act = hip.ACT_NONE
+                p.Y, p.ldy, p.M, p.N = Y.data_ptr(), 128, M, 128
+                hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
+                torch.cuda.synchronize()
+            finally:
+                lib.pg_debug_gemm_specialised(old)
+            assert rel_err(Y.cpu(), ref) < 1e-5, (ln, mode)
+            outs.append(Y.cpu())
+        assert rel_err(outs[0], outs[1].double()) < 2e-6
+
+
+@pytest.mark.parametrize('ln', [True, False])
+def test_gemm_streaming_kernel_rows_do_not_depend_on_their_tile_position(ln):
+    """A row's result is bit-identical wherever the row sits in a 64-row tile (the anchored last tile recomputes rows of its
+    neighbour; a graph run alone must give the bits it gives inside a batch): rows [5, 5 + 200) of a 777-row product, computed
+    inside it and as a product of their own, repeated launches included."""
+    from phoregen_amd import hip
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(5)
+    X = (torch.randn(777, 128, generator=g) * 3 + 0.5).to(DEV)
+    W, b = (torch.randn(128, 128, generator=g) * 0.1).to(DEV), torch.randn(128, generator=g).to(DEV)
+    gam, bet = torch.randn(128, generator=g).to(DEV), torch.randn(128, generator=g).to(DEV)
+
+    def run(Xv):
+        Y = torch.full((Xv.shape[0], 128), float('nan'), device=DEV)
+        p = hip.PgGemm()
+        p.X, p.ldx, p.K1 = Xv.data_ptr(), 128, 128
+        p.W, p.ldw, p.bias = W.data_ptr(), 128, b.data_ptr()
+        if ln:
+            p.ln_gamma, p.ln_beta = gam.data_ptr(), bet.data_ptr()
+        p.out_scale, p.act = (0.37 if ln else 1.0), hip.ACT_NONE
+        p.Y, p.ldy, p.M, p.N = Y.data_ptr(), 128, Xv.shape[0], 128
+        hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
+        torch.cuda.synchronize()
+        return Y
+    whole = run(X)
+    for _ in range(4):
+        assert torch.equal(run(X), whole)
+    assert torch.equal(run(X[5:205]), whole[5:205])
+    assert torch.equal(run(X[713:777]), whole[713:777])
+
+
 @pytest.mark.parametrize('E', [1000, 128 * 7, 33])
 def test_bond_rows_fused_against_torch(E):
     """pg_bond_rows (csrc/bondrow.hip): four jobs over one staging of the h_bond tile -- plain, two gathered adds with the
