@@ -3,8 +3,11 @@
 //   pass A  K path for every row tile -> logits (and, for the position update, the per-head value scalars);
 //   exact softmax over the stored logits (base 2; queries carry log2(e)/sqrt(8));
 //   pass B  V path -> S^T[c,h] (node update) or the weighted sum of relative positions (position update).
-// U (query-folded keys) is read from HBM (pg_attn_fold_query), S goes back for pg_attn_unfold_value, so no
-// second-layer weights sit in LDS and several workgroups share a CU.  fp32 MFMA and VALU share the SIMD pipe on
+// Two forms.  Plain (training, and the standalone calls): U (query-folded keys) is read from HBM (pg_attn_fold_query), S goes
+// back for pg_attn_unfold_value, so no second-layer weights sit in LDS and several workgroups share a CU.  FUSED (the sampler):
+// one persistent 768-thread workgroup per CU keeps the lane-fixed W2k in LDS and folds the query in-kernel; the node-update
+// modes also apply W2v to the aggregate (streamed through L2, as in triplet2.hip) and write the 128-float update itself:
+// the [n][32][64] round trips of U and S (8 KB per node each way) and two launches per sub-layer disappear.  fp32 MFMA and VALU share the SIMD pipe on
 // gfx950 (profiles/r01_micro_mfma_valu_coexec.md): the kernel is written for low instruction count, occupancy only
 // hides the row-gather latency.
 // Lane l = (g = l>>4, m = l&15); 16x16x4 maps as in seg_attn.hip.
@@ -48,8 +51,8 @@ __device__ __forceinline__ float ln_fold_k(f4 (&hid)[8], const float* bp, int g)
   return rs;
 }
 
-template <bool KNN, bool POS, int MAXT, int THREADS>
-__global__ __launch_bounds__(THREADS, 3) void node_attn_kernel(PgTopo t, PgSegAttn p) {
+template <bool KNN, bool POS, int MAXT, int THREADS, bool FUSED>
+__global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTopo t, PgSegAttn p) {
   constexpr int NSTEP = KNN ? 12 : 0;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const bpk = lds;                   // [128] b' of the key MLP
@@ -58,6 +61,8 @@ __global__ __launch_bounds__(THREADS, 3) void node_attn_kernel(PgTopo t, PgSegAt
   float* const wf_v = wf_k + NSTEP * 512;
   float* const w2xv = wf_v + NSTEP * 512;   // POS: [32][64]
   float* const b2xv = w2xv + (POS ? 2048 : 0);
+  float* const w2k = b2xv + (POS ? 16 : 0); // FUSED: lane-fixed W2k [64][64][4]
+  float* const b2v_s = w2k + 16384;         // FUSED node update: [128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, m = lane & 15;
   for (int i = tid; i < 128; i += THREADS) { bpk[i] = p.ln_bk[i]; bpv[i] = p.ln_bv[i]; }
@@ -65,6 +70,10 @@ __global__ __launch_bounds__(THREADS, 3) void node_attn_kernel(PgTopo t, PgSegAt
   if constexpr (POS) {
     for (int i = tid; i < 2048; i += THREADS) w2xv[i] = p.W2xv_l[i];
     for (int i = tid; i < 16; i += THREADS) b2xv[i] = p.b2xv[i];
+  }
+  if constexpr (FUSED) {
+    for (int i = tid; i < 4096; i += THREADS) reinterpret_cast<f4*>(w2k)[i] = reinterpret_cast<const f4*>(p.W2k_l)[i];
+    if constexpr (!POS) for (int i = tid; i < 128; i += THREADS) b2v_s[i] = p.b2v[i];
   }
   __syncthreads();
 
@@ -103,7 +112,21 @@ __global__ __launch_bounds__(THREADS, 3) void node_attn_kernel(PgTopo t, PgSegAt
     // ======================= pass A =======================
     {
       f4 U[8];
-      {
+      if constexpr (FUSED) {          // U[c][h] = sum_d q[8h+d] W2k[8h+d][c]: the arithmetic of pg_attn_fold_query, from LDS
+        const float* qp = p.q + (size_t)seg * 128 + 8 * m;
+        const f4 qa = *reinterpret_cast<const f4*>(qp), qb = *reinterpret_cast<const f4*>(qp + 4);
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = tq * 4 + r;
+            const f4 wa = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i) * 64 + lane) * 4);
+            const f4 wb = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i + 1) * 64 + lane) * 4);
+            U[tq][r] = (qa[0] * wa[0] + qa[1] * wa[1]) + (qa[2] * wa[2] + qa[3] * wa[3]) +
+                       (qb[0] * wb[0] + qb[1] * wb[1]) + (qb[2] * wb[2] + qb[3] * wb[3]);
+            if (r == 3) __builtin_amdgcn_sched_barrier(0);     // at most 8 weight reads in flight: the registers are needed
+          }
+      } else {
         const float* up = p.U + (size_t)seg * 2048 + lane;
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq)
@@ -343,46 +366,90 @@ __global__ __launch_bounds__(THREADS, 3) void node_attn_kernel(PgTopo t, PgSegAt
             for (int tq = 0; tq < 8; ++tq) sT[tq] = mfma16(hv[tq][r], aw[r], sT[tq]);
         }
       }
-      float* sp = p.S + (size_t)seg * 2048 + lane;
+      if constexpr (FUSED) {
+        // out[8h+d] = W2v[8h+d,:] . S[:,h] + b2v[8h+d] * sum(alpha * gate): the arithmetic of pg_attn_unfold_value, W2v streamed
+        // through L2 (64 float4 per lane; the opaque lane copy keeps the 64 addresses from being hoisted out of the node loop)
+        int lz = lane;
+        asm volatile("" : "+v"(lz));
+        const f4* const w2v_g = reinterpret_cast<const f4*>(p.W2v_l);
+        float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int tq = 0; tq < 8; ++tq)
+        for (int i = 0; i < 32; ++i) {
+          const f4 wa = w2v_g[(2 * i) * 64 + lz];
+          const f4 wb = w2v_g[(2 * i + 1) * 64 + lz];
+          const float sv = sT[i >> 2][i & 3] * inv;
+          part[0] += wa[0] * sv; part[1] += wa[1] * sv; part[2] += wa[2] * sv; part[3] += wa[3] * sv;
+          part[4] += wb[0] * sv; part[5] += wb[1] * sv; part[6] += wb[2] * sv; part[7] += wb[3] * sv;
+          if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // 16 weight loads in flight at most
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sp[(tq * 4 + r) * 64] = sT[tq][r] * inv;
-      if (g == 0) p.swn[(size_t)seg * 16 + m] = sw * inv;
+        for (int d = 0; d < 8; ++d) {
+          part[d] += __shfl_xor(part[d], 16);
+          part[d] += __shfl_xor(part[d], 32);
+        }
+        const float swn_ = sw * inv;
+        const int o0 = 8 * m + 2 * g;
+        const float p0 = g == 0 ? part[0] : (g == 1 ? part[2] : (g == 2 ? part[4] : part[6]));
+        const float p1 = g == 0 ? part[1] : (g == 1 ? part[3] : (g == 2 ? part[5] : part[7]));
+        float2 o;
+        o.x = p0 + b2v_s[o0] * swn_;
+        o.y = p1 + b2v_s[o0 + 1] * swn_;
+        *reinterpret_cast<float2*>(p.out + (size_t)seg * 128 + o0) = o;
+      } else {
+        float* sp = p.S + (size_t)seg * 2048 + lane;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sp[(tq * 4 + r) * 64] = sT[tq][r] * inv;
+        if (g == 0) p.swn[(size_t)seg * 16 + m] = sw * inv;
+      }
     }
   }
 }
 
-template <bool KNN, bool POS, int MAXT, int THREADS>
+template <bool KNN, bool POS, int MAXT, int THREADS, bool FUSED>
 static int launch_na(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   constexpr int NSTEP = KNN ? 12 : 0;
-  const size_t lds = (256 + 2 * NSTEP * 512 + (POS ? 2048 + 16 : 0)) * sizeof(float);
-  if (int rc = reserve_lds(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS>), lds, "node_attn")) return rc;
+  const size_t lds = (256 + 2 * NSTEP * 512 + (POS ? 2048 + 16 : 0) + (FUSED ? 16384 + 128 : 0)) * sizeof(float);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED>), lds, "node_attn")) return rc;
   const int per = THREADS / 64;
   int blocks = (p->n_seg + per - 1) / per;
-  if (KNN && blocks > 3 * kNumCU) blocks = 3 * kNumCU;     // LDS-heavy: persistent-ish, the weights are loaded per block
-  hipLaunchKernelGGL((node_attn_kernel<KNN, POS, MAXT, THREADS>), dim3(blocks), dim3(THREADS), lds, st, *t, *p);
+  if (FUSED) { if (blocks > kNumCU) blocks = kNumCU; }      // one persistent workgroup per CU (64 KB of W2k each)
+  else if (KNN && blocks > 3 * kNumCU) blocks = 3 * kNumCU; // LDS-heavy: persistent-ish, the weights are loaded per block
+  hipLaunchKernelGGL((node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED>), dim3(blocks), dim3(THREADS), lds, st, *t, *p);
   return check_launch("pg_seg_attn(node)");
 }
 
-// returns -1 when the shape is outside what the two-pass kernels hold in registers (caller falls back to seg_attn.hip)
-int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+template <bool FUSED>
+static int launch_node_attn_t(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  constexpr int TH = FUSED ? 768 : 256;
   const bool knn = p->mode == PG_SEG_KNN_NODE || p->mode == PG_SEG_KNN_POS;
   const bool pos = p->mode == PG_SEG_KNN_POS || p->mode == PG_SEG_BOND_POS;
   if (knn) {
     if (p->knn_k > 32) return -1;
-    return pos ? launch_na<true, true, 2, 256>(t, p, st) : launch_na<true, false, 2, 256>(t, p, st);
+    return pos ? launch_na<true, true, 2, TH, FUSED>(t, p, st) : launch_na<true, false, 2, TH, FUSED>(t, p, st);
   }
   const int tiles = (t->max_nlig + 15) / 16;
   if (tiles > 5) return -1;
   if (pos) {
-    if (tiles <= 3) return launch_na<false, true, 3, 256>(t, p, st);
-    if (tiles == 4) return launch_na<false, true, 4, 256>(t, p, st);
-    return launch_na<false, true, 5, 256>(t, p, st);
+    if (tiles <= 3) return launch_na<false, true, 3, TH, FUSED>(t, p, st);
+    if (tiles == 4) return launch_na<false, true, 4, TH, FUSED>(t, p, st);
+    return launch_na<false, true, 5, TH, FUSED>(t, p, st);
   }
-  if (tiles <= 3) return launch_na<false, false, 3, 256>(t, p, st);
-  if (tiles == 4) return launch_na<false, false, 4, 256>(t, p, st);
-  return launch_na<false, false, 5, 256>(t, p, st);
+  if (tiles <= 3) return launch_na<false, false, 3, TH, FUSED>(t, p, st);
+  if (tiles == 4) return launch_na<false, false, 4, TH, FUSED>(t, p, st);
+  return launch_na<false, false, 5, TH, FUSED>(t, p, st);
+}
+
+// returns -1 when the shape is outside what the two-pass kernels hold in registers (caller falls back to seg_attn.hip).
+// Fused form: q and W2k_l given (and, for the node-update modes, W2v_l, b2v, out) -- see node_attn_fused_request()
+bool node_attn_fused_request(const PgSegAttn* p) {
+  const bool pos = p->mode == PG_SEG_KNN_POS || p->mode == PG_SEG_BOND_POS;
+  return p->mode <= PG_SEG_BOND_POS && p->q && p->W2k_l && (pos || (p->W2v_l && p->b2v && p->out));
+}
+
+int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  return node_attn_fused_request(p) ? launch_node_attn_t<true>(t, p, st) : launch_node_attn_t<false>(t, p, st);
 }
 
 }  // namespace pg

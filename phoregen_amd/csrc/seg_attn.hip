@@ -20,6 +20,7 @@ namespace pg {
 int launch_triplet(const PgTopo* t, const PgSegAttn* p, hipStream_t st);     // triplet.hip
 int launch_triplet_staged(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // triplet2.hip (-1: not applicable)
 int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st);   // node_attn.hip (-1: shape not covered)
+bool node_attn_fused_request(const PgSegAttn* p);                            // node_attn.hip
 
 // Folded LayerNorm + ReLU (packing._kv_mlp: hidden is centred and sign-normalised, |gamma| lives in the next Linear):
 // z = ReLU(hidden + b' * sigma); returns 1/sigma, which the caller applies to the row's logits / attention weights.
@@ -582,6 +583,17 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
   if (p->mode <= PG_SEG_BOND_POS && !(g_force_generic & 1)) {   // two-pass kernels; pg_debug_force_generic_seg keeps the one-pass kernel testable
     const int rc = launch_node_attn(t, p, st);
     if (rc >= 0) return rc;
+  }
+  if (node_attn_fused_request(p)) {
+    // the fused form was asked for but the one-pass kernel runs (shape outside the two-pass kernels, or forced): fold, attend
+    // and unfold as separate launches through the caller's U / S / swn scratch
+    const bool pos = p->mode == PG_SEG_KNN_POS || p->mode == PG_SEG_BOND_POS;
+    if (!p->U || !p->seg_ids || (!pos && (!p->S || !p->swn))) { set_error("pg_seg_attn: the fused node form needs U (and S, swn) scratch and seg_ids for the one-pass kernel"); return PG_ERR_ARG; }
+    if (int rc = pg_attn_fold_query(p->q, 128, p->W2k_l, p->n_seg, p->seg_ids, const_cast<float*>(p->U), stream)) return rc;
+    PgSegAttn u = *p;
+    u.q = nullptr; u.W2k_l = nullptr;
+    if (int rc = pg_seg_attn(t, &u, stream)) return rc;
+    return pos ? PG_OK : pg_attn_unfold_value(p->S, p->swn, p->W2v_l, p->b2v, p->n_seg, p->seg_ids, p->out, 128, stream);
   }
   switch (p->mode) {
     case PG_SEG_KNN_NODE: return launch_seg<PG_SEG_KNN_NODE>(t, p, st);

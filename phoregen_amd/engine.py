@@ -39,6 +39,7 @@ class Engine:
         self.multi_stream = os.environ.get('PG_STREAMS', '1') != '0'
         self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
         self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
+        self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
         self.fused_bond_rows = os.environ.get('PG_BOND_FUSED', '0') != '0'     # csrc/bondrow.hip; off: measured slower than the separate pg_gemm launches
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
@@ -213,9 +214,11 @@ class Engine:
             self._gemm(prog, blk(4), 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
         knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
         pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
+        fused = self.fused_node and mode != hip.SEG_PHORE      # in-kernel query fold / value unfold (csrc/node_attn.hip)
         for seg_ids, n_seg, is_lig in h_dst_lists:
-            self._call(prog, self.lib.pg_attn_fold_query, wq.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
-                       seg_ids.data_ptr(), wU.data_ptr())
+            if not fused:
+                self._call(prog, self.lib.pg_attn_fold_query, wq.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
+                           seg_ids.data_ptr(), wU.data_ptr())
             kw = dict(x=x, Cdst_k=blk(0), Cdst_v=blk(1), ld_cdst=Y.stride(0), U=wU)
             if knn:
                 kw.update(nrm=w.nrm, nbr=w.nbr, deg=w.deg, ew=w.ew, Csrc_k=blk(2), Csrc_v=blk(3), ld_csrc=Y.stride(0),
@@ -228,10 +231,15 @@ class Engine:
                 kw.update(W2xv_l=a.W2xv_l, b2xv=a.b2xv, dx=dx, accumulate_dx=0)
             else:
                 kw.update(S=wS, swn=wsw)
+            if fused:      # (U / S / swn stay attached as scratch for the one-pass fallback inside pg_seg_attn)
+                kw.update(q=wq, W2k_l=a.W2k_l)
+                if not pos:
+                    assert out.stride(0) == 128
+                    kw.update(W2v_l=a.W2v_l, b2v=a.b2v, out=out)
             if extra:
                 kw.update(extra)
             self._seg(prog, mode, n_seg, seg_ids, a, **kw)
-            if not pos:
+            if not pos and not fused:
                 self._call(prog, self.lib.pg_attn_unfold_value, wS.data_ptr(), wsw.data_ptr(), a.W2v_l.data_ptr(),
                            a.b2v.data_ptr(), n_seg, seg_ids.data_ptr(), out.data_ptr(), out.stride(0))
 
