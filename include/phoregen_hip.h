@@ -188,6 +188,12 @@ typedef struct {
   const float* q;            /* triplet: [n_bond,128] queries, pre-scaled by 1/sqrt(head_dim)      */
   const float* W2k_l;        /* triplet: lane-fixed second-layer key weights [64][64][4]           */
   const float* W2v_l; const float* b2v;      /* triplet: lane-fixed value weights + bias          */
+  /* Fused form of the four node modes (the sampler): q [n_ctx,128] and W2k_l given -> the query is folded in-kernel and U is not
+   * read; the node-update modes (KNN_NODE, BOND_NODE) given W2v_l, b2v and out [n_ctx,128] (rows 128 floats apart) also apply
+   * the value second layer and write out[seg,:] = W2v . S + b2v * sum(alpha * gate) instead of S / swn, i.e. what
+   * pg_attn_fold_query -> pg_seg_attn -> pg_attn_unfold_value compute as three launches.  U (and S, swn) must still point at
+   * scratch of the plain form's size: shapes the two-pass kernels do not hold (knn_k > 32, ligands above 80 atoms) run the
+   * three launches internally. */
   const float* W2xv_l; const float* b2xv;    /* pos modes: lane-fixed [32][64] + [16]             */
   /* outputs */
   float* S; float* swn;      /* node modes: [n_ctx][32][64], [n_ctx][16]                          */
