@@ -149,7 +149,10 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
     }
     __syncthreads();
     T2_STAMP(1);                                  // staging the P blocks
-    const int n_seg = A * nm1;
+    // the group's segments, or the part of them this queue entry hands out (small batches: plan.py splits groups into whole
+    // 12-wave rounds so that the queue can level the workgroups)
+    const int s_begin = __builtin_amdgcn_readfirstlane(d.w & 0xffff);
+    const int n_seg = __builtin_amdgcn_readfirstlane((d.w >> 16) ? (d.w >> 16) : A * nm1);
     const int n_tiles = (nm1 + 15) >> 4;
 
     // per-segment global inputs (the Q row of Cdst, the query, the residual row) are fetched ONE SEGMENT AHEAD: their HBM
@@ -169,9 +172,9 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       nqb = *reinterpret_cast<const f4*>(qp_ + 4);                                                                     \
       nrs = *reinterpret_cast<const float2*>(p.resid + seg_ * 128 + 8 * m + 2 * g);                                    \
     }
-    if (PRE && wave < n_seg) T2_FETCH(wave)
+    if (PRE && s_begin + wave < n_seg) T2_FETCH(s_begin + wave)
 
-    for (int s = wave; s < n_seg; s += WAVES) {
+    for (int s = s_begin + wave; s < n_seg; s += WAVES) {
       const int a = s / nm1, ip = s - a * nm1;            // source atom of the group, target index among the other atoms
       const int j = j0 + a, i = ip + (ip >= j ? 1 : 0);
       const int seg = bond_off + i * nm1 + (j < i ? j : j - 1);          // internal id of edge j->i

@@ -106,19 +106,33 @@ class BatchPlan:
         # source-atom groups of the LDS-staged triplet kernel (csrc/triplet2.hip): consecutive source atoms of one ligand whose
         # P blocks ((n-1) rows each) fit the 80 staged rows; pulled from a queue, most expensive first
         rows_cap, waves = 80, 12
-        its = []
+        groups = []
         for gi in range(B):
             n = int(nlig[gi])
             if n < 2 or n - 1 > rows_cap or n > 96:
                 continue
             A = max(1, min(rows_cap // (n - 1), n))
-            tiles = (n - 1 + 15) // 16
             for j0 in range(0, n, A):
-                a = min(A, n - j0)
-                rounds = (a * (n - 1) + waves - 1) // waves
-                its.append((rounds * (tiles + 1.0) + 0.5, int(lig2ctx[lig_off[gi]]), n | (j0 << 8) | (a << 16), int(bond_off[gi])))
+                groups.append((gi, n, j0, min(A, n - j0)))
+        # small batches (fewer than ~4 groups per workgroup): a group's segments are handed out in up to 4 parts of whole
+        # 12-wave rounds, so that the queue can level the workgroups (16 graphs: 320 groups of 7 rounds on 256 workgroups meant
+        # 14 rounds for the slowest; in parts of 3 + 2 + 2 rounds about 10)
+        want_parts = 1 if len(groups) >= 4 * 256 or not groups else min(4, -(-4 * 256 // len(groups)))
+        its = []
+        for gi, n, j0, a in groups:
+            tiles = (n - 1 + 15) // 16
+            n_seg = a * (n - 1)
+            rounds = (n_seg + waves - 1) // waves
+            parts = max(1, min(want_parts, rounds // 2))
+            r0 = 0
+            for k in range(parts):
+                r1 = r0 + rounds // parts + (1 if k < rounds % parts else 0)
+                s0, s1 = r0 * waves, min(r1 * waves, n_seg)
+                its.append(((r1 - r0) * (tiles + 1.0) + 0.5, int(lig2ctx[lig_off[gi]]), n | (j0 << 8) | (a << 16), int(bond_off[gi]),
+                            0 if parts == 1 else (s0 | (s1 << 16))))
+                r0 = r1
         its.sort(key=lambda r: -r[0])
-        self.tri_iters = torch.tensor([[r[1], r[2], r[3], 0] for r in its], dtype=torch.int32).reshape(-1, 4).to(device)
+        self.tri_iters = torch.tensor([[r[1], r[2], r[3], r[4]] for r in its], dtype=torch.int32).reshape(-1, 4).to(device)
         self.n_tri_iters = len(its) if (B and int(nlig.max()) - 1 <= rows_cap and int(nlig.max()) <= 96) else 0
         self.tri_counter = torch.zeros(1, dtype=torch.int32, device=device)
         for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
