@@ -40,6 +40,7 @@ class Engine:
         self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
         self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
         self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
+        self.join_early = os.environ.get('PG_JOIN_EARLY', '0') == '1'          # side lanes finish before the triplet kernel starts
         self.fused_bond_rows = os.environ.get('PG_BOND_FUSED', '0') != '0'     # csrc/bondrow.hip; off: measured slower than the separate pg_gemm launches
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
@@ -359,7 +360,7 @@ class Engine:
                 self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
                            scale=HEAD_SCALE)
                 self._lane = 0
-            self._join(prog, (3,))
+            self._join(prog, (1, 2, 3) if self.join_early else (3,))
             a = L.TB
             self._event(prog, 'triplet', True)
             self.tri_calls.append(len(prog))
@@ -369,7 +370,8 @@ class Engine:
                       **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter,
                               Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
-            self._join(prog, (1, 2))
+            if not self.join_early:
+                self._join(prog, (1, 2))
             # ---- h' = h + lin_node(aggE + aggB) (:288)
             # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~12 us)
             self._gemm(prog, w.aggE, 128, L.W_lin2[:, :128], w.lin_tmp, n, 128, bias=L.b_lin, add1=hc)
