@@ -17,8 +17,9 @@
 //     every tile is a full tile: the last one starts at row M - 64);
 //   * the gathered epilogue operands of tile t+1 are fetched during tile t and become the MFMA accumulator init of tile t+1.
 // One raw s_barrier per tile; the LDS-DMA is retired by a counted s_waitcnt (the compiler does not count inline-asm loads):
-// the only younger vector-memory operations of a wave at that point are the tile's 32 stores (checked in the build: the
-// ISA must hold exactly 32 buffer_store_dword per stage and no scratch).
+// the only younger vector-memory operations of a wave at that point are the tile's 32 stores (more would be harmless, fewer
+// would let the wait pass early; tests/test_host_cpu.py cross-compiles this file and checks 32 buffer_store_dword per tile
+// body and no scratch in every variant).
 // v_mfma_f32_32x32x2_f32: A lane (l31 = row, kh = k), B lane (l31 = column, kh = k), D reg r = row 8(r>>2) + 4 kh + (r&3).
 // The k order inside a group of four is free: step s of k-group g uses k = 4g + 2 kh + s on both operands.
 #include <type_traits>

@@ -61,6 +61,34 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(lib.pg_last_error(), bytes)
 
 
+def test_streaming_gemm_isa_keeps_its_counted_wait_valid(tmp_path):
+    """csrc/gemm_stream.hip retires its LDS-DMA with `s_waitcnt vmcnt(32)`: correct only while the 32 result stores of a tile are
+    the ONLY younger vector-memory operations of a wave (fewer would let the wait pass before the DMA lands).  Cross-compile
+    the file and check, for every variant that uses the DMA: no scratch (spill traffic would be uncounted VMEM), exactly 32
+    buffer_store_dword per tile body (three bodies per kernel: first tile, stage 1, stage 0), 8 or 4 DMA pieces per body."""
+    import shutil, subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    out = tmp_path / 'gs.s'
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=on', '--cuda-device-only', '-S',
+                    os.path.join(ROOT, 'phoregen_amd', 'csrc', 'gemm_stream.hip'), '-o', str(out)], check=True,
+                   stderr=subprocess.DEVNULL)
+    lines = out.read_text().split('\n')
+    starts = [i for i, l in enumerate(lines) if re.match(r'_ZN2pg18gemm_stream_kernelI.*PgGemmi:', l)]
+    assert len(starts) >= 12
+    for i in starts:
+        nw, nadd, k1, k2, ln = re.match(r'_ZN2pg18gemm_stream_kernelILi(\d)ELi(\d)ELi(\d+)ELi(\d+)ELb([01])E', lines[i]).groups()
+        end = next(j for j in range(i, len(lines)) if 's_endpgm' in lines[j])
+        scratch = next(l for l in lines[end:] if '; ScratchSize:' in l)
+        body = '\n'.join(lines[i:end])
+        assert scratch.split(':')[1].strip() == '0', (lines[i], scratch)
+        if k1 == '128':
+            assert len(re.findall(r'buffer_store_dword ', body)) == 96, lines[i]
+            assert len(re.findall(r'buffer_load_dwordx4 .* lds', body)) == 4 * (8 if nw == '4' else 4), lines[i]
+            assert len(re.findall(r's_waitcnt vmcnt\(32\)\n\ts_barrier', body)) == 2, lines[i]
+
+
 def test_product_never_imports_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'phoregen_amd')):
