@@ -29,6 +29,8 @@ namespace pg {
 #define T2_STAMP(slot) do { } while (0)
 #endif
 
+typedef float t2_f2 __attribute__((ext_vector_type(2)));
+
 constexpr int T2_ROW = 260;          // floats per staged row: P_k[128] | P_v[128] | 4 (bank spread of the b128 key-layout reads)
 constexpr int T2_ROWS = 80;          // staged rows per workgroup
 constexpr int T2_XS = 96;            // ligand atoms whose coordinates are staged
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       const f4* src = reinterpret_cast<const f4*>(p.Csrc_k + (size_t)(bond_off + j0 * nm1) * 256);
       const int n4 = A * nm1 * 64;
       for (int idx = tid; idx < n4; idx += THREADS)
-        *reinterpret_cast<f4*>(pbuf + (idx >> 6) * T2_ROW + (idx & 63) * 4) = src[idx];
+        *reinterpret_cast<f4*>(pbuf + (idx >> 6) * T2_ROW + (idx & 63) * 4) = __builtin_nontemporal_load(src + idx);   // read once
       for (int i = tid; i < n * 3; i += THREADS) xs[i] = p.x[(size_t)lig0 * 3 + i];
     }
     __syncthreads();
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       const size_t seg_ = (size_t)(bond_off + i_ * nm1 + (j_ < i_ ? j_ : j_ - 1));                                     \
       const float* qk_ = p.Cdst_k + seg_ * p.ld_cdst + m;                                                              \
       const float* qv_ = p.Cdst_v + seg_ * p.ld_cdst + m;                                                              \
-      _Pragma("unroll") for (int tq = 0; tq < 8; ++tq) { nQk[tq] = qk_[16 * tq]; nQv[tq] = qv_[16 * tq]; }             \
+      _Pragma("unroll") for (int tq = 0; tq < 8; ++tq) { nQk[tq] = __builtin_nontemporal_load(qk_ + 16 * tq); nQv[tq] = __builtin_nontemporal_load(qv_ + 16 * tq); } \
       const float* qp_ = p.q + seg_ * 128 + 8 * m;                                                                     \
-      nqa = *reinterpret_cast<const f4*>(qp_);                                                                         \
-      nqb = *reinterpret_cast<const f4*>(qp_ + 4);                                                                     \
-      nrs = *reinterpret_cast<const float2*>(p.resid + seg_ * 128 + 8 * m + 2 * g);                                    \
+      nqa = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp_));                                              \
+      nqb = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp_ + 4));                                          \
+      { const t2_f2 r_ = __builtin_nontemporal_load(reinterpret_cast<const t2_f2*>(p.resid + seg_ * 128 + 8 * m + 2 * g)); nrs.x = r_[0]; nrs.y = r_[1]; } \
     }
     if (PRE && s_begin + wave < n_seg) T2_FETCH(s_begin + wave)
 
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       float2 o;
       o.x = rsd.x + p0 * inv + b2v[o0] * has;
       o.y = rsd.y + p1 * inv + b2v[o0 + 1] * has;
-      *reinterpret_cast<float2*>(p.out + ro) = o;
+      __builtin_nontemporal_store((t2_f2){o.x, o.y}, reinterpret_cast<t2_f2*>(p.out + ro));
       T2_STAMP(6);                                // unfold + store
     }
 #undef T2_FETCH
