@@ -11,7 +11,8 @@
 //     register + a scalar tile offset, the LDS destination in M0; two stages, the next tile in flight during the MFMAs;
 //   * the LDS image is what the DMA writes (lane-linear 1 KB pieces of 8 rows x 128 B) with the XOR swizzle applied to the
 //     SOURCE address: piece (i, j) = rows 8i.., k 32j..; row r of a piece at r*128 B, its 16-byte slot p holds
-//     k-group p ^ ((row >> 1) & 7) -> the MFMA operand reads (ds_read_b64, lane = (row, k half)) are 2-way conflicts at worst;
+//     k-group p ^ ((row >> 1) & 7) -> the MFMA operand reads (one ds_read_b128 per lane = a whole slot) are conflict-free in the
+//     16-lane groups the LDS serves a b128 read in;
 //   * the wave's 32 columns of W stay in 64 registers for the whole kernel (lane = (column, k half)): one LDS operand per MFMA;
 //   * results leave straight from the accumulators by buffer stores (descriptor + lane-fixed offset + scalar row offset;
 //     every tile is a full tile: the last one starts at row M - 64);
@@ -21,7 +22,8 @@
 // would let the wait pass early; tests/test_host_cpu.py cross-compiles this file and checks 32 buffer_store_dword per tile
 // body and no scratch in every variant).
 // v_mfma_f32_32x32x2_f32: A lane (l31 = row, kh = k), B lane (l31 = column, kh = k), D reg r = row 8(r>>2) + 4 kh + (r&3).
-// The k order inside a group of four is free: step s of k-group g uses k = 4g + 2 kh + s on both operands.
+// The k order inside a chunk of eight is free: step s (0..3) of chunk c uses k = 8c + 4 kh + s on both operands, so a lane's
+// four values of a chunk are one 16-byte slot.
 #include <type_traits>
 
 #include "common.h"
@@ -64,12 +66,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   // ---- the wave's W slice: 64 registers for the whole kernel ----
   float Wr[K1 ? 64 : 1];
   if constexpr (K1 > 0) {
-    const float* wrow = p.W + (size_t)col * p.ldw + 2 * kh;
+    const float* wrow = p.W + (size_t)col * p.ldw + 4 * kh;
 #pragma unroll
-    for (int kg = 0; kg < 32; ++kg) {
-      const float2 w = *reinterpret_cast<const float2*>(wrow + 4 * kg);
-      Wr[2 * kg] = w.x;
-      Wr[2 * kg + 1] = w.y;
+    for (int c = 0; c < 16; ++c) {
+      const f4 w = *reinterpret_cast<const f4*>(wrow + 8 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Wr[4 * c + e] = w[e];
     }
   }
   // second operand [X | X2] (K2 = 20, the Gaussian smearing of the bond length): no LDS, the lane's ten values of a row
@@ -118,11 +120,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   const unsigned voff_even = row_sub * ldxb + ((pp ^ ((row_sub >> 1) & 7u)) << 4);
   const unsigned voff_odd = row_sub * ldxb + ((pp ^ ((4u + (row_sub >> 1)) & 7u)) << 4);
   const unsigned voff_wave = (wave & 1) ? voff_odd : voff_even;        // NW == 8: wave w fetches piece row i = w
-  // operand reads: row R = 32 b + l31 of k-group 8 j + ks  ->  piece (4 b + (l31 >> 3), j), row l31 & 7, slot ks ^ ((l31 >> 1) & 7)
-  unsigned rd[8];
+  // operand reads: row R = 32 b + l31, chunk c (k = 8c .. 8c+7): the lane's k-group is 2c + kh = 8 j + 2 q + kh (j = c >> 2,
+  // q = c & 3) -> piece (4 b + (l31 >> 3), j), row l31 & 7, slot (2 q + kh) ^ ((l31 >> 1) & 7)
+  unsigned rd[4];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-    rd[ks] = (unsigned)(l31 >> 3) * 4096u + (unsigned)(l31 & 7) * 128u + (((unsigned)ks ^ ((unsigned)(l31 >> 1) & 7u)) << 4) + 8u * kh;
+  for (int q = 0; q < 4; ++q)
+    rd[q] = (unsigned)(l31 >> 3) * 4096u + (unsigned)(l31 & 7) * 128u + (((unsigned)(2 * q + kh) ^ ((unsigned)(l31 >> 1) & 7u)) << 4);
   unsigned voffY[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) voffY[t] = (unsigned)(4 * kh + t) * ldyb + (unsigned)l31 * 4u;
@@ -265,28 +268,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
     }
     if constexpr (K1 > 0) {
       // operands one k-group ahead of their MFMAs (the compiler otherwise reads them right in front of the use)
-      auto frag = [&](int kg, int b) {
-        return *reinterpret_cast<const float2*>(st_lds + rd[kg & 7] + (stage * ST_STAGE + b * 16384u + (kg >> 3) * 1024u));
+      auto frag = [&](int c, int b) {
+        return *reinterpret_cast<const f4*>(st_lds + rd[c & 3] + (stage * ST_STAGE + b * 16384u + (c >> 2) * 1024u));
       };
-      float2 aA0 = frag(0, 0), aA1 = frag(0, 1), aB0, aB1;
+      f4 aA0 = frag(0, 0), aA1 = frag(0, 1), aB0, aB1;
 #pragma unroll
-      for (int kg = 0; kg < 32; kg += 2) {
-        if (kg == 24) {                           // last quarter: the next tile's gathered operand goes out
+      for (int c = 0; c < 16; c += 2) {
+        if (c == 12) {                            // last quarter: the next tile's gathered operand goes out
           if constexpr (NADD == 1) gather(descA1, ld1b, ix1, g1);
           if constexpr (NADD == 2) gather_plain(tile_row0(next), g1);
         }
-        aB0 = frag(kg + 1, 0); aB1 = frag(kg + 1, 1);
-        __builtin_amdgcn_sched_barrier(0);        // the read of k-group kg+1 stays in front of the MFMAs of k-group kg
-        acc[0] = mfma32(aA0.x, Wr[2 * kg], acc[0]);
-        acc[1] = mfma32(aA1.x, Wr[2 * kg], acc[1]);
-        acc[0] = mfma32(aA0.y, Wr[2 * kg + 1], acc[0]);
-        acc[1] = mfma32(aA1.y, Wr[2 * kg + 1], acc[1]);
-        if (kg + 2 < 32) { aA0 = frag(kg + 2, 0); aA1 = frag(kg + 2, 1); }
+        aB0 = frag(c + 1, 0); aB1 = frag(c + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);        // the reads of chunk c+1 stay in front of the MFMAs of chunk c
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = mfma32(aA0[e], Wr[4 * c + e], acc[0]);
+          acc[1] = mfma32(aA1[e], Wr[4 * c + e], acc[1]);
+        }
+        if (c + 2 < 16) { aA0 = frag(c + 2, 0); aA1 = frag(c + 2, 1); }
         __builtin_amdgcn_sched_barrier(0);
-        acc[0] = mfma32(aB0.x, Wr[2 * kg + 2], acc[0]);
-        acc[1] = mfma32(aB1.x, Wr[2 * kg + 2], acc[1]);
-        acc[0] = mfma32(aB0.y, Wr[2 * kg + 3], acc[0]);
-        acc[1] = mfma32(aB1.y, Wr[2 * kg + 3], acc[1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = mfma32(aB0[e], Wr[4 * c + 4 + e], acc[0]);
+          acc[1] = mfma32(aB1[e], Wr[4 * c + 4 + e], acc[1]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     } else {
