@@ -285,21 +285,24 @@ class Engine:
                    w.pos_phore.data_ptr(), p.phore2ctx.data_ptr(), h[0].data_ptr(), x[0].data_ptr())
         self._call(prog, lib.pg_embed_bond, t, w.in_h_edge.data_ptr(), p.bond_graph.data_ptr(), w.in_t.data_ptr(),
                    pk.W_edge_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), hb[0].data_ptr())
-        self._denoiser_program(prog, lig, both)
-        cur = self.final_idx
-        # heads (diffusion.py:221-241)
-        W0, b0, W2, b2 = pk.v0
-        self._gemm(prog, h[cur], 128, W0, w.head, n, 128, bias=b0, act=hip.ACT_SSP)
-        self._call(prog, lib.pg_rows_linear, w.head.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 12, p.n_lig,
-                   p.lig2ctx.data_ptr(), w.out_v.data_ptr(), 12)
-        W0, b0, W2, b2 = pk.b0
-        self._gemm(prog, hb[cur], 128, W0, w.head_b, E, 128, bias=b0, act=hip.ACT_SSP)
-        # out_bond in the caller's edge order: row r reads the internal row of caller edge r
-        self._call(prog, lib.pg_rows_linear, w.head_b.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 6, E,
-                   None if p.edge_identity else p.edge_int.data_ptr(), w.out_bond.data_ptr(), 6)
+        # heads (diffusion.py:221-241).  Neither waits for the last layer's position update: the bond head starts on a side lane as
+        # soon as the last triplet kernel has written h_bond, the node head as soon as the last lin_node has written h
+        def bond_head(hb_final):
+            W0, b0, W2, b2 = pk.b0
+            self._gemm(prog, hb_final, 128, W0, w.head_b, E, 128, bias=b0, act=hip.ACT_SSP)
+            # out_bond in the caller's edge order: row r reads the internal row of caller edge r
+            self._call(prog, lib.pg_rows_linear, w.head_b.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 6, E,
+                       None if p.edge_identity else p.edge_int.data_ptr(), w.out_bond.data_ptr(), 6)
+
+        def node_head(h_final):
+            W0, b0, W2, b2 = pk.v0
+            self._gemm(prog, h_final, 128, W0, w.head, n, 128, bias=b0, act=hip.ACT_SSP)
+            self._call(prog, lib.pg_rows_linear, w.head.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 12, p.n_lig,
+                       p.lig2ctx.data_ptr(), w.out_v.data_ptr(), 12)
+        self._denoiser_program(prog, lig, both, heads=(bond_head, node_head))
         return prog
 
-    def _denoiser_program(self, prog, lig, both):
+    def _denoiser_program(self, prog, lig, both, heads=None):
         """uni_denoiser.py:396-430: knn graph + gate once, then the layers.  State starts in slot 0."""
         w, p, pk, lib = self.ws, self.plan, self.pack, self.lib
         n, E, t = p.n_ctx, p.n_bond, p.topo_ref
@@ -370,12 +373,23 @@ class Engine:
                       **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter,
                               Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
+            last = heads is not None and li == len(pk.layers) - 1
+            if last:                                   # lane 3 (the triplet queries) has been joined: the bond head takes it
+                self._fork(prog, (3,))
+                self._lane = 3
+                heads[0](hbn)
+                self._lane = 0
             if not self.join_early:
                 self._join(prog, (1, 2))
             # ---- h' = h + lin_node(aggE + aggB) (:288)
             # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~12 us)
             self._gemm(prog, w.aggE, 128, L.W_lin2[:, :128], w.lin_tmp, n, 128, bias=L.b_lin, add1=hc)
             self._gemm(prog, w.aggB, 128, L.W_lin2[:, 128:], hn, n, 128, add1=w.lin_tmp)
+            if last:                                   # lane 2 (bond-node attention) has been joined: the node head takes it
+                self._fork(prog, (2,))
+                self._lane = 2
+                heads[1](hn)
+                self._lane = 0
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
             # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
             # only for ligand atoms
@@ -398,6 +412,8 @@ class Engine:
             self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
             self._mark(prog, f'L{li}', hn, hbn, xn, w.aggE, w.aggB, w.dxe, w.dxb, w.nrm, hbc)
             cur = nxt
+        if heads is not None:
+            self._join(prog, (2, 3))
         self.final_idx = cur
 
     def _run(self, prog):
