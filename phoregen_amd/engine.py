@@ -280,11 +280,15 @@ class Engine:
         lig = [(p.lig2ctx, p.n_lig, True)]
         both = [(p.lig2ctx, p.n_lig, True), (p.phore2ctx, p.n_phore, False)]
         h, x, hb = w.h, w.x, w.hb
+        # the bond embedding runs beside the node embedding, the knn search and the edge gate (joined before layer 0 forks)
+        self._fork(prog, (2,))
+        self._lane = 2
+        self._call(prog, lib.pg_embed_bond, t, w.in_h_edge.data_ptr(), p.bond_graph.data_ptr(), w.in_t.data_ptr(),
+                   pk.W_edge_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), hb[0].data_ptr())
+        self._lane = 0
         self._call(prog, lib.pg_embed_ctx, t, w.in_h_node.data_ptr(), w.in_pos.data_ptr(), w.in_t.data_ptr(),
                    pk.W_node_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), w.hp_emb.data_ptr(),
                    w.pos_phore.data_ptr(), p.phore2ctx.data_ptr(), h[0].data_ptr(), x[0].data_ptr())
-        self._call(prog, lib.pg_embed_bond, t, w.in_h_edge.data_ptr(), p.bond_graph.data_ptr(), w.in_t.data_ptr(),
-                   pk.W_edge_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), hb[0].data_ptr())
         # heads (diffusion.py:221-241).  Neither waits for the last layer's position update: the bond head starts on a side lane as
         # soon as the last triplet kernel has written h_bond, the node head as soon as the last lin_node has written h
         def bond_head(hb_final):
@@ -299,10 +303,10 @@ class Engine:
             self._gemm(prog, h_final, 128, W0, w.head, n, 128, bias=b0, act=hip.ACT_SSP)
             self._call(prog, lib.pg_rows_linear, w.head.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 12, p.n_lig,
                        p.lig2ctx.data_ptr(), w.out_v.data_ptr(), 12)
-        self._denoiser_program(prog, lig, both, heads=(bond_head, node_head))
+        self._denoiser_program(prog, lig, both, heads=(bond_head, node_head), pre_join=(2,))
         return prog
 
-    def _denoiser_program(self, prog, lig, both, heads=None):
+    def _denoiser_program(self, prog, lig, both, heads=None, pre_join=None):
         """uni_denoiser.py:396-430: knn graph + gate once, then the layers.  State starts in slot 0."""
         w, p, pk, lib = self.ws, self.plan, self.pack, self.lib
         n, E, t = p.n_ctx, p.n_bond, p.topo_ref
@@ -318,9 +322,18 @@ class Engine:
         for li, L in enumerate(pk.layers):
             nxt = 1 - cur
             hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
+            # direction vectors (read by the knn attention, lane 1) and bond-length smearing (read by the P product on lane 0 and
+            # the Q rows on lane 3) depend on x only: they run beside the first-layer GEMM instead of in front of it
+            side_geom = not self.fused_bond_rows
+            if side_geom:
+                self._fork(prog, (1, 3))
+                self._lane = 1
             self._call(prog, lib.pg_lig_normals, t, xc.data_ptr(), w.phore_norm.data_ptr(), p.phore2ctx.data_ptr(),
                        w.nrm.data_ptr())
+            if side_geom:
+                self._lane = 3
             self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
+            self._lane = 0
             # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
             # (ligand atoms: targets and sources of bond edges)
             if self.row_subsets:
@@ -338,6 +351,10 @@ class Engine:
                     dict(W=L.TB.W_g2, k0=128, K=20, N=256, Y=w.Qd),
                     dict(W=L.TB.W_q_hb, k0=0, K=128, N=128, add1=Y1b(14, 15), idx1='dst', ln=(L.TB.q_ln_g, L.TB.q_ln_b),
                          W2=L.TB.W2q, b2=L.TB.b2q, scale2=HEAD_SCALE, Y2=w.qT)])
+            if li == 0 and pre_join:
+                self._join(prog, pre_join)
+            if side_geom:
+                self._join(prog, (3,))                 # lane 0 (the P product) needs the smearing
             self._fork(prog, (1, 2, 3))
             # ---- node update over knn edges (:281)                                    [lane 1]
             self._lane = 1
