@@ -40,8 +40,6 @@ class Engine:
         self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
         self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
         self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
-        self.join_early = os.environ.get('PG_JOIN_EARLY', '0') == '1'          # side lanes finish before the triplet kernel starts
-        self.fused_bond_rows = os.environ.get('PG_BOND_FUSED', '0') != '0'     # csrc/bondrow.hip; off: measured slower than the separate pg_gemm launches
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -123,6 +121,19 @@ class Engine:
         tap.__name__ = 'join'
         prog.append((tap, None, -1))
 
+    def _sync(self, prog, waiter, on):
+        """Lane `waiter` continues after everything enqueued SO FAR on the lanes `on` (a join of a point, not of the whole lane)."""
+        if not self.multi_stream:
+            return
+        def tap(streams):
+            for l in on:
+                ev = torch.cuda.Event()
+                ev.record(streams[l])
+                streams[waiter].wait_event(ev)
+            return 0
+        tap.__name__ = 'sync'
+        prog.append((tap, None, -1))
+
     def _event(self, prog, name, start):
         """Timing tap: when `self.timers` is a dict, record a HIP event on the launch stream around a kernel."""
         def tap(streams):
@@ -165,32 +176,6 @@ class Engine:
         self._keep += [g, X, W, Y, bias, X2, ln, add1, idx1, add2, idx2, rows]
         self._call(prog, self.lib.pg_gemm, C.byref(g))
 
-    def _bond_rows(self, prog, hb, G, jobs):
-        """One fused launch over the bond rows (csrc/bondrow.hip).  jobs: dicts with W, k0, K, N, Y and optional bias,
-        add1/idx1 ('src'|'dst'), add2/idx2, or for the query MLP: ln=(gamma, beta), W2, b2, scale2, Y2."""
-        p = self.plan
-        b = hip.PgBondRows()
-        b.hb, b.ld_hb, b.G = hb.data_ptr(), hb.stride(0), hip.ptr(G)
-        b.idx_a, b.idx_b, b.E, b.n_jobs = p.bond_src.data_ptr(), p.bond_dst.data_ptr(), p.n_bond, len(jobs)
-        for j, d in zip(b.jobs, jobs):
-            W = d['W']
-            j.W, j.ldw, j.k0, j.K, j.N = W.data_ptr(), W.stride(0), d['k0'], d['K'], d['N']
-            j.bias = hip.ptr(d.get('bias'))
-            for n in ('1', '2'):
-                t = d.get('add' + n)
-                if t is not None:
-                    setattr(j, 'add' + n, t.data_ptr())
-                    setattr(j, 'ld_add' + n, t.stride(0))
-                    setattr(j, f'idx{n}_is_b', int(d['idx' + n] == 'dst'))
-            if 'W2' in d:
-                j.ln_g, j.ln_b, j.W2, j.b2 = d['ln'][0].data_ptr(), d['ln'][1].data_ptr(), d['W2'].data_ptr(), hip.ptr(d.get('b2'))
-                j.N2, j.scale2, j.Y2, j.ldy2 = d['W2'].size(0), d.get('scale2', 1.0), d['Y2'].data_ptr(), d['Y2'].stride(0)
-            else:
-                j.Y, j.ldy = d['Y'].data_ptr(), d['Y'].stride(0)
-            self._keep += list(v for v in d.values() if torch.is_tensor(v)) + [d.get('ln')]
-        self._keep += [b, hb, G]
-        self._call(prog, self.lib.pg_bond_rows, C.byref(b))
-
     def _seg(self, prog, mode, n_seg, seg_ids, a, **kw):
         s = hip.PgSegAttn()
         s.mode, s.n_seg, s.seg_ids = mode, n_seg, hip.ptr(seg_ids)
@@ -202,17 +187,24 @@ class Engine:
         self._keep += [s, seg_ids, a]
         self._call(prog, self.lib.pg_seg_attn, self.plan.topo_ref, C.byref(s))
 
-    def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None, buf=0, extra=None):
+    def _query_gemm(self, prog, a, Y, col0, h_dst_lists, buf):
+        """q = W2q . ReLU(LN(q_hid)) + b2q, scaled by 1/sqrt(head_dim); q_hid = block 4 of the sub-layer's first-layer columns."""
+        n, wq = self.plan.n_ctx, self.ws.q[buf]
+        qh = Y[:, col0 + 4 * 128: col0 + 5 * 128]
+        if len(h_dst_lists) == 1 and self.row_subsets:      # queries are only needed at the target rows
+            ids, cnt, _ = h_dst_lists[0]
+            self._gemm(prog, qh, 128, a.W2q, wq, cnt, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE, rows=ids)
+        else:
+            self._gemm(prog, qh, 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
+
+    def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None, buf=0, extra=None,
+                        query_done=False):
         """Shared tail of the four node-target sub-layers.  Y[:, col0 + 128*b] blocks: k_dst, v_dst, k_src, v_src, q_hid."""
         w, p, n = self.ws, self.plan, self.plan.n_ctx
         wq, wU, wS, wsw = w.q[buf], w.U[buf], w.S[buf], w.swn[buf]
         blk = lambda b: Y[:, col0 + 128 * b: col0 + 128 * (b + 1)]
-        # q = W2q . ReLU(LN(q_hid)) + b2q, scaled by 1/sqrt(head_dim)
-        if len(h_dst_lists) == 1 and self.row_subsets:      # queries are only needed at the target rows
-            ids, cnt, _ = h_dst_lists[0]
-            self._gemm(prog, blk(4), 128, a.W2q, wq, cnt, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE, rows=ids)
-        else:
-            self._gemm(prog, blk(4), 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
+        if not query_done:
+            self._query_gemm(prog, a, Y, col0, h_dst_lists, buf)
         knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
         pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
         fused = self.fused_node and mode != hip.SEG_PHORE      # in-kernel query fold / value unfold (csrc/node_attn.hip)
@@ -323,15 +315,12 @@ class Engine:
             nxt = 1 - cur
             hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
             # direction vectors (read by the knn attention, lane 1) and bond-length smearing (read by the P product on lane 0 and
-            # the Q rows on lane 3) depend on x only: they run beside the first-layer GEMM instead of in front of it
-            side_geom = not self.fused_bond_rows
-            if side_geom:
-                self._fork(prog, (1, 3))
-                self._lane = 1
+            # the Q rows on lane 2) depend on x only: they run beside the first-layer GEMM instead of in front of it
+            self._fork(prog, (1, 3))
+            self._lane = 1
             self._call(prog, lib.pg_lig_normals, t, xc.data_ptr(), w.phore_norm.data_ptr(), p.phore2ctx.data_ptr(),
                        w.nrm.data_ptr())
-            if side_geom:
-                self._lane = 3
+            self._lane = 3
             self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
             self._lane = 0
             # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
@@ -341,46 +330,32 @@ class Engine:
                 self._gemm(prog, hc, 128, L.W_node1[640:], w.Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
             else:
                 self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
-            if self.fused_bond_rows:
-                # every product over the OLD h_bond in one launch: bond-node k/v source halves, triplet P, the triplet's
-                # per-segment constant and the triplet query MLP (hidden layer kept on chip)
-                Y1b = lambda b0, b1: w.Y1[:, b0 * 128:b1 * 128]
-                self._bond_rows(prog, hbc, w.G, [
-                    dict(W=L.NB.W_hb, k0=0, K=128, N=256, Y=w.CsB, add1=Y1b(7, 9), idx1='src'),
-                    dict(W=L.TB.W_hbg, k0=0, K=148, N=256, Y=w.P, add1=Y1b(10, 12), idx1='src', add2=Y1b(12, 14), idx2='dst'),
-                    dict(W=L.TB.W_g2, k0=128, K=20, N=256, Y=w.Qd),
-                    dict(W=L.TB.W_q_hb, k0=0, K=128, N=128, add1=Y1b(14, 15), idx1='dst', ln=(L.TB.q_ln_g, L.TB.q_ln_b),
-                         W2=L.TB.W2q, b2=L.TB.b2q, scale2=HEAD_SCALE, Y2=w.qT)])
             if li == 0 and pre_join:
                 self._join(prog, pre_join)
-            if side_geom:
-                self._join(prog, (3,))                 # lane 0 (the P product) needs the smearing
+            self._join(prog, (3,))                     # the smearing is done (P on lane 0, Q rows on lane 2 read it)
             self._fork(prog, (1, 2, 3))
-            # ---- node update over knn edges (:281)                                    [lane 1]
-            self._lane = 1
-            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0)
-            # ---- node update over bond edges (:284)                                   [lane 2]
-            self._lane = 2
-            if not self.fused_bond_rows:
-                self._gemm(prog, hbc, 128, L.NB.W_hb, w.CsB, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
-            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB, buf=1)
-            # ---- bond update over triplets (:285)                                     [lane 0]
+            last = heads is not None and li == len(pk.layers) - 1
+            # Launch order of a layer.  Lane 0 carries the bond chain (P -> triplet -> bond position update), lane 1 the node
+            # chain (knn attention -> lin_node -> second first-layer GEMM -> knn position update), lane 2 the Q rows and the
+            # bond-node attention, lane 3 the triplet queries: nothing on lane 1 waits for the triplet kernel, and lane 0 picks
+            # the node chain's results up at the two points where the bond chain needs them.
+            # ---- bond update over triplets, its operands (:285)
+            # P[k->j] = W.[h_bond | G] + (source half)[k] + (target half)[j].  Every row of the block a segment j->i reads has the
+            # same target j, so in the staged form that half rides on the segment's own row Q[j->i] instead (one gathered operand
+            # per product; the gather kernel builds Q in-kernel and keeps it on P)
             self._lane = 0
-            if not self.fused_bond_rows:
-                # P[k->j] = W.[h_bond | G] + (source half)[k] + (target half)[j].  Every row of the block a segment j->i reads has
-                # the same target j, so in the staged form that half rides on the segment's own row Q[j->i] instead (one gathered
-                # operand per product; the gather kernel builds Q in-kernel and keeps it on P)
-                self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
-                           add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
-                           **({} if staged else dict(add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)))
-                self._lane = 3                                                          # triplet queries [lane 3]
-                if staged:   # the per-segment constant of the triplet MLPs as rows: Wg2 . smear(d_ji) + (target half)[j]
-                    self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=w.Y1[:, 12 * 128:14 * 128], idx1=p.bond_src)
-                self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
-                self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b),
-                           scale=HEAD_SCALE)
-                self._lane = 0
-            self._join(prog, (1, 2, 3) if self.join_early else (3,))
+            self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
+                       add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
+                       **({} if staged else dict(add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)))
+            self._lane = 2
+            if staged:   # the per-segment constant of the triplet MLPs as rows: Wg2 . smear(d_ji) + (target half)[j]
+                self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=w.Y1[:, 12 * 128:14 * 128], idx1=p.bond_src)
+                self._sync(prog, 0, (2,))              # lane 0 (the triplet kernel) waits for the Q rows, not for all of lane 2
+            self._lane = 3                                                              # triplet queries
+            self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
+            self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b), scale=HEAD_SCALE)
+            self._lane = 0
+            self._join(prog, (3,))
             a = L.TB
             self._event(prog, 'triplet', True)
             self.tri_calls.append(len(prog))
@@ -390,23 +365,26 @@ class Engine:
                       **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter,
                               Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
-            last = heads is not None and li == len(pk.layers) - 1
             if last:                                   # lane 3 (the triplet queries) has been joined: the bond head takes it
                 self._fork(prog, (3,))
                 self._lane = 3
                 heads[0](hbn)
-                self._lane = 0
-            if not self.join_early:
-                self._join(prog, (1, 2))
-            # ---- h' = h + lin_node(aggE + aggB) (:288)
-            # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~12 us)
+            # ---- node update over bond edges (:284)                                   [lane 2]
+            self._lane = 2
+            self._gemm(prog, hbc, 128, L.NB.W_hb, w.CsB, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB, buf=1)
+            # ---- node update over knn edges (:281), then h' = h + lin_node(aggE + aggB) (:288)   [lane 1]
+            self._lane = 1
+            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0)
+            self._sync(prog, 1, (2,))                  # aggB
+            # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~17 us)
             self._gemm(prog, w.aggE, 128, L.W_lin2[:, :128], w.lin_tmp, n, 128, bias=L.b_lin, add1=hc)
             self._gemm(prog, w.aggB, 128, L.W_lin2[:, 128:], hn, n, 128, add1=w.lin_tmp)
-            if last:                                   # lane 2 (bond-node attention) has been joined: the node head takes it
-                self._fork(prog, (2,))
+            if last:                                   # lane 2 has nothing left in this step: the node head takes it
+                self._sync(prog, 2, (1,))
                 self._lane = 2
                 heads[1](hn)
-                self._lane = 0
+                self._lane = 1
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
             # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
             # only for ligand atoms
@@ -416,14 +394,10 @@ class Engine:
                 self._gemm(prog, hn, 128, L.W_node2[512:], w.Y2[:, 512:], p.n_lig, 768, bias=L.b_node2[512:], rows=p.lig2ctx)
             else:
                 self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
-            self._fork(prog, (1,))
-            self._lane = 1
+            self._sync(prog, 0, (1,))                  # lane 0 continues after the triplet kernel AND Y2 (which implies lane 2)
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
-            if self.fused_bond_rows:
-                self._bond_rows(prog, hbn, None, [dict(W=L.PB.W_hb, k0=0, K=128, N=256, Y=w.CsB, add1=w.Y2[:, 7 * 128:9 * 128], idx1='src')])
-            else:
-                self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
             self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1)
             self._join(prog, (1,))
             self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
