@@ -166,12 +166,13 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
     {                                                                                                                  \
       const int a_ = (S) / nm1, ip_ = (S) - a_ * nm1, j_ = j0 + a_, i_ = ip_ + (ip_ >= j_ ? 1 : 0);                    \
       const size_t seg_ = (size_t)(bond_off + i_ * nm1 + (j_ < i_ ? j_ : j_ - 1));                                     \
-      const float* qk_ = p.Cdst_k + seg_ * p.ld_cdst + m;                                                              \
-      const float* qv_ = p.Cdst_v + seg_ * p.ld_cdst + m;                                                              \
-      _Pragma("unroll") for (int tq = 0; tq < 8; ++tq) { nQk[tq] = __builtin_nontemporal_load(qk_ + 16 * tq); nQv[tq] = __builtin_nontemporal_load(qv_ + 16 * tq); } \
+      /* the vector-memory counter is in-order: the query (needed first, by the fold) goes out first, the Q rows after it */ \
       const float* qp_ = p.q + seg_ * 128 + 8 * m;                                                                     \
       nqa = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp_));                                              \
       nqb = __builtin_nontemporal_load(reinterpret_cast<const f4*>(qp_ + 4));                                          \
+      const float* qk_ = p.Cdst_k + seg_ * p.ld_cdst + m;                                                              \
+      const float* qv_ = p.Cdst_v + seg_ * p.ld_cdst + m;                                                              \
+      _Pragma("unroll") for (int tq = 0; tq < 8; ++tq) { nQk[tq] = __builtin_nontemporal_load(qk_ + 16 * tq); nQv[tq] = __builtin_nontemporal_load(qv_ + 16 * tq); } \
       { const t2_f2 r_ = __builtin_nontemporal_load(reinterpret_cast<const t2_f2*>(p.resid + seg_ * 128 + 8 * m + 2 * g)); nrs.x = r_[0]; nrs.y = r_[1]; } \
     }
     if (PRE && s_begin + wave < n_seg) T2_FETCH(s_begin + wave)

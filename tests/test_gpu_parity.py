@@ -220,6 +220,25 @@ def test_gemm_streaming_kernel_rows_do_not_depend_on_their_tile_position(ln):
     assert torch.equal(run(X[713:777]), whole[713:777])
 
 
+@pytest.mark.parametrize('M,n_out,K,gather', [(1000, 6, 128, True), (203720, 6, 128, False), (77, 12, 128, True), (300, 1, 256, True)])
+def test_rows_linear_against_torch(M, n_out, K, gather):
+    """pg_rows_linear (the last Linear of the heads, diffusion.py:223,241): the K = 128 matrix-pipe kernel and the one-wave-per-row
+    kernel (other K), with and without the row gather, output rows strided."""
+    from phoregen_amd import hip
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(M + n_out)
+    X, W, b = torch.randn(M + 50, K, generator=g), torch.randn(n_out, K, generator=g) * 0.2, torch.randn(n_out, generator=g)
+    rows = torch.randint(0, M + 50, (M,), generator=g, dtype=torch.int32)
+    ref = (X[rows.long()] if gather else X[:M]).double() @ W.double().t() + b.double()
+    Xd, Wd, bd, rd = X.to(DEV), W.to(DEV), b.to(DEV), rows.to(DEV)
+    Y = torch.full((M, n_out + 3), float('nan'), device=DEV)
+    hip.check(lib.pg_rows_linear(Xd.data_ptr(), K, K, Wd.data_ptr(), bd.data_ptr(), n_out, M, rd.data_ptr() if gather else None,
+                                 Y.data_ptr(), n_out + 3, hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isnan(Y[:, n_out:]).all()
+    assert rel_err(Y[:, :n_out].cpu(), ref) < 1e-5
+
+
 @pytest.mark.parametrize('E', [1000, 128 * 7, 33])
 def test_bond_rows_fused_against_torch(E):
     """pg_bond_rows (csrc/bondrow.hip): four jobs over one staging of the h_bond tile -- plain, two gathered adds with the
