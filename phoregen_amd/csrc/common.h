@@ -67,6 +67,11 @@ __device__ __forceinline__ float smear(float d, int i) {
   return expf(-0.5f * t * t);
 }
 
+__device__ __forceinline__ float ssp(float v) {  // shifted softplus (models/common.py:58-64): softplus(v) - ln 2, torch threshold 20
+  float sp = v > 20.f ? v : log1pf(expf(v));
+  return sp - 0.69314718055994530942f;
+}
+
 constexpr int kNumCU = 256;
 
 #ifdef PG_ABLATE

@@ -11,10 +11,6 @@ namespace pg {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 1;
 
-__device__ __forceinline__ float ssp(float v) {  // softplus(v) - ln 2, torch threshold 20
-  float sp = v > 20.f ? v : log1pf(expf(v));
-  return sp - 0.69314718055994530942f;
-}
 
 __global__ __launch_bounds__(256) void gemm_kernel(PgGemm p PG_ABL_PARAM) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT];   // staging tiles; reused by the epilogue

@@ -54,7 +54,8 @@ __device__ __forceinline__ void st_dma(unsigned lds_dst, unsigned voff, i4v desc
 }
 
 template <int NW /* waves: 32 output columns each */, int NADD /* 0 | 1: rows add1[idx1[r]] | 2: rows add1[r] */, int K1 /* 128 | 0 */,
-          int K2 /* 0 | 20 */, bool LN /* LayerNorm(128) + ReLU on the X rows (K1 = 128, NW = 4) */>
+          int K2 /* 0 | 20 */, bool LN /* LayerNorm(128) + ReLU on the X rows (K1 = 128, NW = 4) */,
+          bool SSP = false /* shifted softplus on the result (the heads' first layers) */>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(PgGemm p, int n_tiles) {
   extern __shared__ __attribute__((aligned(1024))) char st_lds[];     // the ONLY LDS object: stage s at byte s * 32 KB
   const int lane = threadIdx.x & 63;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
         const unsigned soff = (row0 + 32u * b + 8u * (r >> 2)) * ldyb + (unsigned)colw * 4u;
         float v = acc[b][r];              // (a named float: __builtin_bit_cast straight from the vector element read element 0)
         if constexpr (LN) v *= p.out_scale;
+        if constexpr (SSP) v = ssp(v);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), descY, voffY[r & 3], soff, 0);
       }
     tile = next;
@@ -321,9 +323,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_stream_kernel(P
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the trailing (out-of-range) DMA must not outlive the workgroup's LDS
 }
 
-template <int NW, int NADD, int K1, int K2, bool LN = false>
+template <int NW, int NADD, int K1, int K2, bool LN = false, bool SSP = false>
 static int launch_stream_t(const PgGemm* p, hipStream_t st) {
-  const void* k = reinterpret_cast<const void*>(gemm_stream_kernel<NW, NADD, K1, K2, LN>);
+  const void* k = reinterpret_cast<const void*>(gemm_stream_kernel<NW, NADD, K1, K2, LN, SSP>);
   const size_t lds = K1 ? 2 * ST_STAGE + (LN ? 1024 : 0) : 0;
   if (lds) if (int rc = reserve_lds(k, lds, "pg_gemm(stream)")) return rc;
   const int n_tiles = (p->M + ST_BM - 1) / ST_BM;
@@ -331,17 +333,19 @@ static int launch_stream_t(const PgGemm* p, hipStream_t st) {
   int per_cb = (NW == 4 ? 2 : 1) * kNumCU / n_cb;
   if (per_cb < 1) per_cb = 1;
   if (per_cb > n_tiles) per_cb = n_tiles;
-  hipLaunchKernelGGL((gemm_stream_kernel<NW, NADD, K1, K2, LN>), dim3(per_cb, n_cb), dim3(NW * 64), lds, st, *p, n_tiles);
+  hipLaunchKernelGGL((gemm_stream_kernel<NW, NADD, K1, K2, LN, SSP>), dim3(per_cb, n_cb), dim3(NW * 64), lds, st, *p, n_tiles);
   return check_launch("pg_gemm(stream)");
 }
 
 // eligible: K = 128 from X (optionally + 20 from X2), or K = 20 alone; no row subset / activation; N a multiple of 128; at most
 // one added operand (rows add1[idx1[r]] with the operand's row count, or rows add1[r]); 16-byte aligned rows; everything
 // addressable with 32-bit byte offsets; at least one full tile of rows.  LayerNorm-on-load: K = 128, N = 128, no added operand
-// (the second layer of the query MLPs); out_scale only there
+// (the second layer of the query MLPs); out_scale only there.  Shifted softplus: K = 128, N = 128, bias only (the heads)
 bool gemm_stream_eligible(const PgGemm* p) {
   const bool k128 = p->K1 == 128 && (p->K2 == 0 || p->K2 == 20), k20 = p->K1 == 20 && p->K2 == 0;
-  if (!(k128 || k20) || p->rows || p->act != 0 || (p->N & 127) || p->M < ST_BM) return false;
+  if (!(k128 || k20) || p->rows || (p->N & 127) || p->M < ST_BM) return false;
+  if (p->act == 1) { if (p->K1 != 128 || p->K2 || p->N != 128 || p->ln_gamma || p->add1 || p->add2 || p->out_scale != 1.0f) return false; }
+  else if (p->act != 0) return false;
   if (p->ln_gamma) { if (p->K1 != 128 || p->K2 || p->N != 128 || p->add1 || p->add2) return false; }
   else if (p->out_scale != 1.0f) return false;
   if ((p->ldx & 3) || ((size_t)p->X & 15) || (p->ldw & 1) || ((size_t)p->W & 7)) return false;
@@ -370,6 +374,7 @@ static int launch_stream_k(const PgGemm* p, hipStream_t st) {
 
 int launch_gemm_stream(const PgGemm* p, hipStream_t st) {
   if (p->ln_gamma) return launch_stream_t<4, 0, 128, 0, true>(p, st);
+  if (p->act == 1) return launch_stream_t<4, 0, 128, 0, false, true>(p, st);
   if (p->K1 == 20) {                             // K = 20 alone: the X operand takes the X2 (register) path
     PgGemm q = *p;
     q.X2 = p->X; q.ldx2 = p->ldx; q.K2 = 20; q.K1 = 0;

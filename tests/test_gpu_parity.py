@@ -153,8 +153,8 @@ def test_gemm_streaming_kernel_against_torch(M, N, gather, bias, K1, K2):
 
 @pytest.mark.parametrize('M', [64, 1000, 23288])
 def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
-    """The streaming kernel's LayerNorm-on-load form (second layer of the query MLPs: LN(128) + ReLU on the rows, bias, scale) and
-    its plain added operand (rows add1[r]) against float64 torch and the tiled kernel."""
+    """The streaming kernel's LayerNorm-on-load form (second layer of the query MLPs: LN(128) + ReLU on the rows, bias, scale), its
+    plain added operand (rows add1[r]) and its shifted-softplus epilogue (the heads) against float64 torch and the tiled kernel."""
     from phoregen_amd import hip
     lib = hip.lib()
     g = torch.Generator().manual_seed(M)
@@ -164,8 +164,9 @@ def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
     A = torch.randn(M, 128, generator=g)
     ref_ln = 0.37 * (torch.relu(torch.nn.functional.layer_norm(X.double(), (128,), gam.double(), bet.double())) @ W.double().t() + b.double())
     ref_add = X.double() @ W.double().t() + b.double() + A.double()
+    ref_ssp = torch.nn.functional.softplus(X.double() @ W.double().t() + b.double()) - np.log(2.0)
     Xd, Wd, bd, gd, btd, Ad = (v.to(DEV) for v in (X, W, b, gam, bet, A))
-    for ref, ln in ((ref_ln, True), (ref_add, False)):
+    for ref, ln in ((ref_ln, True), (ref_add, False), (ref_ssp, 'ssp')):
         outs = []
         for mode in (1, 0):
             old = lib.pg_debug_gemm_specialised(mode)
@@ -174,11 +175,13 @@ def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
                 p = hip.PgGemm()
                 p.X, p.ldx, p.K1 = Xd.data_ptr(), 128, 128
                 p.W, p.ldw, p.bias = Wd.data_ptr(), 128, bd.data_ptr()
-                if ln:
+                p.act = hip.ACT_NONE
+                if ln == 'ssp':
+                    p.act, p.out_scale = hip.ACT_SSP, 1.0
+                elif ln:
                     p.ln_gamma, p.ln_beta, p.out_scale = gd.data_ptr(), btd.data_ptr(), 0.37
                 else:
                     p.add1, p.ld_add1, p.out_scale = Ad.data_ptr(), 128, 1.0
-                p.act = hip.ACT_NONE
                 p.Y, p.ldy, p.M, p.N = Y.data_ptr(), 128, M, 128
                 hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
                 torch.cuda.synchronize()
