@@ -348,7 +348,7 @@ bool gemm_stream_eligible(const PgGemm* p) {
   else if (p->act != 0) return false;
   if (p->ln_gamma) { if (p->K1 != 128 || p->K2 || p->N != 128 || p->add1 || p->add2) return false; }
   else if (p->out_scale != 1.0f) return false;
-  if ((p->ldx & 3) || ((size_t)p->X & 15) || (p->ldw & 1) || ((size_t)p->W & 7)) return false;
+  if ((p->ldx & 3) || ((size_t)p->X & 15) || (p->ldw & 3) || ((size_t)p->W & 15)) return false;     // 16-byte loads of X rows and W rows
   if (p->K2 && ((p->ldx2 & 1) || ((size_t)p->X2 & 7))) return false;
   if (k20 && (p->ldx & 1)) return false;
   if (p->add2) return false;
