@@ -335,6 +335,26 @@ def test_plan_and_partition_properties_random_sizes():
         assert int(ch[0]) == 0 and int(ch[-1]) == E and bool((ch[1:] >= ch[:-1]).all())
         parts = partition_graphs(na, world)
         assert sorted(torch.cat(parts).tolist()) == list(range(B))
+        # queue entries of the staged triplet kernel: every segment (bond edge j->i) of every ligand is handed out exactly once,
+        # whole groups or parts of them; a part starts on a 12-wave round boundary
+        if plan.n_tri_iters:
+            seen = torch.zeros(E, dtype=torch.int32)
+            l2c = plan.lig2ctx.long().tolist()
+            first_ctx = {l2c[int(off[g])]: g for g in range(B) if int(na[g]) > 0}
+            for lig0, packed, boff, rng in plan.tri_iters.tolist():
+                n, j0, A = packed & 0xff, (packed >> 8) & 0xff, packed >> 16
+                g = first_ctx[lig0]
+                assert n == int(na[g]) and boff == int(plan.g_bond_off[g]) and A * (n - 1) <= 80 and j0 + A <= n
+                s0, s1 = rng & 0xffff, rng >> 16
+                if rng == 0:
+                    s0, s1 = 0, A * (n - 1)
+                assert 0 <= s0 < s1 <= A * (n - 1) and s0 % 12 == 0
+                for sg in range(s0, s1):
+                    a, ip = divmod(sg, n - 1)
+                    j = j0 + a
+                    i = ip + (1 if ip >= j else 0)
+                    seen[boff + i * (n - 1) + (j if j < i else j - 1)] += 1
+            assert bool((seen == 1).all())
     check()
 
 
