@@ -682,6 +682,36 @@ def test_full_size_batch_equals_single_graph_runs(model, oracle):
     assert all(torch.isfinite(o).all() for o in out)
 
 
+def test_engine_variants_agree(model):
+    """The measurement switches of the engine must not change results beyond fp32 summation order: one stream vs four lanes
+    (bit-identical: same kernels, same order per kernel), node attention with separate fold / unfold launches, the gather triplet
+    kernel, the tiled GEMM kernel instead of the streaming one."""
+    import os
+    from phoregen_amd import hip
+    inp, _, _ = _headline_inputs(12, seed=9)
+    dev_inp = {k: v.to(DEV) for k, v in inp.items()}
+
+    def run(env=None, gemm_mode=None):
+        old_env = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        old_mode = hip.lib().pg_debug_gemm_specialised(gemm_mode) if gemm_mode is not None else None
+        try:
+            model._engine = None                      # the switches are read when an Engine is built
+            with torch.no_grad():
+                return [o.cpu().clone() for o in model(**dev_inp)[:3]]
+        finally:
+            for k, v in old_env.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            if old_mode is not None:
+                hip.lib().pg_debug_gemm_specialised(old_mode)
+            model._engine = None
+    base = run()
+    serial = run({'PG_STREAMS': '0'})
+    assert all(torch.equal(a, b) for a, b in zip(base, serial))
+    for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run(gemm_mode=0)):
+        assert max(rel_err(a, b) for a, b in zip(variant, base)) <= 2e-5
+
+
 def test_full_size_e3_equivariance(model):
     """Rigid motion of ligand + pharmacophore (positions and direction vectors) at full size: type logits invariant,
     predicted coordinates co-rotate (the denoiser is E(3)-equivariant by construction, uni_denoiser.py:260-298)."""
