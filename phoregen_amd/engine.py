@@ -150,11 +150,12 @@ class Engine:
         evs = self.timers.get(name, [])
         return [a.elapsed_time(b) for (sa, a), (sb, b) in zip(evs[0::2], evs[1::2]) if sa and not sb]
 
-    def _mark(self, prog, name, *tensors):
-        """Debug tap: when `self.debug` is a dict, clone the named tensors at this point of the launch list."""
-        def tap(_stream):
+    def _mark(self, prog, name, *tensors, lane=0):
+        """Debug tap: when `self.debug` is a dict, clone the named tensors at this point of the launch list (of `lane`)."""
+        def tap(streams):
             if self.debug is not None:
-                self.debug[name] = tuple(t.clone() for t in tensors)
+                with torch.cuda.stream(streams[lane if self.multi_stream else 0]):
+                    self.debug[name] = tuple(t.clone() for t in tensors)
             return 0
         tap.__name__ = 'tap_' + name
         prog.append((tap, None, -1))
@@ -304,13 +305,17 @@ class Engine:
         n, E, t = p.n_ctx, p.n_bond, p.topo_ref
         h, x, hb = w.h, w.x, w.hb
         g = pk.gate
+        # the knn graph and its gate are read by the knn attention only (lane 1): they run there, beside layer 0's first GEMMs
+        self._fork(prog, (1,))
+        self._lane = 1
         self._call(prog, lib.pg_knn_ctx, t, x[0].data_ptr(), self.k, w.nbr.data_ptr(), w.deg.data_ptr())
         self._call(prog, lib.pg_edge_gate, t, x[0].data_ptr(), w.nbr.data_ptr(), w.deg.data_ptr(), self.k,
                    g['W0'].data_ptr(), g['b0'].data_ptr(), g['g'].data_ptr(), g['b'].data_ptr(), g['W3'].data_ptr(),
                    C.c_float(g['b3']), w.ew.data_ptr())
+        self._mark(prog, 'graph', w.nbr, w.deg, w.ew, lane=1)
+        self._lane = 0
         cur = 0
         staged = bool(p.n_tri_iters and self.staged_triplet)
-        self._mark(prog, 'graph', w.nbr, w.deg, w.ew)
         for li, L in enumerate(pk.layers):
             nxt = 1 - cur
             hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
