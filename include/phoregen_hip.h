@@ -209,7 +209,8 @@ typedef struct {
   /* PG_SEG_TRIPLET, optional: source-atom groups for the LDS-staged kernel (csrc/triplet2.hip).  tri_iters [n_tri_iters][4] =
    * {ctx index of the ligand's first atom, n | j0 << 8 | A << 16, first internal bond row of the graph, s0 | s1 << 16}: the A
    * consecutive source atoms j0.. of an n-atom ligand, A*(n-1) <= 80, longest first; the entry covers the segments [s0, s1) of the
-   * group's A*(n-1) (0: all of them); tri_counter: one int of scratch (the work queue head).
+   * group's A*(n-1) (0: all of them); tri_counter: TWO ints of scratch (queue head, exit count), zero before the first launch --
+   * every launch leaves them zero again.
    * Requires the target-major bond order of the host mirror, Csrc_k/Csrc_v = the two halves of one [n_bond,256] tensor and
    * Cdst_k/Cdst_v [n_bond] rows = smear(d_ji) . Wg2 of the segment's own edge (as in the adjoint's contract). */
   const int* tri_iters; int n_tri_iters; int* tri_counter;

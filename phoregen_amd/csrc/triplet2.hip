@@ -136,7 +136,16 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
     __syncthreads();
     const int it = __builtin_amdgcn_readfirstlane(ctrl[0]);
     T2_STAMP(0);                                  // waiting for the group hand-out (barriers, queue)
-    if (it >= p.n_tri_iters) break;
+    if (it >= p.n_tri_iters) {
+      // the queue leaves itself ready for the next launch: the last workgroup out (all others have made their final draw before
+      // they count themselves out) zeroes the head and the exit count -- no memset between the six launches of a step
+      if (tid == 0 && atomicAdd(p.tri_counter + 1, 1) == (int)gridDim.x - 1) {
+        p.tri_counter[0] = 0;
+        p.tri_counter[1] = 0;
+        __threadfence();
+      }
+      break;
+    }
     const int4 d = iters[it];
     const int lig0 = __builtin_amdgcn_readfirstlane(d.x);
     const int n = __builtin_amdgcn_readfirstlane(d.y & 0xff), j0 = __builtin_amdgcn_readfirstlane((d.y >> 8) & 0xff);
@@ -429,8 +438,6 @@ template <int THREADS, int MAXT>
 static int launch_t2(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   const size_t lds = t2_lds_floats() * sizeof(float);
   if (int rc = reserve_lds(reinterpret_cast<const void*>(triplet2_kernel<THREADS, MAXT>), lds, "pg_seg_attn(triplet, staged)")) return rc;
-  hipError_t e = hipMemsetAsync(p->tri_counter, 0, sizeof(int), st);
-  if (e != hipSuccess) { set_error("pg_seg_attn(triplet, staged): %s", hipGetErrorString(e)); return PG_ERR_HIP; }
   hipLaunchKernelGGL((triplet2_kernel<THREADS, MAXT>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p);
   return check_launch("pg_seg_attn(triplet, staged)");
 }

@@ -337,8 +337,9 @@ class Engine:
                 self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
             if li == 0 and pre_join:
                 self._join(prog, pre_join)
-            self._join(prog, (3,))                     # the smearing is done (P on lane 0, Q rows on lane 2 read it)
             self._fork(prog, (1, 2, 3))
+            self._sync(prog, 0, (3,))                  # the smearing (alone on lane 3 so far) is read by P on lane 0
+            self._sync(prog, 2, (3,))                  # ... and by the Q rows on lane 2; the queries on lane 3 do not wait for it
             last = heads is not None and li == len(pk.layers) - 1
             # Launch order of a layer.  Lane 0 carries the bond chain (P -> triplet -> bond position update), lane 1 the node
             # chain (knn attention -> lin_node -> second first-layer GEMM -> knn position update), lane 2 the Q rows and the

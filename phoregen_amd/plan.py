@@ -134,7 +134,7 @@ class BatchPlan:
         its.sort(key=lambda r: -r[0])
         self.tri_iters = torch.tensor([[r[1], r[2], r[3], r[4]] for r in its], dtype=torch.int32).reshape(-1, 4).to(device)
         self.n_tri_iters = len(its) if (B and int(nlig.max()) - 1 <= rows_cap and int(nlig.max()) <= 96) else 0
-        self.tri_counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.tri_counter = torch.zeros(2, dtype=torch.int32, device=device)      # queue head + exit count; the kernel re-zeroes them
         for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
                      'bond_src', 'bond_dst', 'bond_desc', 'g_bond_off'):
             setattr(t, name, getattr(self, name).data_ptr())
