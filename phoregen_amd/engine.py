@@ -386,11 +386,6 @@ class Engine:
             # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~17 us)
             self._gemm(prog, w.aggE, 128, L.W_lin2[:, :128], w.lin_tmp, n, 128, bias=L.b_lin, add1=hc)
             self._gemm(prog, w.aggB, 128, L.W_lin2[:, 128:], hn, n, 128, add1=w.lin_tmp)
-            if last:                                   # lane 2 has nothing left in this step: the node head takes it
-                self._sync(prog, 2, (1,))
-                self._lane = 2
-                heads[1](hn)
-                self._lane = 1
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
             # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
             # only for ligand atoms
@@ -401,6 +396,13 @@ class Engine:
             else:
                 self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
             self._sync(prog, 0, (1,))                  # lane 0 continues after the triplet kernel AND Y2 (which implies lane 2)
+            if last:
+                # lane 2 has nothing left in this step: the node head takes it.  Forked from lane 0 (which has just seen h'), not
+                # from lane 1: a lane-2-waits-lane-1 edge after lane 1 waited on lane 2 crashes hipGraph capture (PG_GRAPH=1)
+                self._fork(prog, (2,))
+                self._lane = 2
+                heads[1](hn)
+                self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
             self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)

@@ -708,6 +708,8 @@ def test_engine_variants_agree(model):
     base = run()
     serial = run({'PG_STREAMS': '0'})
     assert all(torch.equal(a, b) for a, b in zip(base, serial))
+    replay = run({'PG_GRAPH': '1'})                   # hipGraph capture of the four-lane launch list
+    assert all(torch.equal(a, b) for a, b in zip(base, replay))
     with torch.no_grad():                             # the four-lane launch list is race-free: repeated runs give the same bits
         for _ in range(6):
             again = [o.cpu() for o in model(**dev_inp)[:3]]
