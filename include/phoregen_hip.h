@@ -147,6 +147,12 @@ int pg_edge_gate(const PgTopo* t, const float* x_ctx, const int* nbr, const int*
                  const float* W0, const float* b0, const float* gamma, const float* beta,
                  const float* W3, float b3, float* ew /*[n_ctx,k]*/, void* stream);
 
+/* optional, after pg_edge_gate: stable partition of every node's neighbour slots (and their gate values) by the kind of the source
+ * node, ligand atoms first.  The attention kernels sum over a node's rows, so the order is free; with it at most one 16-row tile
+ * per node mixes the two kinds and the uniform tiles skip the other kind's 20 distance columns (csrc/node_attn.hip). */
+int pg_knn_group_by_kind(const PgTopo* t, int k, int* nbr /*[n_ctx,k] in place*/, const int* deg, float* ew /*[n_ctx,k] in place*/,
+                         void* stream);
+
 /* per-bond Gaussian smearing of the bond length: G[e, 0:20] (uni_denoiser.py:128,137) */
 int pg_bond_smear(const PgTopo* t, const float* x_ctx, float* G /*[n_bond,20]*/, void* stream);
 

@@ -159,6 +159,24 @@ __global__ __launch_bounds__(256) void knn_ctx_kernel(PgTopo t, const float* x, 
   wave_knn(x, first, count, node, k, nbr + (size_t)node * k, deg + node);
 }
 
+// stable partition of every node's neighbour list by the source's kind (ligand atoms first), gate values moved along.  The knn
+// attention's 40 distance columns are 20 per kind (common.py outer product with the edge type): a row tile whose sources are all of
+// one kind skips the other kind's 5 MFMA k-steps (node_attn.hip), and after the partition at most one tile per node is mixed.
+// Attention sums over a node's rows, so the order is free (fp32 summation order only).
+__global__ __launch_bounds__(256) void knn_group_kernel(PgTopo t, int k, int* nbr, const int* deg, float* ew) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (node >= t.n_ctx) return;
+  const bool valid = lane < deg[node] && lane < k;
+  int v = 0;
+  float e = 0.f;
+  if (valid) { v = nbr[(size_t)node * k + lane]; e = ew[(size_t)node * k + lane]; }
+  const bool lig = valid && t.ctx_is_lig[v] != 0;
+  const unsigned long long ml = __ballot(lig), mv = __ballot(valid);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int pos = lig ? __popcll(ml & below) : __popcll(ml) + __popcll(mv & ~ml & below);
+  if (valid) { nbr[(size_t)node * k + pos] = v; ew[(size_t)node * k + pos] = e; }
+}
+
 // direction vectors (models/common.py:300-314)
 __global__ __launch_bounds__(256) void lig_normals_kernel(PgTopo t, const float* x, const float* phore_norm,
                                                           const int* phore2ctx, float* nrm) {
@@ -340,6 +358,13 @@ extern "C" int pg_knn_ctx(const PgTopo* t, const float* x_ctx, int k, int* nbr, 
   if (int rc = check_graph_size(t, "pg_knn_ctx")) return rc;
   hipLaunchKernelGGL(knn_ctx_kernel, dim3((t->n_ctx + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, x_ctx, k, nbr, deg);
   return check_launch("pg_knn_ctx");
+}
+
+extern "C" int pg_knn_group_by_kind(const PgTopo* t, int k, int* nbr, const int* deg, float* ew, void* stream) {
+  if (k < 1 || k > 64) { set_error("pg_knn_group_by_kind: k = %d out of range [1, 64]", k); return PG_ERR_ARG; }
+  if (t->n_ctx == 0) return PG_OK;
+  hipLaunchKernelGGL(knn_group_kernel, dim3((t->n_ctx + 3) / 4), dim3(256), 0, (hipStream_t)stream, *t, k, nbr, deg, ew);
+  return check_launch("pg_knn_group_by_kind");
 }
 
 extern "C" int pg_lig_normals(const PgTopo* t, const float* x_ctx, const float* phore_norm, const int* phore2ctx,

@@ -108,6 +108,9 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
     float feat[MAXT][NSTEP > 0 ? NSTEP : 1];
     f4 lg[MAXT];
     f4 vv[POS ? MAXT : 1];
+    // KNN: the 40 distance columns are 20 per source kind (feature steps 0-4 ligand sources, 5-9 pharmacophore sources); a tile
+    // without sources of a kind has zeros there and skips those MFMA steps (wave-uniform; pg_knn_group_by_kind makes most tiles so)
+    bool has_lig[MAXT], has_ph[MAXT];
 
     // ======================= pass A =======================
     {
@@ -168,6 +171,8 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
               feat[tile][st] = src_lig ? sv : 0.f;
               feat[tile][5 + st] = src_lig ? 0.f : sv;
             }
+            has_lig[tile] = __ballot(valid && src_lig) != 0ull;
+            has_ph[tile] = __ballot(valid && !src_lig) != 0ull;
             feat[tile][10] = g == 0 ? dots[0] : (g == 1 ? dots[1] : (g == 2 ? dots[2] : ((valid && src_lig) ? 1.f : 0.f)));
             feat[tile][11] = g == 0 ? ((valid && !src_lig) ? 1.f : 0.f) : (g == 3 ? 1.f : 0.f);
           }
@@ -184,13 +189,17 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             }
           }
 #pragma unroll
-          for (int st = 0; st < NSTEP; ++st)
+          for (int blk3 = 0; blk3 < (NSTEP ? 3 : 0); ++blk3) {
+            if ((blk3 == 0 && !has_lig[tile]) || (blk3 == 1 && !has_ph[tile])) continue;
 #pragma unroll
-            for (int tq = 0; tq < 8; ++tq) {
-              float w = wf_k[(st * 8 + tq) * 64 + lane];
-              if (st == 11) w = g == 3 ? ckp[16 * tq + m] : w;
-              hid[tq] = mfma16(w, feat[tile][st], hid[tq]);
-            }
+            for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
+#pragma unroll
+              for (int tq = 0; tq < 8; ++tq) {
+                float w = wf_k[(st * 8 + tq) * 64 + lane];
+                if (st == 11) w = g == 3 ? ckp[16 * tq + m] : w;
+                hid[tq] = mfma16(w, feat[tile][st], hid[tq]);
+              }
+          }
           const float rs = ln_fold_k(hid, bpk, g);
           f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -220,13 +229,17 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
               hx[tq] = c;
             }
 #pragma unroll
-            for (int st = 0; st < NSTEP; ++st)
+            for (int blk3 = 0; blk3 < (NSTEP ? 3 : 0); ++blk3) {
+              if ((blk3 == 0 && !has_lig[tile]) || (blk3 == 1 && !has_ph[tile])) continue;
 #pragma unroll
-              for (int tq = 0; tq < 8; ++tq) {
-                float w = wf_v[(st * 8 + tq) * 64 + lane];
-                if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
-                hx[tq] = mfma16(w, feat[tile][st], hx[tq]);
-              }
+              for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
+#pragma unroll
+                for (int tq = 0; tq < 8; ++tq) {
+                  float w = wf_v[(st * 8 + tq) * 64 + lane];
+                  if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
+                  hx[tq] = mfma16(w, feat[tile][st], hx[tq]);
+                }
+            }
             const float rsx = ln_fold_k(hx, bpv, g);
             f4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -336,13 +349,17 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int tq = 0; tq < 8; ++tq) hv[tq] += cvp[16 * tq + m];
           }
 #pragma unroll
-          for (int st = 0; st < NSTEP; ++st)
+          for (int blk3 = 0; blk3 < (NSTEP ? 3 : 0); ++blk3) {
+            if ((blk3 == 0 && !has_lig[tile]) || (blk3 == 1 && !has_ph[tile])) continue;
 #pragma unroll
-            for (int tq = 0; tq < 8; ++tq) {
-              float w = wf_v[(st * 8 + tq) * 64 + lane];
-              if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
-              hv[tq] = mfma16(feat[tile][st], w, hv[tq]);
-            }
+            for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
+#pragma unroll
+              for (int tq = 0; tq < 8; ++tq) {
+                float w = wf_v[(st * 8 + tq) * 64 + lane];
+                if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
+                hv[tq] = mfma16(feat[tile][st], w, hv[tq]);
+              }
+          }
           f4 q2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int tq = 0; tq < 8; ++tq) q2 += hv[tq] * hv[tq];

@@ -40,6 +40,7 @@ class Engine:
         self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
         self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
         self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
+        self.group_knn = os.environ.get('PG_KNN_GROUP', '1') != '0'            # neighbour slots partitioned by source kind
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -313,6 +314,8 @@ class Engine:
                    g['W0'].data_ptr(), g['b0'].data_ptr(), g['g'].data_ptr(), g['b'].data_ptr(), g['W3'].data_ptr(),
                    C.c_float(g['b3']), w.ew.data_ptr())
         self._mark(prog, 'graph', w.nbr, w.deg, w.ew, lane=1)
+        if self.group_knn:      # ligand-source rows first: uniform row tiles skip the other kind's distance columns (node_attn.hip)
+            self._call(prog, lib.pg_knn_group_by_kind, t, self.k, w.nbr.data_ptr(), w.deg.data_ptr(), w.ew.data_ptr())
         self._lane = 0
         cur = 0
         staged = bool(p.n_tri_iters and self.staged_triplet)

@@ -96,6 +96,7 @@ _PROTOS = {
     'pg_lig_nn3': (C.c_int, [C.POINTER(PgTopo), c_fp, c_ip, C.c_void_p]),
     'pg_edge_gate': (C.c_int, [C.POINTER(PgTopo), c_fp, c_ip, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
                                C.c_float, c_fp, C.c_void_p]),
+    'pg_knn_group_by_kind': (C.c_int, [C.POINTER(PgTopo), C.c_int, c_ip, c_ip, c_fp, C.c_void_p]),
     'pg_bond_smear': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, C.c_void_p]),
     'pg_seg_attn': (C.c_int, [C.POINTER(PgTopo), C.POINTER(PgSegAttn), C.c_void_p]),
     'pg_attn_fold_query': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_ip, c_fp, C.c_void_p]),
