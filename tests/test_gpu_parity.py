@@ -682,6 +682,40 @@ def test_full_size_batch_equals_single_graph_runs(model, oracle):
     assert all(torch.isfinite(o).all() for o in out)
 
 
+def test_knn_group_by_kind_is_a_stable_partition(model):
+    """pg_knn_group_by_kind: per node the valid neighbour slots become [ligand sources..., pharmacophore sources...], each kind
+    in its original (distance) order, the gate values move with their neighbours, slots past the degree are untouched."""
+    from phoregen_amd import hip
+    from phoregen_amd.plan import BatchPlan, make_edge_data
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(3)
+    na, nph = torch.tensor([5, 30, 1, 12]), torch.tensor([7, 20, 40, 3])
+    ei, be = make_edge_data(na)
+    B = na.numel()
+    plan = BatchPlan(torch.repeat_interleave(torch.arange(B), na), torch.repeat_interleave(torch.arange(B), nph), ei, be, B, DEV)
+    n, k = plan.n_ctx, 32
+    x = torch.randn(n, 3, generator=g).to(DEV)
+    nbr = torch.full((n, k), -7, dtype=torch.int32, device=DEV)
+    deg = torch.zeros(n, dtype=torch.int32, device=DEV)
+    hip.check(lib.pg_knn_ctx(plan.topo_ref, x.data_ptr(), k, nbr.data_ptr(), deg.data_ptr(), hip.stream_ptr()))
+    ew = torch.rand(n, k, generator=g).to(DEV)
+    nbr0, ew0 = nbr.clone(), ew.clone()
+    hip.check(lib.pg_knn_group_by_kind(plan.topo_ref, k, nbr.data_ptr(), deg.data_ptr(), ew.data_ptr(), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    is_lig = torch.zeros(n, dtype=torch.bool)
+    is_lig[plan.lig2ctx_long.cpu()] = True
+    nbr0, ew0, nbr1, ew1, deg_c = nbr0.cpu(), ew0.cpu(), nbr.cpu(), ew.cpu(), deg.cpu()
+    assert int(deg_c.max()) > 16 and int(deg_c.min()) < 32
+    for node in range(n):
+        d = int(deg_c[node])
+        src, gate = nbr0[node, :d], ew0[node, :d]
+        kind = is_lig[src.long()]
+        want = torch.cat([src[kind], src[~kind]])
+        assert torch.equal(nbr1[node, :d], want)
+        assert torch.equal(ew1[node, :d], torch.cat([gate[kind], gate[~kind]]))
+        assert torch.equal(nbr1[node, d:], nbr0[node, d:]) and torch.equal(ew1[node, d:], ew0[node, d:])
+
+
 def test_engine_variants_agree(model):
     """The measurement switches of the engine must not change results beyond fp32 summation order: one stream vs four lanes
     (bit-identical: same kernels, same order per kernel), node attention with separate fold / unfold launches, the gather triplet
