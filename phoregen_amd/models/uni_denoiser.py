@@ -110,5 +110,12 @@ class UniTransformerO2TwoUpdateGeneralBond(nn.Module):
                 return_all=False):
         """Same contract as uni_denoiser.py:396-430: ctx-ordered h [N,128], x [N,3], bond_index [2,E] in ctx
         indices, h_bond [E,128], masks, batch, phore_norm [N_phore,3] -> {'x','h','h_bond'}."""
+        if group_idx is not None:
+            # the reference appends two more edge-type columns then (uni_denoiser.py:386-393), which changes the first-layer widths
+            # of every knn MLP; both shipped configs pass None (diffusion.py:211)
+            raise NotImplementedError('phoregen_amd: group_idx must be None (edge_feat_dim=4 kernels; both shipped configs)')
+        if mask_ligand_atom is not None and mask_ligand_atom is not mask_ligand and \
+                not torch.equal(mask_ligand_atom.bool(), mask_ligand.bool()):
+            raise NotImplementedError('phoregen_amd: mask_ligand_atom must equal mask_ligand (diffusion.py:208-216 passes one mask)')
         from ..engine import denoiser_forward_standalone
         return denoiser_forward_standalone(self, h, x, bond_index, h_bond, mask_ligand, batch, phore_norm, return_all)

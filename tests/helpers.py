@@ -86,6 +86,35 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+# ---- conditioning floor of the recorded sampler steps (oracle/make_conditioning_floor.py; frozen, kernel-independent) ----
+FLOOR_MULT = 3.0       # fixed: |hip - reference| <= max(5 x TOL, FLOOR_MULT x floor); never retuned for a kernel
+_FLOOR = None
+
+
+def conditioning_floor(name, s):
+    """[v, x0, bond] ensemble floor of recorded step `s` of sampler fixture `name`: the largest distance of K = 12 fp32
+    evaluations of the reference's dataflow (atom / bond rows permuted, coordinates moved by <= 1 ulp) from the float64 result."""
+    global _FLOOR
+    if _FLOOR is None:
+        import json
+        with open(os.path.join(GOLDEN, 'conditioning_floor.json')) as f:
+            _FLOOR = json.load(f)
+    return _FLOOR['floor'][name][s]
+
+
+def record_parity_ratio(test, name, s, errs, floors, tol):
+    """Evidence trail (gpurun_out/ is scratch; the table judged is copied to profiles/): one JSON line per checked step."""
+    import json
+    d = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_ratios.jsonl'), 'a') as f:
+            f.write(json.dumps(dict(test=test, fixture=name, step=s, err=[float(e) for e in errs], floor=list(floors),
+                                    tol=[float(x) for x in tol])) + '\n')
+    except OSError:
+        pass
+
+
 class Oracle64:
     """The oracle's dataflow in float64 (same fp32-generated weights, exactly converted): the "exact" result against which
     the conditioning of a weight set is measured -- rel_err(oracle fp32, oracle fp64) is the error ANY fp32 implementation

@@ -89,6 +89,53 @@ def test_phore_encoder_is_callable_like_the_reference(model):
         model.denoiser.base_block[0].node_layer_with_bond(h_emb, dist, torch.stack([src, dst]))
 
 
+@pytest.mark.parametrize('name', ['g3_forward_a', 'g3_forward_b', 'g3_forward_a_gamma_signed', 'g3_forward_a_trained_like'])
+def test_denoiser_module_forward_is_callable_like_the_reference(name):
+    """uni_denoiser.py:396-430 through the plugin seam `models.get_denoiser_net(cfg)(h, x, group_idx, bond_index, h_bond,
+    mask_ligand, mask_ligand_atom, batch, phore_norm)` (SURVEY.md 8(b) "Denoiser module"): the reference's recorded inputs of
+    layer 0 in, its recorded outputs of layer 5 out (G3 fixtures, four weight profiles)."""
+    from phoregen_amd.config import default_model_config
+    from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.weights import init_deterministic_
+    prof = next((p for p in ('gamma_signed', 'trained_like') if name.endswith(p)), 'default')
+    m = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0, profile=prof).eval().to(DEV)
+    g = golden(name)
+    h, x, bi, hb, mask, batch, pn = (t(g['L0_in_' + k]).to(DEV) for k in ('h', 'x', 'bond_index', 'h_bond', 'mask_ligand', 'batch',
+                                                                          'phore_norm'))
+    with torch.no_grad():
+        out = m.denoiser(h, x, None, bi, hb, mask, mask, batch, phore_norm=pn, return_all=True)
+    assert set(out) == {'x', 'h', 'h_bond', 'all_x', 'all_h', 'all_h_bond'}
+    errs = {k: rel_err(out[k].cpu(), g['L5_out_' + k]) for k in ('h', 'h_bond', 'x')}
+    assert max(errs.values()) <= 2e-5, (name, errs)
+    assert torch.equal(out['all_h'][0], h) and torch.equal(out['all_x'][-1], out['x'])
+    # pharmacophore rows do not move (uni_denoiser.py:295-296)
+    assert torch.equal(out['x'][~mask], x[~mask])
+    # the reference grows the edge-type one-hot by two columns for a group index (:386-393): not silently ignored
+    with pytest.raises(NotImplementedError):
+        m.denoiser(h, x, torch.zeros_like(batch), bi, hb, mask, mask, batch, phore_norm=pn)
+    with pytest.raises(NotImplementedError):
+        m.denoiser(h, x, None, bi, hb, mask, ~mask, batch, phore_norm=pn)
+
+
+def test_sample_nodes_normal_mode(model):
+    """diffusion.py:356-387 with sample_mode='normal' (sample_utils.py:28-37: clamp(round(N(mid, std)), lo, hi))."""
+    from phoregen_amd.data import parse_phore_file
+    data = parse_phore_file(os.path.join(ROOT, 'tests', 'data', 'synthetic_test.phore')).to(DEV)
+    torch.manual_seed(7)
+    na = model.sample_nodes(data, 256, DEV, sample_mode='normal', normal_scale=4.0)
+    eng = model._count_engine
+    lo = int((eng.ws.count_l * 74 + 4).round().item())
+    hi = int((eng.ws.count_u * 74 + 4).round().item())
+    assert na.shape == (256,) and na.dtype == torch.int32 and int(na.min()) >= lo and int(na.max()) <= hi
+    # same generator state -> the reference's own draw: torch.normal(mid, std, (B,)) clamped and rounded
+    torch.manual_seed(7)
+    mid, std = (lo + hi) / 2, (hi - lo) / 4.0
+    ref = torch.normal(mid, std, (256,)).clamp(lo, hi).round().int()
+    assert torch.equal(na.cpu(), ref)
+    res = model.sample(data, 3, DEV, sample_mode='normal', normal_scale=4.0, num_steps=2)
+    assert int(res['lig_info'][0].min()) >= lo and int(res['lig_info'][0].max()) <= hi
+
+
 def test_trajectory_with_per_graph_centres(model):
     """Multi-pharmacophore batches (f-2) return trajectories: frame k of graph g = its ligand-frame state + centre g."""
     from oracle.make_inputs import synthetic_phore
