@@ -84,16 +84,26 @@ class SamplingJob:
         return torch.cat(xs), torch.cat(ps), torch.cat(ns), torch.cat(bp), self.num_atoms[gids], torch.cat(cs)
 
 
-def sample_job_shard(model, job, graph_ids, batch_size=128, seed=0, num_steps=None, pos_guidance_opt=None):
+def sample_job_shard(model, job, graph_ids, batch_size=128, seed=0, num_steps=None, pos_guidance_opt=None,
+                     guidance_norm='batch_size'):
     """Sample the graphs `graph_ids` (ascending) of `job` on this process's GPU in batches of <= batch_size.  Noise is keyed
-    by the GLOBAL graph id and the guidance energies are normalised by `batch_size`, so the result of a graph does not
-    depend on which shard or batch it lands in.  Returns pred = [logits_node, pos, logits_edge] in graph_ids order."""
+    by the GLOBAL graph id, so the result of a graph does not depend on which shard or batch it lands in.
+    guidance_norm: the guidance energies are means over the graphs of a call (sample_utils.py:135-165 divide by num_graphs).
+      'batch_size' (default, an INTENTIONAL deviation for partitioned jobs): every call divides by `batch_size`, also a shorter
+                   tail batch or a shard with fewer graphs -- the drift a graph feels is then the same in every partition of the
+                   job (sharded == unsharded, tests/test_gpu_sharding.py);
+      'actual'   : divide by the number of graphs in the call, as the reference's loop does for its last batch
+                   (sample_all.py:88: n = min(batch_size, remaining)) -- a tail-batch graph then gets the reference's stronger drift.
+    Returns pred = [logits_node, pos, logits_edge] in graph_ids order."""
+    if guidance_norm not in ('batch_size', 'actual'):
+        raise ValueError(f'guidance_norm={guidance_norm!r}')
     parts = ([], [], [])
     for b0 in range(0, int(graph_ids.numel()), batch_size):
         gids = graph_ids[b0:b0 + batch_size]
         hp, pp, pn, bp, na, centers = job.batch_inputs(gids)
         res = model.sample_batch(hp, pp, pn, bp, na, centers, pos_guidance_opt=pos_guidance_opt, rng='device', seed=seed,
-                                 return_traj=False, num_steps=num_steps, graph_ids=gids, guidance_batch=batch_size)
+                                 return_traj=False, num_steps=num_steps, graph_ids=gids,
+                                 guidance_batch=batch_size if guidance_norm == 'batch_size' else int(gids.numel()))
         for acc, t in zip(parts, res['pred']):
             acc.append(t)
     dev = next(model.parameters()).device
@@ -147,10 +157,15 @@ class GradientBuckets:
     is single-GPU).  Parameters are grouped into ~`bucket_mb` MB buckets in reverse registration order (roughly the order their
     gradients are produced); a `post_accumulate_grad` hook counts arrivals and, when a bucket is complete, packs it and starts
     an ASYNCHRONOUS all-reduce (RCCL runs it on its own stream: the collective of bucket k travels over xGMI while the
-    backward of the earlier layers is still computing).  `finish()` -- before `optimizer.step()` -- reduces whatever did not
-    fire (parameters without a gradient contribute zeros), waits, averages and writes the results back into `.grad`.
+    backward of the earlier layers is still computing).  Buckets are launched STRICTLY IN INDEX ORDER (bucket k only after
+    buckets 0..k-1), as DDP does: every rank then issues the same sequence of collectives even if its autograd order differs
+    (a parameter unused on one rank, a data-dependent branch) -- a bucket that completes early waits for its predecessors.
+    `finish()` -- before `optimizer.step()` -- launches whatever did not fire (parameters without a gradient contribute zeros),
+    waits, averages and writes the results back into `.grad`.  One backward per `finish()`: a second `backward()` before
+    `finish()` (gradient accumulation) would be dropped by the write-back, so it raises instead.
     A few-MB bucket is the size at which an xGMI ring (per-link bound, ~153 GB/s) is already bandwidth- rather than
-    latency-dominated; PhoreDiff's 20.8 MB of gradients make ~5 buckets."""
+    latency-dominated; PhoreDiff's 20.8 MB of gradients make ~5 buckets.  The collectives run whenever a process group is
+    initialised (a 1-rank `nccl` group included: tests/test_gpu_training.py drives the RCCL path that way on one GPU)."""
 
     def __init__(self, params, bucket_mb=4.0, group=None, average=True):
         self.group, self.average = group, average
@@ -168,30 +183,50 @@ class GradientBuckets:
         self.owner = {id(p): bi for bi, b in enumerate(self.buckets) for p in b}
         self.flat = [None] * len(self.buckets)
         self.work = [None] * len(self.buckets)
-        self.ready = [0] * len(self.buckets)
+        self.fired = [set() for _ in self.buckets]     # parameters whose gradient has arrived in this backward
+        # parameters a bucket does not wait for: those that produced no gradient in the previous step (an unused parameter would
+        # otherwise hold its bucket -- and, launches being in order, every later one -- back until finish())
+        self.absent = [set() for _ in self.buckets]
+        self.next_launch = 0                 # buckets [0, next_launch) have been launched
+        self.launch_log = []                 # (bucket, launched from a hook?) in launch order, per backward (tests)
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_available() and dist.is_initialized()
 
     def _on_grad(self, p):
         bi = self.owner[id(p)]
-        self.ready[bi] += 1
-        if self.ready[bi] == len(self.buckets[bi]) and self.work[bi] is None:
-            self._launch(bi)
+        if id(p) in self.fired[bi]:
+            raise RuntimeError('GradientBuckets: a parameter received a second gradient before finish() -- call finish() after '
+                               'every backward() (gradient accumulation over micro-batches is not supported by the hook path)')
+        if self.work[bi] is not None:
+            raise RuntimeError('GradientBuckets: a parameter that had no gradient in the previous step received one after its '
+                               'bucket was launched; call reset_absent() when the set of used parameters changes')
+        self.fired[bi].add(id(p))
+        while self.next_launch < len(self.buckets) and self._complete(self.next_launch):
+            self._launch(self.next_launch, True)
 
-    def _launch(self, bi):
+    def _complete(self, bi):
+        return len(self.fired[bi] | self.absent[bi]) == len(self.buckets[bi])
+
+    def reset_absent(self):
+        """Forget which parameters were unused in the previous step (every bucket waits for all of its parameters again)."""
+        self.absent = [set() for _ in self.buckets]
+
+    def _launch(self, bi, from_hook=False):
+        assert bi == self.next_launch and self.work[bi] is None
         b = self.buckets[bi]
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
         self.flat[bi] = flat
         self.work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self._active() else True
+        self.next_launch = bi + 1
+        self.launch_log.append((bi, from_hook))
 
     def finish(self):
         """Wait for every bucket (launching the ones whose hooks did not all fire) and write the reduced gradients back."""
         world = dist.get_world_size(self.group) if self._active() else 1
-        for bi, b in enumerate(self.buckets):
-            if self.work[bi] is None:
-                self._launch(bi)
+        while self.next_launch < len(self.buckets):
+            self._launch(self.next_launch)
         n_elems = 0
         for bi, b in enumerate(self.buckets):
             if self.work[bi] is not True:
@@ -208,7 +243,9 @@ class GradientBuckets:
                     p.grad.copy_(g)
                 off += p.numel()
             n_elems += off
-            self.flat[bi], self.work[bi], self.ready[bi] = None, None, 0
+            self.absent[bi] = {id(p) for p in b} - self.fired[bi]
+            self.flat[bi], self.work[bi], self.fired[bi] = None, None, set()
+        self.next_launch = 0
         return n_elems
 
     def remove(self):

@@ -100,3 +100,57 @@ def test_consecutive_sample_calls_draw_fresh_noise(model):
     assert torch.equal(a['traj'][1], c['traj'][1]) and torch.equal(a['pred'][0], c['pred'][0])
     # graphs of one call differ from each other as well
     assert not torch.equal(a['traj'][1][0][:9], a['traj'][1][0][9:18])
+
+
+def test_config4_full_batch_equals_single_graph_runs(model):
+    """BASELINE config 4 at its real batch size: ONE 128-graph batch of a config-4-shaped job -- 32 different pharmacophores
+    (p ~ N(80, 25^2), CpxPhore / DockPhore statistics) x 4 samples, n ~ N(40, 6^2) -- as `run_sampling_job` cuts them
+    (sample_all.py:69-175 serves such a job one pharmacophore at a time).  Size-independent properties: (1) the sampler's result
+    for a graph inside the 128-graph mixed batch equals that graph sampled alone (types bit-exact, coordinates <= 1e-6), which is
+    what makes any shard / batch cut of the job exact; (2) one forward of the whole batch == the same graphs alone, and one
+    of them against the oracle."""
+    import torch.nn.functional as F
+    from helpers import make_oracle, rel_err
+    from phoregen_amd.parallel import sample_job_shard
+    from phoregen_amd.plan import make_edge_data
+    job = _job(n_phores=32, samples=4, seed=17)
+    G = job.n_graphs
+    assert G == 128 and len({int(p[0].size(0)) for p in job.phores}) > 10          # really mixed pharmacophore sizes
+    steps = 4
+    whole = sample_job_shard(model, job, torch.arange(G), batch_size=128, seed=21, num_steps=steps)
+    n_off = torch.cat([torch.zeros(1, dtype=torch.long), job.num_atoms.cumsum(0)])
+    e_off = torch.cat([torch.zeros(1, dtype=torch.long), (job.num_atoms * (job.num_atoms - 1)).cumsum(0)])
+    for gi in (0, 41, 86, 127):
+        alone = sample_job_shard(model, job, torch.tensor([gi]), batch_size=128, seed=21, num_steps=steps)
+        sl_n, sl_e = slice(int(n_off[gi]), int(n_off[gi + 1])), slice(int(e_off[gi]), int(e_off[gi + 1]))
+        assert torch.equal(alone[0].argmax(-1), whole[0][sl_n].argmax(-1)) and torch.equal(alone[2].argmax(-1), whole[2][sl_e].argmax(-1))
+        assert float((alone[1] - whole[1][sl_n]).abs().max()) <= 1e-6 * max(1.0, float(whole[1].abs().max()))
+        assert float((alone[0] - whole[0][sl_n]).abs().max()) <= 1e-5 * float(whole[0].abs().max())
+    assert all(torch.isfinite(t).all() for t in whole)
+    # ---- one forward of the full mixed batch, graph slices against single-graph forwards and the oracle ----
+    hp, pp, pn, bp, na, _ = job.batch_inputs(torch.arange(G))
+    g = torch.Generator().manual_seed(23)
+    N = int(na.sum())
+    ei, be = make_edge_data(na)
+    inp = dict(h_node_pert=F.one_hot(torch.randint(0, 12, (N,), generator=g), 12).float(), pos_pert=3.0 * torch.randn(N, 3, generator=g),
+               batch_node=torch.repeat_interleave(torch.arange(G), na), h_edge_pert=F.one_hot(torch.randint(0, 6, (ei.size(1),), generator=g), 6).float(),
+               edge_index=ei, batch_edge=be, time_step=torch.randint(0, 1000, (G,), generator=g), h_phore=hp, pos_phore=pp,
+               phore_norm=pn, batch_phore=bp)
+    nph = torch.bincount(bp, minlength=G)
+    p_off = torch.cat([torch.zeros(1, dtype=torch.long), nph.cumsum(0)])
+    with torch.no_grad():
+        out = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in inp.items()})[:3]]
+        for gi in (3, 100):
+            n0, n1, e0, e1, p0, p1 = (int(v) for v in (n_off[gi], n_off[gi + 1], e_off[gi], e_off[gi + 1], p_off[gi], p_off[gi + 1]))
+            one = dict(h_node_pert=inp['h_node_pert'][n0:n1], pos_pert=inp['pos_pert'][n0:n1], batch_node=torch.zeros(n1 - n0, dtype=torch.long),
+                       h_edge_pert=inp['h_edge_pert'][e0:e1], edge_index=ei[:, e0:e1] - n0, batch_edge=torch.zeros(e1 - e0, dtype=torch.long),
+                       time_step=inp['time_step'][gi:gi + 1], h_phore=hp[p0:p1], pos_phore=pp[p0:p1], phore_norm=pn[p0:p1],
+                       batch_phore=torch.zeros(p1 - p0, dtype=torch.long))
+            alone = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in one.items()})[:3]]
+            assert rel_err(out[0][n0:n1], alone[0]) <= 1e-6 and rel_err(out[1][n0:n1], alone[1]) <= 1e-6
+            assert rel_err(out[2][e0:e1], alone[2]) <= 1e-6
+            if gi == 100:
+                torch.set_num_threads(8)
+                ref = make_oracle(0).forward(**one)
+                errs = [rel_err(alone[i], ref[i]) for i in range(3)]
+                assert max(errs) <= 2e-5, errs

@@ -276,3 +276,49 @@ def test_validation_pass_without_grad(model):
     assert not loss_ng.requires_grad and loss.requires_grad
     assert abs(loss_ng.item() - loss.item()) <= 1e-6 * abs(loss.item())
     assert info_ng['loss_edge'] == pytest.approx(info['loss_edge'], rel=1e-6)
+
+
+def test_gradient_buckets_over_rccl_one_rank(model):
+    """f-4 on the device (reference harness: run/run.py:160-311, `RunDdp`): a 1-rank `nccl` (= RCCL) process group on cuda:0,
+    `GradientBuckets` attached to the real model, `compute_loss().backward()` through the HIP adjoints, `finish()`.  The bucket
+    all-reduces are launched from the gradient hooks WHILE the backward runs (in bucket-index order), they go through RCCL on
+    device memory, and with one rank the reduced gradients must be the local ones bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from phoregen_amd.parallel import GradientBuckets
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    gb = None
+    try:
+        g = golden('g6_loss_a')
+        batch, draws = _batch(g), _draws(g)
+        model.train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        gb = GradientBuckets(params, bucket_mb=1.0)
+        assert len(gb.buckets) >= 4 and gb._active()
+        for it in range(2):
+            model.zero_grad(set_to_none=True)
+            gb.launch_log.clear()
+            loss, _ = model.compute_loss(batch, draws=draws)
+            loss.backward()
+            hooked = [b for b, h in gb.launch_log if h]
+            local = [p.grad.clone() if p.grad is not None else None for p in params]
+            n = gb.finish()
+            torch.cuda.synchronize()
+            assert [b for b, _ in gb.launch_log] == list(range(len(gb.buckets)))          # index order
+            assert n == sum(p.numel() for p in params)
+            for p, l in zip(params, local):
+                assert p.grad is not None and p.grad.is_cuda
+                assert torch.equal(p.grad, l if l is not None else torch.zeros_like(p))      # world size 1: sum / 1 == local
+            if it == 1:      # (step 0 learns which parameters never receive a gradient; from then on nothing waits for finish())
+                assert hooked == list(range(len(gb.buckets))), (hooked, len(gb.buckets))
+        assert abs(float(loss) - float(g['loss'])) <= 1e-4 * abs(float(g['loss']))
+    finally:
+        if gb is not None:
+            gb.remove()
+        dist.destroy_process_group()
+        model.zero_grad(set_to_none=True)

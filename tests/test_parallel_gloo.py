@@ -135,8 +135,24 @@ def _bucket_worker(rank, world, port, q):
             p.grad = None
         net(x).pow(2).sum().backward()
         local = [p.grad.numpy().copy() if p.grad is not None else None for p in params]
+        out_hooks_step2 = [h for _, h in gb.launch_log][-len(gb.buckets):]      # (step 2: the unused `extra` no longer holds bucket 0 back)
         n = gb.finish()
         out[it] = (local, [p.grad.numpy().copy() if p.grad is not None else None for p in params], n)      # numpy: plain pickles
+    # rank-dependent autograd graph: rank 1 skips the first Linear (its gradient hooks never fire there) -- the buckets must still
+    # be launched in the same (index) order on both ranks, early-complete buckets waiting for their predecessors
+    for p in params:
+        p.grad = None
+    gb.launch_log.clear()
+    assert out_hooks_step2 == [True] * len(gb.buckets), out_hooks_step2
+    if rank == 0:
+        net(x).pow(2).sum().backward()
+    else:
+        net[2:](torch.randn(16, 300, generator=torch.Generator().manual_seed(77))).pow(2).sum().backward()
+    local = [p.grad.numpy().copy() if p.grad is not None else None for p in params]
+    n = gb.finish()
+    out[2] = (local, [p.grad.numpy().copy() if p.grad is not None else None for p in params], n)
+    out['launch_order'] = [b for b, _ in gb.launch_log]
+    out['from_hook'] = [h for _, h in gb.launch_log]
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -152,7 +168,11 @@ def test_bucketed_hook_allreduce_world_size_2_gloo():
     res = dict(q.get(timeout=120) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
-    for it in range(2):
+    n_b = len(res[0]['launch_order'])
+    assert res[0]['launch_order'] == res[1]['launch_order'] == list(range(n_b)) and n_b >= 2
+    assert all(res[0]['from_hook'])     # rank 0: every bucket from a hook (the never-used parameter is known absent after step 1)
+    assert not all(res[1]['from_hook'])                                  # rank 1: the first Linear's bucket only in finish()
+    for it in range(3):
         l0, r0, n0 = res[0][it]
         l1, r1, n1 = res[1][it]
         import numpy as np
@@ -163,3 +183,27 @@ def test_bucketed_hook_allreduce_world_size_2_gloo():
             za = a if a is not None else np.zeros_like(ra)
             zb = b if b is not None else np.zeros_like(rb)
             assert np.allclose(ra, (za + zb) / 2, atol=1e-6) and np.array_equal(ra, rb)
+
+
+def test_bucket_hooks_refuse_a_second_backward_before_finish():
+    """Gradient accumulation over micro-batches would be silently dropped by finish()'s write-back: it raises instead."""
+    import pytest
+    from phoregen_amd.parallel import GradientBuckets
+    net = torch.nn.Linear(5, 3)
+    gb = GradientBuckets(net.parameters(), bucket_mb=0.001)
+    x = torch.randn(4, 5)
+    net(x).sum().backward()
+    with pytest.raises(RuntimeError, match='second gradient'):
+        net(x).sum().backward()
+    gb.remove()
+    # after finish() the next backward is fine, and without a process group the gradients are left as they are
+    net.zero_grad(set_to_none=True)
+    gb = GradientBuckets(net.parameters(), bucket_mb=0.001)
+    net(x).sum().backward()
+    g0 = net.weight.grad.clone()
+    gb.finish()
+    assert torch.equal(net.weight.grad, g0)
+    net.zero_grad(set_to_none=True)
+    net(x).sum().backward()
+    gb.finish()
+    assert [b for b, _ in gb.launch_log] == list(range(len(gb.buckets))) * 2
