@@ -6,9 +6,10 @@ config 3) on N MI355X GPUs.
 
 A "step" is one iteration of the reverse-diffusion loop (models/diffusion.py:432-517): denoiser forward + categorical
 posteriors + Gaussian posterior + trajectory write, on synthetic graphs of the LigPhore shape and deterministic
-random-init weights, inputs resident in HBM.  Graphs are independent, so each rank runs its own 128-graph batch
-(weak scaling, no collective inside the loop); the only collective is the final gather of `pred` over RCCL, exercised
-after the timed region.  Prints ONE JSON line on rank 0.
+random-init weights, inputs resident in HBM.  Graphs are independent: by default ONE 128-graph batch is partitioned over the
+N ranks by n^3 (strong scaling, the figure SURVEY.md 8(d) and the ">= 6x at 8 GPUs" target refer to; `--weak` gives every rank
+its own 128-graph batch instead), no collective inside the loop; the only collective is the final gather of `pred` over RCCL,
+exercised after the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -107,9 +108,10 @@ def algorithmic_counts(n_at, n_ph, knn=32, H=128):
     layer_b = 2 * 4 * (128 + 3) * n_all + 2 * 512 * e_bond + 16 * e_knn + 16 * e_bond + 20 * e_knn + 3.31e6
     step_b = 6 * layer_b + 4 * (81 * n_lig + 36 * e_bond)
     # what the triplet kernel actually executes after folding the second key/value layers:
-    # 112 MFMA 16x16x4 (2048 FLOP) per 16-row tile + per-segment fold/unfold (2 x 128x128 MACs) + Q (2 x 20x128 MACs)
+    # 112 MFMA 16x16x4 (2048 FLOP) per 16-row tile + per-segment fold/unfold (2 x 128x128 MACs).  (Q = Wg2 . smear(d_ji) is NOT
+    # computed in the staged kernel: it arrives as a row of a [E,20]x[20,256] GEMM, so its FLOPs are not this kernel's)
     tiles = int((triplet_tiles(n_at) * n_at * (n_at - 1)).sum())
-    tri_exec = tiles * 112 * 2048 + e_bond * (2 * 2 * H * H + 2 * 2 * 20 * H)
+    tri_exec = tiles * 112 * 2048 + e_bond * (2 * 2 * H * H)
     return dict(n_all=n_all, n_lig=n_lig, e_knn=e_knn, e_bond=e_bond, e3=e3, flops_step=6 * layer_f,
                 flops_triplet_kernel=tri_kernel, flops_triplet_executed=tri_exec, tri_tiles=tiles, bytes_step=step_b,
                 tri_useful_rows=e3, tri_padded_rows=16 * tiles)      # (e3 = n(n-1)(n-2) useful rows)

@@ -62,36 +62,9 @@ typedef struct {
                               * streaming kernel, which addresses the gathered rows with 32-bit byte offsets */
 } PgGemm;
 int pg_gemm(const PgGemm* p, void* stream);
-/* test / tuning hook (returns the old setting): 0 keeps the tall [h_bond | G] product on the tiled kernel instead of the
- * wave-specialised one, 2 sends the K = 128 bond-row products there as well */
-int pg_debug_gemm_specialised(int on);
-
-/* ---- fused dense layers over the bond rows ---------------------------------------------------------------
- * Every job is Y_j[e, 0:N] = [h_bond | G][e, k0:k0+K] . W_j[0:N, 0:K]^T + bias_j + add1_j[idx(e)] + add2_j[idx'(e)] for all
- * bond rows e, computed from ONE staging of the 128-row h_bond tile (csrc/bondrow.hip).  The last job may carry a second
- * layer (the triplet query MLP of models/common.py:99-119): Y2 = scale2 * (W2 . ReLU(LayerNorm_128(Y_first)) + b2), whose
- * hidden layer never leaves the chip.  Replaces the per-product pg_gemm launches over h_bond
- * (models/uni_denoiser.py:43-59 bond-node k/v first layers, :141-155 triplet k/v/q first layers, :190-201 bond-pos). */
-#define PG_BOND_MAX_JOBS 6
-typedef struct {
-  const float* W; int ldw;     /* [N, >= K] row-major weight rows                                                   */
-  int k0, K;                   /* contraction over columns k0 .. k0+K-1 of [h_bond (0..127) | G (128..147)], K even  */
-  int N;                       /* output columns                                                                     */
-  const float* bias;           /* [N] or NULL                                                                        */
-  const float* add1; int ld_add1; int idx1_is_b;   /* optional gathered row add: add1[idx(e), 0:N], idx = idx_b or idx_a */
-  const float* add2; int ld_add2; int idx2_is_b;
-  float* Y; int ldy;           /* [E, N] (unused when a second layer is given)                                       */
-  const float* ln_g; const float* ln_b; const float* W2; const float* b2;   /* second layer (NULL W2: none), W2 [N2,128] */
-  int N2; float scale2; float* Y2; int ldy2;
-} PgBondJob;
-typedef struct {
-  const float* hb; int ld_hb;  /* [E,128] bond features                                                              */
-  const float* G;              /* [E,20] bond-length smearing or NULL                                                */
-  const int* idx_a; const int* idx_b;   /* [E] gather indices (bond source / target ctx rows)                        */
-  int E; int n_jobs;
-  PgBondJob jobs[PG_BOND_MAX_JOBS];
-} PgBondRows;
-int pg_bond_rows(const PgBondRows* p, void* stream);
+/* test hook (returns the old setting): 0 keeps every product on the tiled kernel (csrc/gemm.hip) instead of the streaming one
+ * (csrc/gemm_stream.hip), so that the tests can hold the two against each other */
+int pg_debug_gemm_streaming(int on);
 
 /* ---- graph topology of one batch ------------------------------------------------------------
  * Built once per batch by the host mirror (phoregen_amd/plan.py); constant over the 1000 steps. */

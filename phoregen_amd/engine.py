@@ -100,11 +100,14 @@ class Engine:
         """Side lanes start after everything enqueued so far on lane 0."""
         if not self.multi_stream:
             return
+        evs = []                                    # one event per tap, created at the first run and re-recorded every step (a
+                                                    # wait refers to the record that precedes it, so re-use across steps is safe)
         def tap(streams):
-            ev = torch.cuda.Event()
-            ev.record(streams[0])
+            if not evs:
+                evs.append(torch.cuda.Event())
+            evs[0].record(streams[0])
             for l in lanes:
-                streams[l].wait_event(ev)
+                streams[l].wait_event(evs[0])
             return 0
         tap.__name__ = 'fork'
         prog.append((tap, None, -1))
@@ -113,9 +116,11 @@ class Engine:
         """Lane 0 continues after the side lanes have drained."""
         if not self.multi_stream:
             return
+        evs = []
         def tap(streams):
-            for l in lanes:
-                ev = torch.cuda.Event()
+            if not evs:
+                evs.extend(torch.cuda.Event() for _ in lanes)
+            for ev, l in zip(evs, lanes):
                 ev.record(streams[l])
                 streams[0].wait_event(ev)
             return 0
@@ -126,9 +131,11 @@ class Engine:
         """Lane `waiter` continues after everything enqueued SO FAR on the lanes `on` (a join of a point, not of the whole lane)."""
         if not self.multi_stream:
             return
+        evs = []
         def tap(streams):
-            for l in on:
-                ev = torch.cuda.Event()
+            if not evs:
+                evs.extend(torch.cuda.Event() for _ in on)
+            for ev, l in zip(evs, on):
                 ev.record(streams[l])
                 streams[waiter].wait_event(ev)
             return 0
@@ -507,6 +514,10 @@ def phore_encoder_standalone(module, h, edge_feat, edge_index, e_w=None):
     dev = h.device
     if dev.type != 'cuda':
         raise RuntimeError('phoregen_amd: NodeUpdateLayer.forward runs on the MI355X HIP path only (no CPU fallback)')
+    if torch.is_grad_enabled() and (h.requires_grad or edge_feat.requires_grad or any(p.requires_grad for p in module.parameters())):
+        # this entry runs the forward kernels only; inside compute_loss the encoder is differentiated by training.TrainForward
+        raise RuntimeError('phoregen_amd: NodeUpdateLayer.forward (standalone pharmacophore encoder) does not record gradients; '
+                           'call it under torch.no_grad(), or train through PhoreDiff.compute_loss')
     if e_w is not None or edge_feat.dim() != 2 or edge_feat.size(1) != 1:
         raise NotImplementedError('phoregen_amd: NodeUpdateLayer.forward is callable in the pharmacophore-encoder form '
                                   '(one scalar edge feature, no edge gate); inside the denoiser it is fused into the layer')

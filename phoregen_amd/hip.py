@@ -26,23 +26,6 @@ class PgGemm(C.Structure):
                 ('Y', c_fp), ('ldy', C.c_int), ('M', C.c_int), ('N', C.c_int), ('rows', c_ip), ('add_rows', C.c_int)]
 
 
-class PgBondJob(C.Structure):
-    _fields_ = [('W', c_fp), ('ldw', C.c_int), ('k0', C.c_int), ('K', C.c_int), ('N', C.c_int), ('bias', c_fp),
-                ('add1', c_fp), ('ld_add1', C.c_int), ('idx1_is_b', C.c_int),
-                ('add2', c_fp), ('ld_add2', C.c_int), ('idx2_is_b', C.c_int),
-                ('Y', c_fp), ('ldy', C.c_int),
-                ('ln_g', c_fp), ('ln_b', c_fp), ('W2', c_fp), ('b2', c_fp),
-                ('N2', C.c_int), ('scale2', C.c_float), ('Y2', c_fp), ('ldy2', C.c_int)]
-
-
-PG_BOND_MAX_JOBS = 6
-
-
-class PgBondRows(C.Structure):
-    _fields_ = [('hb', c_fp), ('ld_hb', C.c_int), ('G', c_fp), ('idx_a', c_ip), ('idx_b', c_ip), ('E', C.c_int),
-                ('n_jobs', C.c_int), ('jobs', PgBondJob * PG_BOND_MAX_JOBS)]
-
-
 class PgTopo(C.Structure):
     _fields_ = [('n_graphs', C.c_int), ('n_ctx', C.c_int), ('n_lig', C.c_int), ('n_phore', C.c_int),
                 ('n_bond', C.c_int), ('max_nlig', C.c_int), ('max_gctx', C.c_int),
@@ -87,8 +70,7 @@ _PROTOS = {
     'pg_selftest_philox': (C.c_int, [c_ip, C.c_int, c_ip, C.c_void_p]),
     'pg_debug_force_generic_seg': (C.c_int, [C.c_int]),
     'pg_gemm': (C.c_int, [C.POINTER(PgGemm), C.c_void_p]),
-    'pg_bond_rows': (C.c_int, [C.POINTER(PgBondRows), C.c_void_p]),
-    'pg_debug_gemm_specialised': (C.c_int, [C.c_int]),
+    'pg_debug_gemm_streaming': (C.c_int, [C.c_int]),
     'pg_embed_ctx': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 11 + [C.c_void_p]),
     'pg_embed_bond': (C.c_int, [C.POINTER(PgTopo)] + [c_fp] * 7 + [C.c_void_p]),
     'pg_knn_ctx': (C.c_int, [C.POINTER(PgTopo), c_fp, C.c_int, c_ip, c_ip, C.c_void_p]),

@@ -127,7 +127,7 @@ def test_gemm_streaming_kernel_against_torch(M, N, gather, bias, K1, K2):
     Xd, X2d, Wd, bd, Ad, id_ = (v.to(DEV) for v in (X, X2, W, b, A, idx))
     outs = []
     for mode in (1, 0):                                   # streaming kernel, then the tiled kernel
-        old = lib.pg_debug_gemm_specialised(mode)
+        old = lib.pg_debug_gemm_streaming(mode)
         try:
             Yfull = torch.full((M, N + 64), float('nan'), device=DEV)
             Y = Yfull[:, 32:32 + N]
@@ -144,7 +144,7 @@ def test_gemm_streaming_kernel_against_torch(M, N, gather, bias, K1, K2):
             hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
             torch.cuda.synchronize()
         finally:
-            lib.pg_debug_gemm_specialised(old)
+            lib.pg_debug_gemm_streaming(old)
         assert torch.isnan(Yfull[:, :32]).all() and torch.isnan(Yfull[:, 32 + N:]).all()      # nothing outside the view
         assert rel_err(Y.cpu(), ref) < 1e-5, mode
         outs.append(Y.cpu())
@@ -169,7 +169,7 @@ def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
     for ref, ln in ((ref_ln, True), (ref_add, False), (ref_ssp, 'ssp')):
         outs = []
         for mode in (1, 0):
-            old = lib.pg_debug_gemm_specialised(mode)
+            old = lib.pg_debug_gemm_streaming(mode)
             try:
                 Y = torch.full((M, 128), float('nan'), device=DEV)
                 p = hip.PgGemm()
@@ -186,7 +186,7 @@ def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
                 hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
                 torch.cuda.synchronize()
             finally:
-                lib.pg_debug_gemm_specialised(old)
+                lib.pg_debug_gemm_streaming(old)
             assert rel_err(Y.cpu(), ref) < 1e-5, (ln, mode)
             outs.append(Y.cpu())
         assert rel_err(outs[0], outs[1].double()) < 2e-6
@@ -240,51 +240,6 @@ def test_rows_linear_against_torch(M, n_out, K, gather):
     torch.cuda.synchronize()
     assert torch.isnan(Y[:, n_out:]).all()
     assert rel_err(Y[:, :n_out].cpu(), ref) < 1e-5
-
-
-@pytest.mark.parametrize('E', [1000, 128 * 7, 33])
-def test_bond_rows_fused_against_torch(E):
-    """pg_bond_rows (csrc/bondrow.hip): four jobs over one staging of the h_bond tile -- plain, two gathered adds with the
-    [h_bond | G] contraction, the G-only contraction, and the two-layer query MLP -- against float64 torch."""
-    from phoregen_amd import hip
-    lib = hip.lib()
-    g = torch.Generator().manual_seed(E)
-    hb, G = torch.randn(E, 128, generator=g), torch.rand(E, 20, generator=g)
-    nodes = torch.randn(57, 1920, generator=g)
-    ia = torch.randint(0, 57, (E,), generator=g, dtype=torch.int32)
-    ib = torch.randint(0, 57, (E,), generator=g, dtype=torch.int32)
-    W1, W2, W3, W4 = (torch.randn(n, k, generator=g) * 0.1 for n, k in ((256, 128), (256, 148), (256, 20), (128, 128)))
-    bias = torch.randn(256, generator=g)
-    lg, lb, W5, b5 = torch.randn(128, generator=g), torch.randn(128, generator=g), torch.randn(128, 128, generator=g) * 0.1, torch.randn(128, generator=g)
-    d = lambda t_: t_.to(DEV).contiguous()
-    hb_d, G_d, nodes_d, ia_d, ib_d = d(hb), d(G), d(nodes), d(ia), d(ib)
-    W1d, W2d, W3d, W4d, W5d, bias_d, lg_d, lb_d, b5_d = (d(x) for x in (W1, W2, W3, W4, W5, bias, lg, lb, b5))
-    Y1, Y2, Y3, Y4 = (torch.full((E, n), float('nan'), device=DEV) for n in (256, 256, 256, 128))
-    b = hip.PgBondRows()
-    b.hb, b.ld_hb, b.G, b.idx_a, b.idx_b, b.E, b.n_jobs = hb_d.data_ptr(), 128, G_d.data_ptr(), ia_d.data_ptr(), ib_d.data_ptr(), E, 4
-    j = b.jobs[0]
-    j.W, j.ldw, j.k0, j.K, j.N, j.bias, j.Y, j.ldy = W1d.data_ptr(), 128, 0, 128, 256, bias_d.data_ptr(), Y1.data_ptr(), 256
-    j = b.jobs[1]
-    j.W, j.ldw, j.k0, j.K, j.N, j.Y, j.ldy = W2d.data_ptr(), 148, 0, 148, 256, Y2.data_ptr(), 256
-    j.add1, j.ld_add1, j.idx1_is_b = nodes_d.data_ptr(), 1920, 0
-    j.add2, j.ld_add2, j.idx2_is_b = nodes_d[:, 256:].data_ptr(), 1920, 1
-    j = b.jobs[2]
-    j.W, j.ldw, j.k0, j.K, j.N, j.Y, j.ldy = W3d.data_ptr(), 20, 128, 20, 256, Y3.data_ptr(), 256
-    j = b.jobs[3]
-    j.W, j.ldw, j.k0, j.K, j.N = W4d.data_ptr(), 128, 0, 128, 128
-    j.add1, j.ld_add1, j.idx1_is_b = nodes_d[:, 512:].data_ptr(), 1920, 1
-    j.ln_g, j.ln_b, j.W2, j.b2, j.N2, j.scale2, j.Y2, j.ldy2 = lg_d.data_ptr(), lb_d.data_ptr(), W5d.data_ptr(), b5_d.data_ptr(), 128, 0.37, Y4.data_ptr(), 128
-    hip.check(lib.pg_bond_rows(C.byref(b), hip.stream_ptr()), 'pg_bond_rows')
-    torch.cuda.synchronize()
-    D = lambda x: x.double()
-    r1 = D(hb) @ D(W1).t() + D(bias)
-    r2 = torch.cat([D(hb), D(G)], 1) @ D(W2).t() + D(nodes)[ia.long(), :256] + D(nodes)[ib.long(), 256:512]
-    r3 = D(G) @ D(W3).t()
-    hid = D(hb) @ D(W4).t() + D(nodes)[ib.long(), 512:640]
-    r4 = 0.37 * (torch.relu(torch.nn.functional.layer_norm(hid, (128,), D(lg), D(lb))) @ D(W5).t() + D(b5))
-    for got, ref in ((Y1, r1), (Y2, r2), (Y3, r3), (Y4, r4)):
-        assert torch.isfinite(got).all()
-        assert rel_err(got.cpu(), ref) < 1e-5
 
 
 def _fwd_inputs(g):
@@ -731,7 +686,7 @@ def test_engine_variants_agree(model):
     def run(env=None, gemm_mode=None):
         old_env = {k: os.environ.get(k) for k in (env or {})}
         os.environ.update(env or {})
-        old_mode = hip.lib().pg_debug_gemm_specialised(gemm_mode) if gemm_mode is not None else None
+        old_mode = hip.lib().pg_debug_gemm_streaming(gemm_mode) if gemm_mode is not None else None
         try:
             model._engine = None                      # the switches are read when an Engine is built
             with torch.no_grad():
@@ -740,7 +695,7 @@ def test_engine_variants_agree(model):
             for k, v in old_env.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             if old_mode is not None:
-                hip.lib().pg_debug_gemm_specialised(old_mode)
+                hip.lib().pg_debug_gemm_streaming(old_mode)
             model._engine = None
     base = run()
     serial = run({'PG_STREAMS': '0'})

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 from phoregen_amd import hip
 lib = hip.lib()
-lib.pg_debug_gemm_specialised(int(os.environ.get('PG_GEMM_SP', '1')))
+lib.pg_debug_gemm_streaming(int(os.environ.get('PG_GEMM_SP', '1')))
 dev = 'cuda'
 def run(M, N, K1, K2=0, ln=False, gather=0, act=0, reps=10, ldx=None):
     ldx = ldx or K1

@@ -40,6 +40,8 @@ def main(argv=None):
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--n-mean', type=float, default=25.0, help='mean ligand size (config 5: 25; the sampler headline shape: 40)')
     ap.add_argument('--n-max', type=int, default=60)
+    ap.add_argument('--buckets', action='store_true', help='one GPU: also time the step with GradientBuckets attached and a 1-rank '
+                    'nccl (RCCL) process group, i.e. the hook-launched bucket all-reduces of the data-parallel path (f-4)')
     a = ap.parse_args(argv)
     from phoregen_amd.config import default_model_config
     from phoregen_amd.models.diffusion import PhoreDiff
@@ -59,6 +61,7 @@ def main(argv=None):
     # data parallel: ~4 MB gradient buckets, all-reduced asynchronously from gradient hooks while the backward continues
     buckets = GradientBuckets(model.parameters(), bucket_mb=4.0) if world > 1 else None
     torch.manual_seed(0)
+    ms_plain = None
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -76,6 +79,21 @@ def main(argv=None):
         info = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    if a.buckets and world == 1:      # the same step again with the bucketed all-reduce path on a 1-rank RCCL group
+        ms_plain = ms
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1)
+        buckets = GradientBuckets(model.parameters(), bucket_mb=4.0)
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            info = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / a.steps
+        hooked = sum(1 for _, h in buckets.launch_log[-len(buckets.buckets):] if h)
+        dist.destroy_process_group()
     if world > 1:
         tmax = torch.tensor([ms], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -88,6 +106,8 @@ def main(argv=None):
                       'higher_is_better': False, 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'dtype': 'f32',
                       'data': 'synthetic', 'config': {'workload': 'BASELINE.json configs[4] shape: %d synthetic ligand-phore pairs, n~N(%g,%g) clamp [8,%d]' % (a.graphs, a.n_mean, a.n_mean / 5.0, a.n_max),
                                                       'graphs': a.graphs, 'n_lig': int(na.sum()), 'e_bond': e_bond, 'e3': e3},
+                      **({'ms_without_buckets': ms_plain, 'buckets': len(buckets.buckets), 'buckets_launched_from_hooks': hooked,
+                          'note': 'value = with GradientBuckets on a 1-rank nccl group'} if ms_plain is not None else {}),
                       'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30, 'last_loss': info['loss']}))
 
 

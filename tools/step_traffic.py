@@ -18,6 +18,8 @@ for name in set(tot['FETCH_SIZE']) | set(tot['WRITE_SIZE']):
     wr = tot['WRITE_SIZE'][name] * 1024 / steps / 1e9
     rows.append((rd + wr, name, calls[name] / steps, rd, wr))
 rows.sort(reverse=True)
+if not rows:
+    sys.exit(f'step_traffic: no counter_collection.csv rows under {root} (did rocprofv3 run?)')
 print(f'# HBM-side traffic per sampler step by kernel (PG_STREAMS=0, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, '
       f'{steps} steps; FETCH_SIZE KiB x2, WRITE_SIZE KiB x1)\n')
 print('| kernel | launches/step | read GB/step | write GB/step | total GB/step |\n|---|---|---|---|---|')
