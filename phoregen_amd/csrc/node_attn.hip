@@ -77,8 +77,19 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
   }
   __syncthreads();
 
-  const int n_waves = gridDim.x * (THREADS / 64);
-  for (int si = blockIdx.x * (THREADS / 64) + wave; si < p.n_seg; si += n_waves) {
+  // Node hand-out.  Fused (persistent) form: XCD-affine -- the node list (graph after graph) is cut into chunks of one node per wave,
+  // the chunk range into 8 contiguous parts, and part x is served by the workgroups with blockIdx % 8 == x, which the dispatcher
+  // places on one XCD (MI355X_MICROARCH.md, "Workgroup dispatch": a speed assumption only).  A graph's first-layer rows (the
+  // Csrc blocks every one of its ~150 nodes gathers 32 of) are then pulled through ONE L2 instead of all eight.
+  constexpr int PER = THREADS / 64;
+  const int n_chunks = (p.n_seg + PER - 1) / PER;
+  const int n_x = FUSED ? ((int)gridDim.x < 8 ? (int)gridDim.x : 8) : 1;
+  const int xcd = FUSED ? (int)blockIdx.x % n_x : 0, jx = FUSED ? (int)blockIdx.x / n_x : (int)blockIdx.x;
+  const int n_jx = FUSED ? ((int)gridDim.x - xcd + n_x - 1) / n_x : (int)gridDim.x;
+  const int c_lo = (int)((long long)n_chunks * xcd / n_x), c_hi = (int)((long long)n_chunks * (xcd + 1) / n_x);
+  for (int ch = c_lo + jx; ch < c_hi; ch += n_jx) {
+    const int si = ch * PER + wave;
+    if (si >= p.n_seg) continue;
     const int seg = p.seg_ids ? p.seg_ids[si] : si;        // target ctx node
     int n_rows, lig0 = 0, n = 0, li = 0;
     const int* eid_g = nullptr;

@@ -165,7 +165,9 @@ def test_out_of_memory_surfaces_with_the_reference_message_contract(model):
     from phoregen_amd.data import PhoreGraph
     x, pos, norm = synthetic_phore(torch.Generator().manual_seed(3), 40)
     data = PhoreGraph(x, pos, norm, torch.zeros(3)).to(DEV)
-    torch.cuda.empty_cache()
+    import gc
+    gc.collect()                 # engines of earlier tests sit in reference cycles (launch-list closures): without this their
+    torch.cuda.empty_cache()     # workspaces would be collected DURING sample() and satisfy its allocations from the cache
     free, _total = torch.cuda.mem_get_info()
     hog = torch.empty(max(free - (48 << 20), 0), dtype=torch.uint8, device=DEV)       # leave 48 MB
     try:
