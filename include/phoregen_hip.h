@@ -62,9 +62,8 @@ typedef struct {
                               * streaming kernel, which addresses the gathered rows with 32-bit byte offsets */
 } PgGemm;
 int pg_gemm(const PgGemm* p, void* stream);
-/* test hook (returns the old setting): 0 keeps every product on the tiled kernel (csrc/gemm.hip), 2 keeps the K = 128 products on
- * the fp32-MFMA streaming kernel (csrc/gemm_stream.hip) instead of the split-bf16 one (csrc/gemm_emu.hip); 1 = default.  The tests
- * hold the three against each other */
+/* test hook (returns the old setting): 0 keeps every product on the tiled kernel (csrc/gemm.hip) instead of the streaming one
+ * (csrc/gemm_stream.hip), so that the tests can hold the two against each other */
 int pg_debug_gemm_streaming(int on);
 
 /* ---- graph topology of one batch ------------------------------------------------------------

@@ -256,14 +256,12 @@ __global__ __launch_bounds__(256) void rows_linear_mfma_kernel(const float* X, i
 
 }  // namespace pg
 
-namespace pg {   // gemm_stream.hip, gemm_emu.hip
+namespace pg {   // gemm_stream.hip
 bool gemm_stream_eligible(const PgGemm* p);
 int launch_gemm_stream(const PgGemm* p, hipStream_t st);
-bool gemm_emu_eligible(const PgGemm* p);
-int launch_gemm_emu(const PgGemm* p, hipStream_t st);
 }
 
-static int g_gemm_stream = 1;      // 0: tiled kernel only; 1: default; 2: fp32-MFMA streaming kernel, no split-bf16 kernel (tests: the kernels against each other)
+static int g_gemm_stream = 1;      // 0: tiled kernel only (tests: the two kernels against each other)
 extern "C" int pg_debug_gemm_streaming(int on) { const int old = g_gemm_stream; g_gemm_stream = on; return old; }
 
 extern "C" int pg_gemm(const PgGemm* p, void* stream) {
@@ -273,11 +271,7 @@ extern "C" int pg_gemm(const PgGemm* p, void* stream) {
   if (p->ln_gamma && (p->K2 != 0 || p->K1 != 128 || (p->ldx & 3) || ((size_t)p->X & 15))) { pg::set_error("pg_gemm: LayerNorm-on-load needs K1 == 128, K2 == 0, 16-byte aligned rows"); return PG_ERR_ARG; }
   // K = 128 (+ 20) / K = 20 products with a plain epilogue or LayerNorm-on-load: the streaming kernel (LDS-DMA tiles, no vector-ALU
   // work on the memory path; gemm_stream.hip); everything else (row subsets, odd K, two gathered operands): the tiled kernel
-  if (g_gemm_stream && pg::gemm_stream_eligible(p)) {
-    // K = 128 (+ 20): fp32 operands split exactly into three bf16 parts, six partial products on the bf16 matrix pipe (gemm_emu.hip)
-    if (g_gemm_stream == 1 && pg::gemm_emu_eligible(p)) return pg::launch_gemm_emu(p, (hipStream_t)stream);
-    return pg::launch_gemm_stream(p, (hipStream_t)stream);
-  }
+  if (g_gemm_stream && pg::gemm_stream_eligible(p)) return pg::launch_gemm_stream(p, (hipStream_t)stream);
   const int row_blocks = (p->M + pg::BM - 1) / pg::BM;
   dim3 grid((p->N + pg::BN - 1) / pg::BN, row_blocks < 65535 ? row_blocks : 65535);
   hipLaunchKernelGGL(pg::gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *p PG_ABL_ARG("PG_GEMM_ABLATE"));

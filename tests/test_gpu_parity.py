@@ -126,7 +126,7 @@ def test_gemm_streaming_kernel_against_torch(M, N, gather, bias, K1, K2):
         ref = ref + A.double()[idx.long(), 256:256 + N]
     Xd, X2d, Wd, bd, Ad, id_ = (v.to(DEV) for v in (X, X2, W, b, A, idx))
     outs = []
-    for mode in (1, 2, 0):                                # split-bf16 kernel (K1 = 128) / streaming kernel, fp32 streaming kernel, tiled kernel
+    for mode in (1, 0):                                   # streaming kernel, then the tiled kernel
         old = lib.pg_debug_gemm_streaming(mode)
         try:
             Yfull = torch.full((M, N + 64), float('nan'), device=DEV)
@@ -148,7 +148,7 @@ def test_gemm_streaming_kernel_against_torch(M, N, gather, bias, K1, K2):
         assert torch.isnan(Yfull[:, :32]).all() and torch.isnan(Yfull[:, 32 + N:]).all()      # nothing outside the view
         assert rel_err(Y.cpu(), ref) < 1e-5, mode
         outs.append(Y.cpu())
-    assert rel_err(outs[0], outs[2].double()) < 2e-6 and rel_err(outs[1], outs[2].double()) < 2e-6
+    assert rel_err(outs[0], outs[1].double()) < 2e-6
 
 
 @pytest.mark.parametrize('M', [64, 1000, 23288])
@@ -168,7 +168,7 @@ def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
     Xd, Wd, bd, gd, btd, Ad = (v.to(DEV) for v in (X, W, b, gam, bet, A))
     for ref, ln in ((ref_ln, True), (ref_add, False), (ref_ssp, 'ssp')):
         outs = []
-        for mode in (1, 2, 0):
+        for mode in (1, 0):
             old = lib.pg_debug_gemm_streaming(mode)
             try:
                 Y = torch.full((M, 128), float('nan'), device=DEV)
@@ -189,43 +189,7 @@ def test_gemm_streaming_kernel_layernorm_and_plain_add(M):
                 lib.pg_debug_gemm_streaming(old)
             assert rel_err(Y.cpu(), ref) < 1e-5, (ln, mode)
             outs.append(Y.cpu())
-        assert rel_err(outs[0], outs[2].double()) < 2e-6 and rel_err(outs[1], outs[2].double()) < 2e-6
-
-
-@pytest.mark.parametrize('scale_spread', [0, 12, 30])
-def test_gemm_split_bf16_kernel_is_fp32_grade(scale_spread):
-    """csrc/gemm_emu.hip: every fp32 operand split exactly into three bf16 numbers, the six leading partial products accumulated
-    in fp32 on the bf16 matrix pipe.  Claim: an fp32 GEMM in every respect but the summation order.  Checked element-wise against
-    float64 on operands with full 24-bit significands and magnitudes spread over 2^-spread..2^spread per column of k: the error of
-    every output element, relative to sum_k |x_k w_k| (the quantity fp32 rounding errors scale with), stays below 2^-21 -- and
-    within 2 x of what the fp32-MFMA kernel (exact fmaf chain) shows on the same data."""
-    from phoregen_amd import hip
-    lib = hip.lib()
-    M, N = 4096 + 37, 256
-    g = torch.Generator().manual_seed(scale_spread + 1)
-    ex = (torch.rand(128, generator=g) * 2 - 1) * scale_spread
-    X = torch.randn(M, 128, generator=g) * torch.exp2(ex)
-    W = torch.randn(N, 128, generator=g) * torch.exp2(-ex) * torch.exp2((torch.rand(N, 1, generator=g) * 2 - 1) * 8)
-    ref = X.double() @ W.double().t()
-    mag = X.double().abs() @ W.double().abs().t()
-    Xd, Wd = X.to(DEV), W.to(DEV)
-    errs = {}
-    for mode in (1, 2):
-        old = lib.pg_debug_gemm_streaming(mode)
-        try:
-            Y = torch.full((M, N), float('nan'), device=DEV)
-            p = hip.PgGemm()
-            p.X, p.ldx, p.K1 = Xd.data_ptr(), 128, 128
-            p.W, p.ldw = Wd.data_ptr(), 128
-            p.out_scale, p.act = 1.0, hip.ACT_NONE
-            p.Y, p.ldy, p.M, p.N = Y.data_ptr(), N, M, N
-            hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
-            torch.cuda.synchronize()
-        finally:
-            lib.pg_debug_gemm_streaming(old)
-        errs[mode] = float(((Y.cpu().double() - ref).abs() / mag).max())
-    assert errs[1] <= 2.0 ** -21, errs
-    assert errs[1] <= 2.0 * errs[2] + 2.0 ** -24, errs
+        assert rel_err(outs[0], outs[1].double()) < 2e-6
 
 
 @pytest.mark.parametrize('ln', [True, False])

@@ -89,35 +89,6 @@ def test_streaming_gemm_isa_keeps_its_counted_wait_valid(tmp_path):
             assert len(re.findall(r's_waitcnt vmcnt\(32\)\n\ts_barrier', body)) == 2, lines[i]
 
 
-def test_split_bf16_gemm_isa_keeps_its_counted_wait_valid(tmp_path):
-    """csrc/gemm_emu.hip retires its LDS-DMA with `s_waitcnt vmcnt(32)` as well: every tile body must carry exactly 32 result stores
-    (the only vector-memory operations younger than the DMA that may still be in flight at the next tile's top), 96 bf16 MFMAs
-    (2 row blocks x 8 chunks x 6 partial products), 8 DMA pieces per tile and no scratch."""
-    import shutil, subprocess
-    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    if not os.path.exists(hipcc):
-        pytest.skip('no hipcc')
-    out = tmp_path / 'ge.s'
-    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=on', '--cuda-device-only', '-S',
-                    os.path.join(ROOT, 'phoregen_amd', 'csrc', 'gemm_emu.hip'), '-o', str(out)], check=True,
-                   stderr=subprocess.DEVNULL)
-    lines = out.read_text().split('\n')
-    starts = [i for i, l in enumerate(lines) if re.match(r'_ZN2pg15gemm_emu_kernelI.*PgGemmi:', l)]
-    assert len(starts) == 8
-    for i in starts:
-        end = next(j for j in range(i, len(lines)) if 's_endpgm' in lines[j])
-        scratch = next(l for l in lines[end:] if '; ScratchSize:' in l)
-        body = '\n'.join(lines[i:end])
-        assert scratch.split(':')[1].strip() == '0', (lines[i], scratch)
-        stores = len(re.findall(r'buffer_store_dword ', body))
-        bodies = stores // 32                                   # (the compiler may peel the first tile)
-        assert stores == 32 * bodies and bodies in (1, 2), (lines[i], stores)
-        assert len(re.findall(r'v_mfma_f32_32x32x16_bf16', body)) == 96 * bodies, lines[i]
-        assert len(re.findall(r'buffer_load_dwordx4 .* lds', body)) == 8 * (bodies + 1), lines[i]
-        assert len(re.findall(r's_waitcnt vmcnt\(32\)\n\ts_barrier', body)) == 1 and \
-            len(re.findall(r's_waitcnt vmcnt\(0\)\n\ts_barrier', body)) == 1, lines[i]
-
-
 def test_product_never_imports_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, 'phoregen_amd')):
