@@ -91,6 +91,10 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
     const int si = ch * PER + wave;
     if (si >= p.n_seg) continue;
     const int seg = p.seg_ids ? p.seg_ids[si] : si;        // target ctx node
+    // opaque copy of the lane id: LDS weight reads addressed through it are not loop-invariant, so the compiler cannot hoist them
+    // out of the node loop into registers it then has to spill (the fused knn form carried 70 spilled registers that way)
+    int lw = lane;
+    asm volatile("" : "+v"(lw));
     int n_rows, lig0 = 0, n = 0, li = 0;
     const int* eid_g = nullptr;
     if constexpr (KNN) {
@@ -134,8 +138,8 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = tq * 4 + r;
-            const f4 wa = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i) * 64 + lane) * 4);
-            const f4 wb = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i + 1) * 64 + lane) * 4);
+            const f4 wa = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i) * 64 + lw) * 4);
+            const f4 wb = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i + 1) * 64 + lw) * 4);
             U[tq][r] = (qa[0] * wa[0] + qa[1] * wa[1]) + (qa[2] * wa[2] + qa[3] * wa[3]) +
                        (qb[0] * wb[0] + qb[1] * wb[1]) + (qb[2] * wb[2] + qb[3] * wb[3]);
             if (r == 3) __builtin_amdgcn_sched_barrier(0);     // at most 8 weight reads in flight: the registers are needed
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
 #pragma unroll
               for (int tq = 0; tq < 8; ++tq) {
-                float w = wf_k[(st * 8 + tq) * 64 + lane];
+                float w = wf_k[(st * 8 + tq) * 64 + lw];
                 if (st == 11) w = g == 3 ? ckp[16 * tq + m] : w;
                 hid[tq] = mfma16(w, feat[tile][st], hid[tq]);
               }
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
               for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
 #pragma unroll
                 for (int tq = 0; tq < 8; ++tq) {
-                  float w = wf_v[(st * 8 + tq) * 64 + lane];
+                  float w = wf_v[(st * 8 + tq) * 64 + lw];
                   if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
                   hx[tq] = mfma16(w, feat[tile][st], hx[tq]);
                 }
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
               for (int r = 0; r < 4; r += 2) {
-                a1 = mfma16(hx[tq][r], w2xv[(tq * 4 + r) * 64 + lane], a1);
-                a2 = mfma16(hx[tq][r + 1], w2xv[(tq * 4 + r + 1) * 64 + lane], a2);
+                a1 = mfma16(hx[tq][r], w2xv[(tq * 4 + r) * 64 + lw], a1);
+                a2 = mfma16(hx[tq][r + 1], w2xv[(tq * 4 + r + 1) * 64 + lw], a2);
               }
             a1 += a2;
             const float bx = b2xv[m];
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
 #pragma unroll
               for (int tq = 0; tq < 8; ++tq) {
-                float w = wf_v[(st * 8 + tq) * 64 + lane];
+                float w = wf_v[(st * 8 + tq) * 64 + lw];
                 if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
                 hv[tq] = mfma16(feat[tile][st], w, hv[tq]);
               }
