@@ -92,6 +92,27 @@ def triplet_tiles(n_at):
     return (n_at - 1 + 15) // 16
 
 
+def knn_node_mfma(eng):
+    """16x16x4 MFMAs one knn-node sub-layer (csrc/node_attn.hip, both launches: ligand + pharmacophore targets) EXECUTES on the
+    engine's current neighbour lists: per 16-row tile and pass 8 x (2 + 5 [tile has ligand sources] + 5 [tile has pharmacophore
+    sources]) first-layer steps + 32 for the logits / the value aggregate; two passes.  (The neighbour slots are partitioned by
+    source kind, ligand atoms first: pg_knn_group_by_kind.)"""
+    w, p = eng.ws, eng.plan
+    deg = w.deg.long()
+    k = w.nbr.size(1)
+    valid = torch.arange(k, device=deg.device)[None, :] < deg[:, None]
+    is_lig = torch.zeros(p.n_ctx, dtype=torch.bool, device=deg.device)
+    is_lig[p.lig2ctx_long] = True
+    n_l = (is_lig[w.nbr.long().clamp(min=0)] & valid).sum(1)                # ligand sources of every node (they come first)
+    total = 0
+    for t0 in range(0, k, 16):
+        in_tile = (deg > t0)
+        has_l = in_tile & (n_l > t0)
+        has_p = in_tile & (deg > n_l) & (torch.minimum(deg, torch.tensor(t0 + 16, device=deg.device)) > n_l)
+        total += int((in_tile.long() * (8 * 2 + 32) + has_l.long() * 40 + has_p.long() * 40).sum())
+    return 2 * total
+
+
 def algorithmic_counts(n_at, n_ph, knn=32, H=128):
     """Per-step algorithmic work: sizes, GEMM FLOPs of the factored form, compulsory HBM bytes."""
     n_all = int((n_at + n_ph).sum())
@@ -266,7 +287,7 @@ def main():
                                   return_traj=True, num_steps=W + R * K, graph_ids=gids)
         for i in range(W):
             model.reverse_step(st, i, T - 1 - i)
-        times, tri = [], []
+        times, tri, knn = [], [], []
         i = W
         for r in range(R):
             barrier()
@@ -280,7 +301,10 @@ def main():
             times.append(max_over_ranks(time.perf_counter() - t0))
             if time_triplet:
                 tri += st.eng.kernel_ms('triplet')
+                knn += st.eng.kernel_ms('knn_node')
                 st.eng.timers = None
+        if time_triplet:
+            run.knn_ms, run.knn_mfma = knn, knn_node_mfma(st.eng)
         return times, tri, model.finish_sampling(st)
 
     # ---- strong scaling (headline): ONE batch of --graphs graphs, partitioned over the ranks by n^3 cost ----
@@ -348,6 +372,18 @@ def main():
                          'survey_flops_per_launch': counts['flops_triplet_kernel'], 'survey_achieved': alg_tf,
                          'survey_frac': (alg_tf / peak_tf) if alg_tf else None,
                          'share_of_step': (6 * tri_avg_ms) / (dt / K * 1e3) if tri_ms else None},
+            # the kernel furthest below its roofline (round-2 review): the knn-node attention sub-layer, both launches of a layer
+            'roofline_knn_node': (lambda ms, mf: {
+                'kernel': 'knn-node attention (pg_seg_attn PG_SEG_KNN_NODE fused form, node_attn_kernel<true,false,2,768,true>, '
+                          '2 launches per layer: ligand targets + pharmacophore targets), rank 0',
+                'bound': 'mfma', 'peak': peak_tf, 'unit': 'TFLOP/s', 'avg_sublayer_ms': ms, 'sublayers_timed': len(run.knn_ms),
+                'flops_per_sublayer': mf * 2048 + 2 * 2 * 128 * 128 * counts['n_all'],
+                'achieved': (mf * 2048 + 2 * 2 * 128 * 128 * counts['n_all']) / (ms * 1e-3) / 1e12,
+                'frac': (mf * 2048 + 2 * 2 * 128 * 128 * counts['n_all']) / (ms * 1e-3) / 1e12 / peak_tf,
+                'note': 'achieved = fp32 FLOPs EXECUTED (16x16x4 MFMAs counted from the current neighbour lists, kind-uniform tiles '
+                        'skip the other kind\'s distance columns, + query fold / value unfold per node) / mean duration of the two '
+                        'launches (HIP events on their lane); inside the four-lane step, other lanes run beside it'})(
+                sum(run.knn_ms) / max(len(run.knn_ms), 1), run.knn_mfma) if getattr(run, 'knn_ms', None) else None,
             'step_roofline': {'flops_alg_survey': counts['flops_step'], 'bytes_alg': counts['bytes_step'],
                               'survey_mfma_frac': counts['flops_step'] / (dt / K) / (peak_tf * 1e12),
                               'hbm_frac': counts['bytes_step'] / (dt / K) / 8e12,

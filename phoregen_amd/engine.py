@@ -143,11 +143,13 @@ class Engine:
         prog.append((tap, None, -1))
 
     def _event(self, prog, name, start):
-        """Timing tap: when `self.timers` is a dict, record a HIP event on the launch stream around a kernel."""
+        """Timing tap: when `self.timers` is a dict, record a HIP event around a kernel -- on the lane (stream) the kernel is
+        launched on, i.e. the lane that is current while the launch list is built."""
+        lane = self._lane if self.multi_stream else 0
         def tap(streams):
             if self.timers is not None:
                 ev = torch.cuda.Event(enable_timing=True)
-                ev.record(streams[0])
+                ev.record(streams[lane])
                 self.timers.setdefault(name, []).append((start, ev))
             return 0
         tap.__name__ = 'event_' + name
@@ -391,7 +393,10 @@ class Engine:
             self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB, buf=1)
             # ---- node update over knn edges (:281), then h' = h + lin_node(aggE + aggB) (:288)   [lane 1]
             self._lane = 1
-            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0)
+            self._query_gemm(prog, L.NE, w.Y1, 0, both, 0)
+            self._event(prog, 'knn_node', True)       # (both launches of the sub-layer: ligand targets, pharmacophore targets)
+            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0, query_done=True)
+            self._event(prog, 'knn_node', False)
             self._sync(prog, 1, (2,))                  # aggB
             # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~17 us)
             self._gemm(prog, w.aggE, 128, L.W_lin2[:, :128], w.lin_tmp, n, 128, bias=L.b_lin, add1=hc)
