@@ -96,7 +96,11 @@ __device__ __constant__ const float kT2Freq[12] = {0.f, 1.f, 2.f, 3.f, 0.5f, (fl
 
 constexpr size_t t2_lds_floats() { return 16384 + 2 * 1536 + 3 * 128 + 3 * T2_XS + 4 + (size_t)T2_ROWS * T2_ROW; }
 
-template <int THREADS, int MAXT>
+// TRAIN: the training forward (PhoreDiff.compute_loss): the normalised aggregate S and the attention mass go to
+// pg_attn_unfold_value like in the node modes, and the softmax weights alpha[seg][atom k][head] are left for the one-pass adjoint
+// (pg_seg_attn_bwd); rows are indexed by the atom k there, so the row of the source atom j itself (which this kernel never
+// visits) is written as zero
+template <int THREADS, int MAXT, bool TRAIN = false>
 __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p) {
   constexpr bool PRE = THREADS <= 512;          // next-segment prefetch of the per-segment global inputs
   constexpr int WAVES = THREADS / 64;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
 
   // LDS copies are laid out for 16-byte reads: feature weights [step][half][lane][4] (a lane's 8 tq values = two ds_read_b128),
   // the value LayerNorm shift [m][8] (channel 16 tq + m at m*8 + tq)
-  for (int i = tid; i < 128; i += THREADS) { bk[i] = p.ln_bk[i]; bv[(i & 15) * 8 + (i >> 4)] = p.ln_bv[i]; b2v[i] = p.b2v[i]; }
+  for (int i = tid; i < 128; i += THREADS) { bk[i] = p.ln_bk[i]; bv[(i & 15) * 8 + (i >> 4)] = p.ln_bv[i]; b2v[i] = TRAIN ? 0.f : p.b2v[i]; }
   for (int i = tid; i < 1536; i += THREADS) {             // source index i = (st * 8 + tq) * 64 + lane
     const int ln_ = i & 63, tq_ = (i >> 6) & 7, st_ = i >> 9;
     const int d_ = ((st_ * 2 + (tq_ >> 2)) * 64 + ln_) * 4 + (tq_ & 3);
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
     // round trip overlaps the previous segment's arithmetic instead of opening every segment with a wait
     float nQk[8], nQv[8];
     f4 nqa, nqb;
-    float2 nrs;
+    float2 nrs = {0.f, 0.f};
 #define T2_FETCH(S)                                                                                                    \
     {                                                                                                                  \
       const int a_ = (S) / nm1, ip_ = (S) - a_ * nm1, j_ = j0 + a_, i_ = ip_ + (ip_ >= j_ ? 1 : 0);                    \
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       const float* qk_ = p.Cdst_k + seg_ * p.ld_cdst + m;                                                              \
       const float* qv_ = p.Cdst_v + seg_ * p.ld_cdst + m;                                                              \
       _Pragma("unroll") for (int tq = 0; tq < 8; ++tq) { nQk[tq] = __builtin_nontemporal_load(qk_ + 16 * tq); nQv[tq] = __builtin_nontemporal_load(qv_ + 16 * tq); } \
-      { const t2_f2 r_ = __builtin_nontemporal_load(reinterpret_cast<const t2_f2*>(p.resid + seg_ * 128 + 8 * m + 2 * g)); nrs.x = r_[0]; nrs.y = r_[1]; } \
+      if constexpr (!TRAIN) { const t2_f2 r_ = __builtin_nontemporal_load(reinterpret_cast<const t2_f2*>(p.resid + seg_ * 128 + 8 * m + 2 * g)); nrs.x = r_[0]; nrs.y = r_[1]; } \
     }
     if (PRE && s_begin + wave < n_seg) T2_FETCH(s_begin + wave)
 
@@ -342,6 +346,19 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       l += __shfl_xor(l, 32);
       const float inv = l > 0.f ? 1.0f / l : 0.f;
 
+      if constexpr (TRAIN) {
+        if (p.alpha) {
+          float* const ap = p.alpha + (size_t)seg * p.alpha_rows * 16 + m;
+#pragma unroll
+          for (int tile = 0; tile < MAXT; ++tile)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kr = tile * 16 + 4 * g + r;                 // row among the other atoms of j -> atom kr (+1 past j)
+              if (kr < nm1) ap[(kr + (kr >= j ? 1 : 0)) * 16] = lg[tile][r] * inv;
+            }
+          if (g == 0) ap[j * 16] = 0.f;
+        }
+      }
       T2_STAMP(4);                                // softmax
       // =============================== pass B: S^T[c, h] = sum_rows z_v[row, c] * alpha[row, h] ===============================
       f4 sT[8];
@@ -396,6 +413,15 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
       }
 
       T2_STAMP(5);                                // pass B
+      if constexpr (TRAIN) {
+        float* const sp = p.S + (size_t)seg * 2048 + lane;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sp[(tq * 4 + r) * 64] = sT[tq][r] * inv;
+        if (g == 0) p.swn[(size_t)seg * 16 + m] = l > 0.f ? 1.f : 0.f;
+        continue;
+      }
       // =============================== epilogue: out = resid + W2v_h . S[:,h] / l + b2v ===============================
       // W2v streams through L2: 64 float4 per lane, addresses independent of everything computed in the segment
       const size_t ro = (size_t)seg * 128 + 8 * m + 2 * g;
@@ -434,28 +460,36 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
 #endif
 }
 
-template <int THREADS, int MAXT>
+template <int THREADS, int MAXT, bool TRAIN = false>
 static int launch_t2(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   const size_t lds = t2_lds_floats() * sizeof(float);
-  if (int rc = reserve_lds(reinterpret_cast<const void*>(triplet2_kernel<THREADS, MAXT>), lds, "pg_seg_attn(triplet, staged)")) return rc;
-  hipLaunchKernelGGL((triplet2_kernel<THREADS, MAXT>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(triplet2_kernel<THREADS, MAXT, TRAIN>), lds, "pg_seg_attn(triplet, staged)")) return rc;
+  hipLaunchKernelGGL((triplet2_kernel<THREADS, MAXT, TRAIN>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p);
   return check_launch("pg_seg_attn(triplet, staged)");
 }
 
 int g_t2_waves = 12;  // waves per workgroup: 12 (3 per SIMD, no look-ahead prefetch; measured 1.98 ms) or 8 (with it, 2.07 ms);
                       // pg_debug_force_generic_seg bit 2 selects 8
 
-// usable when the caller provides the source-atom groups (PgSegAttn.tri_iters), asks for the sampling form (out = resid +
-// update, no S / alpha side outputs) and P is one [n_bond, 256] = [P_k | P_v] tensor; returns -1 otherwise
+// usable when the caller provides the source-atom groups (PgSegAttn.tri_iters) and P is one [n_bond, 256] = [P_k | P_v] tensor,
+// for the sampling form (out = resid + update) and for the training form (S, swn and optionally alpha out; q and W2k_l given);
+// returns -1 otherwise
 int launch_triplet_staged(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  if (!p->tri_iters || !p->tri_counter || p->n_tri_iters <= 0) return -1;
+  const bool train = p->S != nullptr;
 #ifdef PG_T2_PROF
-  if (!p->tri_iters || !p->tri_counter || p->n_tri_iters <= 0 || p->S || !p->out || !p->resid) return -1;
+  if (train || !p->out || !p->resid) return -1;
 #else
-  if (!p->tri_iters || !p->tri_counter || p->n_tri_iters <= 0 || p->S || p->alpha || !p->out || !p->resid) return -1;
+  if (train ? (!p->swn || !p->q || !p->W2k_l || (p->alpha && p->alpha_rows < t->max_nlig)) : (p->alpha || !p->out || !p->resid)) return -1;
 #endif
   if (p->Csrc_v != p->Csrc_k + 128 || p->ld_csrc != 256 || ((size_t)p->Csrc_k & 15) || !p->Cdst_k || !p->Cdst_v) return -1;
   if (t->max_nlig - 1 > T2_ROWS || t->max_nlig > T2_XS) return -1;
   const int tiles = (t->max_nlig - 1 + 15) / 16;
+  if (train) {
+    if (tiles <= 3) return launch_t2<768, 3, true>(t, p, st);
+    if (tiles == 4) return launch_t2<768, 4, true>(t, p, st);
+    return launch_t2<768, 5, true>(t, p, st);
+  }
   if (g_t2_waves == 12) {
     if (tiles <= 3) return launch_t2<768, 3>(t, p, st);
     if (tiles == 4) return launch_t2<768, 4>(t, p, st);

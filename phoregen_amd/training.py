@@ -270,6 +270,9 @@ class SegCoreFn(torch.autograd.Function):
         if tf is not None:
             for k in ('q', 'W2k_l', 'W2v_l', 'b2v', 'Wg2_k', 'Wg2_v', 'G', 'seg_ids', 'seg_chunks'):
                 setattr(s, k, tf[k].data_ptr())
+            if tf.get('n_tri_iters') and os.environ.get('PG_TRI_STAGED', '1') != '0':
+                # source-atom groups of the plan: the LDS-staged kernel (csrc/triplet2.hip, training form) takes the launch
+                s.tri_iters, s.n_tri_iters, s.tri_counter = tf['tri_iters'].data_ptr(), tf['n_tri_iters'], tf['tri_counter'].data_ptr()
             if cfg['max_rows'] <= 80 and onepass:   # the tuned kernel runs: it can hand the softmax weights to the adjoint
                 arows = (cfg['max_rows'] + 15) // 16 * 16
                 alpha = torch.empty(cfg['n_seg'] * arows * 16, dtype=torch.float32, device=dev)
@@ -526,7 +529,8 @@ class TrainForward:
                        max_rows=max_lig, need_gx=True,
                        tri_fwd=dict(q=qT.detach(), W2k_l=a.W2k_l.detach(), W2v_l=a.W2v_l.detach(), b2v=a.b2v.detach(),
                                     Wg2_k=a.Wg2_k.detach(), Wg2_v=a.Wg2_v.detach(), G=G.detach().contiguous(),
-                                    seg_ids=p.tri_order, seg_chunks=p.tri_chunks))
+                                    seg_ids=p.tri_order, seg_chunks=p.tri_chunks, tri_iters=p.tri_iters,
+                                    n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter))
             S, swn = seg_core(cfg, Q, P, U, x, Wf_k=a.Wf_k, Wf_v=a.Wf_v, bk=a.ln_bk, bv=a.ln_bv)
             hb_new = hb + UnfoldFn.apply(S, swn, a.W2v_l, a.b2v, None, E)
             h_new = h + linear(aggE + aggB, L.W_lin, L.b_lin)
