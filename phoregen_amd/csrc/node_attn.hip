@@ -65,8 +65,22 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
   float* const b2v_s = w2k + 16384;         // FUSED node update: [128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, m = lane & 15;
+  // Two target lists in one launch (fused knn form, PgSegAttn.seg_ids2): the grid is rows of 8 workgroups (one per XCD under
+  // round-robin placement); the first `rows1` rows serve list 1, the others list 2 -- in proportion to the lists' node counts, so
+  // both finish after the same number of node rounds.  One list: every row serves it.
+  const int n_rows_grid = FUSED ? ((int)gridDim.x + 7) / 8 : 1;
+  int rows1 = n_rows_grid;
+  if (FUSED && KNN && p.n_seg2 > 0) {
+    rows1 = (int)(((long long)n_rows_grid * p.n_seg + (p.n_seg + p.n_seg2) / 2) / (p.n_seg + p.n_seg2));
+    rows1 = rows1 < 1 ? 1 : (rows1 > n_rows_grid - 1 ? n_rows_grid - 1 : rows1);
+  }
+  const bool list2 = FUSED && KNN && p.n_seg2 > 0 && (int)blockIdx.x / 8 >= rows1;
+  const int* const my_ids = list2 ? p.seg_ids2 : p.seg_ids;
+  const int my_n = list2 ? p.n_seg2 : p.n_seg;
+  const float* const my_wf_k = list2 ? p.Wf_k2 : p.Wf_k;
+  const float* const my_wf_v = list2 ? p.Wf_v2 : p.Wf_v;
   for (int i = tid; i < 128; i += THREADS) { bpk[i] = p.ln_bk[i]; bpv[i] = p.ln_bv[i]; }
-  for (int i = tid; i < NSTEP * 512; i += THREADS) { wf_k[i] = p.Wf_k[i]; wf_v[i] = p.Wf_v[i]; }
+  for (int i = tid; i < NSTEP * 512; i += THREADS) { wf_k[i] = my_wf_k[i]; wf_v[i] = my_wf_v[i]; }
   if constexpr (POS) {
     for (int i = tid; i < 2048; i += THREADS) w2xv[i] = p.W2xv_l[i];
     for (int i = tid; i < 16; i += THREADS) b2xv[i] = p.b2xv[i];
@@ -82,15 +96,19 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
   // places on one XCD (MI355X_MICROARCH.md, "Workgroup dispatch": a speed assumption only).  A graph's first-layer rows (the
   // Csrc blocks every one of its ~150 nodes gathers 32 of) are then pulled through ONE L2 instead of all eight.
   constexpr int PER = THREADS / 64;
-  const int n_chunks = (p.n_seg + PER - 1) / PER;
-  const int n_x = FUSED ? ((int)gridDim.x < 8 ? (int)gridDim.x : 8) : 1;
-  const int xcd = FUSED ? (int)blockIdx.x % n_x : 0, jx = FUSED ? (int)blockIdx.x / n_x : (int)blockIdx.x;
-  const int n_jx = FUSED ? ((int)gridDim.x - xcd + n_x - 1) / n_x : (int)gridDim.x;
+  const int n_chunks = (my_n + PER - 1) / PER;
+  // this list's workgroups: rows [row_lo, row_hi) of the grid (a row = 8 consecutive workgroups); a partial last row belongs to list 2
+  const int row_lo = list2 ? rows1 : 0, row_hi = (FUSED && KNN && p.n_seg2 > 0 && !list2) ? rows1 : n_rows_grid;
+  const int wg_lo = row_lo * 8, wg_hi = row_hi * 8 < (int)gridDim.x ? row_hi * 8 : (int)gridDim.x;
+  const int n_wg = FUSED ? wg_hi - wg_lo : (int)gridDim.x, b_loc = FUSED ? (int)blockIdx.x - wg_lo : (int)blockIdx.x;
+  const int n_x = FUSED ? (n_wg < 8 ? n_wg : 8) : 1;
+  const int xcd = FUSED ? b_loc % n_x : 0, jx = FUSED ? b_loc / n_x : b_loc;
+  const int n_jx = FUSED ? (n_wg - xcd + n_x - 1) / n_x : n_wg;
   const int c_lo = (int)((long long)n_chunks * xcd / n_x), c_hi = (int)((long long)n_chunks * (xcd + 1) / n_x);
   for (int ch = c_lo + jx; ch < c_hi; ch += n_jx) {
     const int si = ch * PER + wave;
-    if (si >= p.n_seg) continue;
-    const int seg = p.seg_ids ? p.seg_ids[si] : si;        // target ctx node
+    if (si >= my_n) continue;
+    const int seg = my_ids ? my_ids[si] : si;              // target ctx node
     // opaque copy of the lane id: LDS weight reads addressed through it are not loop-invariant, so the compiler cannot hoist them
     // out of the node loop into registers it then has to spill (the fused knn form carried 70 spilled registers that way)
     int lw = lane;
@@ -199,7 +217,10 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int tq = 0; tq < 8; ++tq) {
               f4 c = {0.f, 0.f, 0.f, 0.f};
               if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
-              if constexpr (!KNN) c += *reinterpret_cast<const f4*>(ckp + 16 * tq + 4 * g);
+              if constexpr (!KNN) {
+                c += *reinterpret_cast<const f4*>(ckp + 16 * tq + 4 * g);
+                if (p.Ysrc_k && valid) c += *reinterpret_cast<const f4*>(p.Ysrc_k + (size_t)src * p.ld_ysrc + 4 * g + 16 * tq);
+              }
               hid[tq] = c;
             }
           }
@@ -240,7 +261,10 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int tq = 0; tq < 8; ++tq) {
               f4 c = {0.f, 0.f, 0.f, 0.f};
               if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
-              if constexpr (!KNN) c += *reinterpret_cast<const f4*>(cvp + 16 * tq + 4 * g);
+              if constexpr (!KNN) {
+                c += *reinterpret_cast<const f4*>(cvp + 16 * tq + 4 * g);
+                if (p.Ysrc_v && valid) c += *reinterpret_cast<const f4*>(p.Ysrc_v + (size_t)src * p.ld_ysrc + 4 * g + 16 * tq);
+              }
               hx[tq] = c;
             }
 #pragma unroll
@@ -358,6 +382,13 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             const float* pv = p.Csrc_v + (size_t)crow * p.ld_csrc + m;
 #pragma unroll
             for (int tq = 0; tq < 8; ++tq) hv[tq][r] = vr ? pv[16 * tq] : 0.f;
+            if constexpr (!KNN) {
+              if (p.Ysrc_v && vr) {
+                const float* ys = p.Ysrc_v + (size_t)(lig0 + kr) * p.ld_ysrc + m;
+#pragma unroll
+                for (int tq = 0; tq < 8; ++tq) hv[tq][r] += ys[16 * tq];
+              }
+            }
           }
           if constexpr (!KNN) {
 #pragma unroll
@@ -446,6 +477,10 @@ static int launch_na(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   if (int rc = reserve_lds(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED>), lds, "node_attn")) return rc;
   const int per = THREADS / 64;
   int blocks = (p->n_seg + per - 1) / per;
+  if (FUSED && KNN && p->n_seg2 > 0) {
+    blocks += (p->n_seg2 + per - 1) / per;
+    if (blocks < 16) blocks = 16;                            // (two lists: at least one row of 8 workgroups each)
+  }
   if (FUSED) { if (blocks > kNumCU) blocks = kNumCU; }      // one persistent workgroup per CU (64 KB of W2k each)
   else if (KNN && blocks > 3 * kNumCU) blocks = 3 * kNumCU; // LDS-heavy: persistent-ish, the weights are loaded per block
   hipLaunchKernelGGL((node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED>), dim3(blocks), dim3(THREADS), lds, st, *t, *p);

@@ -41,6 +41,10 @@ class Engine:
         self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
         self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
         self.group_knn = os.environ.get('PG_KNN_GROUP', '1') != '0'            # neighbour slots partitioned by source kind
+        self.merge_knn_lists = os.environ.get('PG_KNN_MERGE', '1') != '0'      # ligand + pharmacophore targets of a knn sub-layer in one launch
+        # bond position update: the edge product h_bond' . W_hb leaves right after the triplet kernel and the attention kernel adds
+        # the per-source-atom rows of Y2 itself (PgSegAttn.Ysrc_k), instead of a gathered GEMM that has to wait for Y2 (0: the old form)
+        self.split_pos_gemm = os.environ.get('PG_POS_SPLIT', '1') != '0'
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -84,6 +88,7 @@ class Engine:
         w.aggE, w.aggB = _f(n, 128, device=d, zero=True), _f(n, 128, device=d, zero=True)
         w.lin_tmp = _f(n, 128, device=d)
         w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)
+        w.CsB2 = _f(E, 256, device=d)                                  # bond-pos edge product h_bond' . W_hb (written right after the triplet kernel)
         w.Qd = _f(E, 256, device=d)                                    # triplet: per-segment constant smear(d_ji) . Wg2 (k | v)
         w.qhid, w.qT = _f(E, 128, device=d), _f(E, 128, device=d)
         w.dxe, w.dxb = _f(n, 3, device=d, zero=True), _f(n, 3, device=d, zero=True)
@@ -219,7 +224,12 @@ class Engine:
         knn = mode in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS)
         pos = mode in (hip.SEG_KNN_POS, hip.SEG_BOND_POS)
         fused = self.fused_node and mode != hip.SEG_PHORE      # in-kernel query fold / value unfold (csrc/node_attn.hip)
-        for seg_ids, n_seg, is_lig in h_dst_lists:
+        # fused knn form with two target lists (ligand + pharmacophore targets, different feature weights): ONE launch, the
+        # persistent workgroups split between the lists in proportion to their sizes (PgSegAttn.seg_ids2)
+        merged = fused and knn and len(h_dst_lists) == 2 and self.merge_knn_lists and all(n > 0 for _, n, _ in h_dst_lists) and \
+            sum(n for _, n, _ in h_dst_lists) >= 3 * 256 * 12      # (>= 3 node rounds of the persistent grid; smaller batches: measured slower)
+        lists = [h_dst_lists[0]] if merged else h_dst_lists
+        for seg_ids, n_seg, is_lig in lists:
             if not fused:
                 self._call(prog, self.lib.pg_attn_fold_query, wq.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
                            seg_ids.data_ptr(), wU.data_ptr())
@@ -227,6 +237,9 @@ class Engine:
             if knn:
                 kw.update(nrm=w.nrm, nbr=w.nbr, deg=w.deg, ew=w.ew, Csrc_k=blk(2), Csrc_v=blk(3), ld_csrc=Y.stride(0),
                           Wf_k=a.Wf_k[is_lig], Wf_v=a.Wf_v[is_lig])
+                if merged:
+                    ids2, n2, lig2 = h_dst_lists[1]
+                    kw.update(seg_ids2=ids2, n_seg2=n2, Wf_k2=a.Wf_k[lig2], Wf_v2=a.Wf_v[lig2])
             elif mode == hip.SEG_PHORE:
                 kw.update(Csrc_k=blk(2), Csrc_v=blk(3), ld_csrc=Y.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v)
             else:
@@ -383,6 +396,9 @@ class Engine:
                       **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter,
                               Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
+            split_pos = self.split_pos_gemm and p.topo.max_nlig <= 80
+            if split_pos:                              # needs h_bond' only: runs while the node chain is still finishing
+                self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB2, E, 256)
             if last:                                   # lane 3 (the triplet queries) has been joined: the bond head takes it
                 self._fork(prog, (3,))
                 self._lane = 3
@@ -411,17 +427,26 @@ class Engine:
             else:
                 self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
             self._sync(prog, 0, (1,))                  # lane 0 continues after the triplet kernel AND Y2 (which implies lane 2)
+            # the bond position update's query MLP runs beside its edge product / the knn position update, not in front of the
+            # attention on lane 0: lane 3 is free after the triplet queries (last layer: lane 2, in front of the node head --
+            # forked from lane 0, which has just seen h' and Y2: a lane-2-waits-lane-1 edge after lane 1 waited on lane 2 crashes
+            # hipGraph capture, PG_GRAPH=1)
+            qlane = 2 if last else 3
+            self._fork(prog, (qlane,))
+            self._lane = qlane
+            self._query_gemm(prog, L.PB, w.Y2, 5 * 128, lig, 1)
+            self._sync(prog, 0, (qlane,))              # (a join of this point of the lane: the node head below is not waited for)
             if last:
-                # lane 2 has nothing left in this step: the node head takes it.  Forked from lane 0 (which has just seen h'), not
-                # from lane 1: a lane-2-waits-lane-1 edge after lane 1 waited on lane 2 crashes hipGraph capture (PG_GRAPH=1)
-                self._fork(prog, (2,))
-                self._lane = 2
-                heads[1](hn)
-                self._lane = 1
+                heads[1](hn)                           # lane 2 has nothing else left in this step: the node head takes it
+            self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
-            self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
-            self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1)
+            if split_pos:
+                self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB2, buf=1, query_done=True,
+                                     extra=dict(Ysrc_k=w.Y2[:, 7 * 128:8 * 128], Ysrc_v=w.Y2[:, 8 * 128:9 * 128], ld_ysrc=w.Y2.stride(0)))
+            else:
+                self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
+                self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1, query_done=True)
             self._join(prog, (1,))
             self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
             self._mark(prog, f'L{li}', hn, hbn, xn, w.aggE, w.aggB, w.dxe, w.dxb, w.nrm, hbc)

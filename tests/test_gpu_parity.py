@@ -706,7 +706,9 @@ def test_engine_variants_agree(model):
         for _ in range(6):
             again = [o.cpu() for o in model(**dev_inp)[:3]]
             assert all(torch.equal(a, b) for a, b in zip(base, again))
-    for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run(gemm_mode=0)):
+    two_launches = run({'PG_KNN_MERGE': '0'})         # ligand / pharmacophore targets of a knn sub-layer as two launches: same bits per node
+    assert all(torch.equal(a, b) for a, b in zip(base, two_launches))
+    for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run({'PG_POS_SPLIT': '0'}), run(gemm_mode=0)):
         assert max(rel_err(a, b) for a, b in zip(variant, base)) <= 2e-5
 
 
