@@ -198,11 +198,6 @@ typedef struct {
    * split between the two lists in proportion to their sizes, so that the two lists finish together instead of each rounding
    * its own number of node rounds up (one launch instead of two).  n_seg2 = 0: one list. */
   const int* seg_ids2; int n_seg2; const float* Wf_k2; const float* Wf_v2;
-  /* Bond modes, optional: per-SOURCE-ATOM rows added to the gathered edge rows -- hidden[row k] = Csrc[edge k->i] + Ysrc[atom k]
-   * + Cdst[i]: the source half of the factored first layer (models/uni_denoiser.py:190-193 [h_bond, h_dst, h_src]) read from the
-   * [n_ctx, ld_ysrc] node product directly instead of being folded into Csrc by a gathered GEMM epilogue, so that the edge product
-   * h_bond . W_hb does not have to wait for the node product.  Two-pass kernels only (ligands of <= 80 atoms). */
-  const float* Ysrc_k; const float* Ysrc_v; int ld_ysrc;
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 

@@ -217,10 +217,7 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int tq = 0; tq < 8; ++tq) {
               f4 c = {0.f, 0.f, 0.f, 0.f};
               if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
-              if constexpr (!KNN) {
-                c += *reinterpret_cast<const f4*>(ckp + 16 * tq + 4 * g);
-                if (p.Ysrc_k && valid) c += *reinterpret_cast<const f4*>(p.Ysrc_k + (size_t)src * p.ld_ysrc + 4 * g + 16 * tq);
-              }
+              if constexpr (!KNN) c += *reinterpret_cast<const f4*>(ckp + 16 * tq + 4 * g);
               hid[tq] = c;
             }
           }
@@ -261,10 +258,7 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             for (int tq = 0; tq < 8; ++tq) {
               f4 c = {0.f, 0.f, 0.f, 0.f};
               if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
-              if constexpr (!KNN) {
-                c += *reinterpret_cast<const f4*>(cvp + 16 * tq + 4 * g);
-                if (p.Ysrc_v && valid) c += *reinterpret_cast<const f4*>(p.Ysrc_v + (size_t)src * p.ld_ysrc + 4 * g + 16 * tq);
-              }
+              if constexpr (!KNN) c += *reinterpret_cast<const f4*>(cvp + 16 * tq + 4 * g);
               hx[tq] = c;
             }
 #pragma unroll
@@ -382,13 +376,6 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
             const float* pv = p.Csrc_v + (size_t)crow * p.ld_csrc + m;
 #pragma unroll
             for (int tq = 0; tq < 8; ++tq) hv[tq][r] = vr ? pv[16 * tq] : 0.f;
-            if constexpr (!KNN) {
-              if (p.Ysrc_v && vr) {
-                const float* ys = p.Ysrc_v + (size_t)(lig0 + kr) * p.ld_ysrc + m;
-#pragma unroll
-                for (int tq = 0; tq < 8; ++tq) hv[tq][r] += ys[16 * tq];
-              }
-            }
           }
           if constexpr (!KNN) {
 #pragma unroll

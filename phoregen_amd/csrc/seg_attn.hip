@@ -563,16 +563,6 @@ static int launch_seg(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   return check_launch("pg_seg_attn");
 }
 
-// Csrc[e, 0:256] += Ysrc[bond_src[e], 0:256]  (fallback of PgSegAttn.Ysrc_k / Ysrc_v for the one-pass kernel)
-__global__ void add_src_rows_kernel(float* csrc, int ld_csrc, const float* ysrc, int ld_ysrc, const int* bond_src, int n_bond) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t e = idx >> 6;
-  if (e >= (size_t)n_bond) return;
-  const int c4 = (int)(idx & 63) * 4;
-  f4* dst = reinterpret_cast<f4*>(csrc + e * ld_csrc + c4);
-  *dst = *dst + *reinterpret_cast<const f4*>(ysrc + (size_t)bond_src[e] * ld_ysrc + c4);
-}
-
 }  // namespace pg
 
 using namespace pg;
@@ -609,22 +599,6 @@ extern "C" int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream) {
   if (p->mode <= PG_SEG_BOND_POS && !(g_force_generic & 1)) {   // two-pass kernels; pg_debug_force_generic_seg keeps the one-pass kernel testable
     const int rc = launch_node_attn(t, p, st);
     if (rc >= 0) return rc;
-  }
-  if (p->Ysrc_k || p->Ysrc_v) {
-    // the one-pass kernel runs (ligands above 80 atoms, or forced): fold the per-source-atom rows into the edge rows first, IN PLACE
-    // (Csrc is the caller's scratch product h_bond . W_hb in this form), then attend without them
-    if ((p->mode != PG_SEG_BOND_NODE && p->mode != PG_SEG_BOND_POS) || !p->Ysrc_k || p->Ysrc_v != p->Ysrc_k + 128 ||
-        p->Csrc_v != p->Csrc_k + 128) {
-      set_error("pg_seg_attn: Ysrc_k / Ysrc_v need a bond mode and [k | v] halves 128 floats apart in both Ysrc and Csrc");
-      return PG_ERR_ARG;
-    }
-    const size_t total = (size_t)t->n_bond * 64;         // float4 pieces of the 256-float rows
-    hipLaunchKernelGGL(add_src_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, const_cast<float*>(p->Csrc_k),
-                       p->ld_csrc, p->Ysrc_k, p->ld_ysrc, t->bond_src, t->n_bond);
-    if (int rc = check_launch("pg_seg_attn(add source rows)")) return rc;
-    PgSegAttn u = *p;
-    u.Ysrc_k = u.Ysrc_v = nullptr;
-    return pg_seg_attn(t, &u, stream);
   }
   if (node_attn_fused_request(p)) {
     // the fused form was asked for but the one-pass kernel runs (shape outside the two-pass kernels, or forced): fold, attend

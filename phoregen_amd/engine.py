@@ -42,9 +42,6 @@ class Engine:
         self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
         self.group_knn = os.environ.get('PG_KNN_GROUP', '1') != '0'            # neighbour slots partitioned by source kind
         self.merge_knn_lists = os.environ.get('PG_KNN_MERGE', '1') != '0'      # ligand + pharmacophore targets of a knn sub-layer in one launch
-        # bond position update: the edge product h_bond' . W_hb leaves right after the triplet kernel and the attention kernel adds
-        # the per-source-atom rows of Y2 itself (PgSegAttn.Ysrc_k), instead of a gathered GEMM that has to wait for Y2 (0: the old form)
-        self.split_pos_gemm = os.environ.get('PG_POS_SPLIT', '1') != '0'
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -88,7 +85,6 @@ class Engine:
         w.aggE, w.aggB = _f(n, 128, device=d, zero=True), _f(n, 128, device=d, zero=True)
         w.lin_tmp = _f(n, 128, device=d)
         w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)
-        w.CsB2 = _f(E, 256, device=d)                                  # bond-pos edge product h_bond' . W_hb (written right after the triplet kernel)
         w.Qd = _f(E, 256, device=d)                                    # triplet: per-segment constant smear(d_ji) . Wg2 (k | v)
         w.qhid, w.qT = _f(E, 128, device=d), _f(E, 128, device=d)
         w.dxe, w.dxb = _f(n, 3, device=d, zero=True), _f(n, 3, device=d, zero=True)
@@ -145,6 +141,28 @@ class Engine:
                 streams[waiter].wait_event(ev)
             return 0
         tap.__name__ = 'sync'
+        prog.append((tap, None, -1))
+
+    def _record(self, prog, lane):
+        """Mark this point of `lane`; `_wait` lets another lane continue after it (a `_sync` whose wait is placed later in the list)."""
+        evs = []
+        if self.multi_stream:
+            def tap(streams):
+                if not evs:
+                    evs.append(torch.cuda.Event())
+                evs[0].record(streams[lane])
+                return 0
+            tap.__name__ = 'record'
+            prog.append((tap, None, -1))
+        return evs
+
+    def _wait(self, prog, waiter, evs):
+        if not self.multi_stream:
+            return
+        def tap(streams):
+            streams[waiter].wait_event(evs[0])
+            return 0
+        tap.__name__ = 'wait'
         prog.append((tap, None, -1))
 
     def _event(self, prog, name, start):
@@ -396,9 +414,6 @@ class Engine:
                       **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter,
                               Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
-            split_pos = self.split_pos_gemm and p.topo.max_nlig <= 80
-            if split_pos:                              # needs h_bond' only: runs while the node chain is still finishing
-                self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB2, E, 256)
             if last:                                   # lane 3 (the triplet queries) has been joined: the bond head takes it
                 self._fork(prog, (3,))
                 self._lane = 3
@@ -435,18 +450,15 @@ class Engine:
             self._fork(prog, (qlane,))
             self._lane = qlane
             self._query_gemm(prog, L.PB, w.Y2, 5 * 128, lig, 1)
-            self._sync(prog, 0, (qlane,))              # (a join of this point of the lane: the node head below is not waited for)
+            q_done = self._record(prog, qlane)         # (this point of the lane: the node head below is not waited for)
             if last:
                 heads[1](hn)                           # lane 2 has nothing else left in this step: the node head takes it
             self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
-            if split_pos:
-                self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB2, buf=1, query_done=True,
-                                     extra=dict(Ysrc_k=w.Y2[:, 7 * 128:8 * 128], Ysrc_v=w.Y2[:, 8 * 128:9 * 128], ld_ysrc=w.Y2.stride(0)))
-            else:
-                self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
-                self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1, query_done=True)
+            self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            self._wait(prog, 0, q_done)
+            self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1, query_done=True)
             self._join(prog, (1,))
             self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
             self._mark(prog, f'L{li}', hn, hbn, xn, w.aggE, w.aggB, w.dxe, w.dxb, w.nrm, hbc)

@@ -708,7 +708,7 @@ def test_engine_variants_agree(model):
             assert all(torch.equal(a, b) for a, b in zip(base, again))
     two_launches = run({'PG_KNN_MERGE': '0'})         # ligand / pharmacophore targets of a knn sub-layer as two launches: same bits per node
     assert all(torch.equal(a, b) for a, b in zip(base, two_launches))
-    for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run({'PG_POS_SPLIT': '0'}), run(gemm_mode=0)):
+    for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run(gemm_mode=0)):
         assert max(rel_err(a, b) for a, b in zip(variant, base)) <= 2e-5
 
 
