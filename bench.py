@@ -366,7 +366,7 @@ def main():
                          'avg_launch_ms': tri_avg_ms, 'launches_timed': len(tri_ms),
                          'flops_per_launch': counts['flops_triplet_executed'],
                          'note': 'achieved = fp32 FLOPs the kernel EXECUTES per launch (112 MFMA 16x16x4 per 16-row tile + query fold / '
-                                 'value unfold + Q, padding rows included) / mean launch duration (HIP events on the launch stream). '
+                                 'value unfold, padding rows included; Q arrives as a GEMM row) / mean launch duration (HIP events on the launch stream). '
                                  'SURVEY 8d counts the unfolded second layers the kernel never runs: see survey_* (can exceed 1).',
                          'useful_frac': (exec_tf / peak_tf * counts['tri_useful_rows'] / counts['tri_padded_rows']) if exec_tf else None,
                          'survey_flops_per_launch': counts['flops_triplet_kernel'], 'survey_achieved': alg_tf,
