@@ -42,6 +42,9 @@ class Engine:
         self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
         self.group_knn = os.environ.get('PG_KNN_GROUP', '1') != '0'            # neighbour slots partitioned by source kind
         self.merge_knn_lists = os.environ.get('PG_KNN_MERGE', '1') != '0'      # ligand + pharmacophore targets of a knn sub-layer in one launch
+        # the next layer's first-layer blocks, triplet queries and bond-node rows (everything in front of its triplet kernel that does
+        # not depend on the new coordinates) run on lane 2 during this layer's position updates
+        self.layer_ahead = os.environ.get('PG_LAYER_AHEAD', '1') != '0'
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -84,7 +87,8 @@ class Engine:
         w.swn = [_f(n, 16, device=d) for _ in range(2)]
         w.aggE, w.aggB = _f(n, 128, device=d, zero=True), _f(n, 128, device=d, zero=True)
         w.lin_tmp = _f(n, 128, device=d)
-        w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)
+        w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)     # (CsB: bond-pos edge rows)
+        w.CsB2 = _f(E, 256, device=d)                                  # bond-node edge rows (written one layer ahead, see _denoiser_program)
         w.Qd = _f(E, 256, device=d)                                    # triplet: per-segment constant smear(d_ji) . Wg2 (k | v)
         w.qhid, w.qT = _f(E, 128, device=d), _f(E, 128, device=d)
         w.dxe, w.dxb = _f(n, 3, device=d, zero=True), _f(n, 3, device=d, zero=True)
@@ -359,9 +363,32 @@ class Engine:
         self._lane = 0
         cur = 0
         staged = bool(p.n_tri_iters and self.staged_triplet)
+        n_layers = len(pk.layers)
+        # next layer's x-independent products inside this layer's position phase: measured (same box, alternating runs) 16 graphs
+        # 3.93 -> 3.83 ms, 32 graphs 5.94 -> 5.67, 64 graphs 10.55 -> 10.36, 128 graphs 20.12 -> 20.17 (the triplet kernel then
+        # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
+        ahead = self.layer_ahead and self.multi_stream and E < 160000
+
+        def first_layer_gemm(L, h_in):
+            # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
+            # (ligand atoms: targets and sources of bond edges)
+            if self.row_subsets:
+                self._gemm(prog, h_in, 128, L.W_node1[:640], w.Y1[:, :640], n, 640, bias=L.b_node1[:640])
+                self._gemm(prog, h_in, 128, L.W_node1[640:], w.Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
+            else:
+                self._gemm(prog, h_in, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
+
+        def triplet_queries(L, hb_in):
+            self._gemm(prog, hb_in, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
+            self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b), scale=HEAD_SCALE)
+
+        def bond_node_rows(L, hb_in):
+            self._gemm(prog, hb_in, 128, L.NB.W_hb, w.CsB2, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
+
         for li, L in enumerate(pk.layers):
             nxt = 1 - cur
             hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
+            pre = ahead and li > 0            # Y1, the triplet queries and the bond-node rows of this layer were launched by the previous one
             # direction vectors (read by the knn attention, lane 1) and bond-length smearing (read by the P product on lane 0 and
             # the Q rows on lane 2) depend on x only: they run beside the first-layer GEMM instead of in front of it
             self._fork(prog, (1, 3))
@@ -371,19 +398,16 @@ class Engine:
             self._lane = 3
             self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
             self._lane = 0
-            # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
-            # (ligand atoms: targets and sources of bond edges)
-            if self.row_subsets:
-                self._gemm(prog, hc, 128, L.W_node1[:640], w.Y1[:, :640], n, 640, bias=L.b_node1[:640])
-                self._gemm(prog, hc, 128, L.W_node1[640:], w.Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
+            if pre:
+                self._sync(prog, 0, (2,))              # lane 2 carried them through the previous layer's position updates
             else:
-                self._gemm(prog, hc, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
+                first_layer_gemm(L, hc)
             if li == 0 and pre_join:
                 self._join(prog, pre_join)
             self._fork(prog, (1, 2, 3))
             self._sync(prog, 0, (3,))                  # the smearing (alone on lane 3 so far) is read by P on lane 0
             self._sync(prog, 2, (3,))                  # ... and by the Q rows on lane 2; the queries on lane 3 do not wait for it
-            last = heads is not None and li == len(pk.layers) - 1
+            last = heads is not None and li == n_layers - 1
             # Launch order of a layer.  Lane 0 carries the bond chain (P -> triplet -> bond position update), lane 1 the node
             # chain (knn attention -> lin_node -> second first-layer GEMM -> knn position update), lane 2 the Q rows and the
             # bond-node attention, lane 3 the triplet queries: nothing on lane 1 waits for the triplet kernel, and lane 0 picks
@@ -400,9 +424,9 @@ class Engine:
             if staged:   # the per-segment constant of the triplet MLPs as rows: Wg2 . smear(d_ji) + (target half)[j]
                 self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=w.Y1[:, 12 * 128:14 * 128], idx1=p.bond_src)
                 self._sync(prog, 0, (2,))              # lane 0 (the triplet kernel) waits for the Q rows, not for all of lane 2
-            self._lane = 3                                                              # triplet queries
-            self._gemm(prog, hbc, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
-            self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b), scale=HEAD_SCALE)
+            if not pre:
+                self._lane = 3                                                          # triplet queries
+                triplet_queries(L, hbc)
             self._lane = 0
             self._join(prog, (3,))
             a = L.TB
@@ -420,8 +444,9 @@ class Engine:
                 heads[0](hbn)
             # ---- node update over bond edges (:284)                                   [lane 2]
             self._lane = 2
-            self._gemm(prog, hbc, 128, L.NB.W_hb, w.CsB, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
-            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB, buf=1)
+            if not pre:
+                bond_node_rows(L, hbc)
+            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=1)
             # ---- node update over knn edges (:281), then h' = h + lin_node(aggE + aggB) (:288)   [lane 1]
             self._lane = 1
             self._query_gemm(prog, L.NE, w.Y1, 0, both, 0)
@@ -447,12 +472,22 @@ class Engine:
             # forked from lane 0, which has just seen h' and Y2: a lane-2-waits-lane-1 edge after lane 1 waited on lane 2 crashes
             # hipGraph capture, PG_GRAPH=1)
             qlane = 2 if last else 3
-            self._fork(prog, (qlane,))
+            self._fork(prog, (2, 3) if (ahead and li + 1 < n_layers) else (qlane,))
             self._lane = qlane
             self._query_gemm(prog, L.PB, w.Y2, 5 * 128, lig, 1)
             q_done = self._record(prog, qlane)         # (this point of the lane: the node head below is not waited for)
             if last:
                 heads[1](hn)                           # lane 2 has nothing else left in this step: the node head takes it
+            elif ahead and li + 1 < n_layers:
+                # ---- the NEXT layer's products that do not depend on the new coordinates: its first-layer blocks (h' is final:
+                #      every reader of this layer's Y1 has run), its triplet queries and bond-node rows (h_bond' is final, the
+                #      triplet kernel has read qT): they fill lane 2 during this layer's position updates instead of standing in
+                #      front of the next triplet kernel.  (Forked from lane 0 like the node head, for the same reason.)
+                Ln = pk.layers[li + 1]
+                self._lane = 2
+                first_layer_gemm(Ln, hn)
+                triplet_queries(Ln, hbn)
+                bond_node_rows(Ln, hbn)
             self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0

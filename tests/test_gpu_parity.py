@@ -706,6 +706,8 @@ def test_engine_variants_agree(model):
         for _ in range(6):
             again = [o.cpu() for o in model(**dev_inp)[:3]]
             assert all(torch.equal(a, b) for a, b in zip(base, again))
+    layer_by_layer = run({'PG_LAYER_AHEAD': '0'})     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
+    assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
     two_launches = run({'PG_KNN_MERGE': '0'})         # ligand / pharmacophore targets of a knn sub-layer as two launches: same bits per node
     assert all(torch.equal(a, b) for a, b in zip(base, two_launches))
     for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run(gemm_mode=0)):
