@@ -104,6 +104,27 @@ def test_gemm_against_torch(M, N, K1, K2):
         assert rel_err(Y.cpu(), ref) < 1e-5
 
 
+def test_tiled_gemm_walks_row_blocks_beyond_grid_y():
+    """The tiled kernel keeps its row blocks on grid.y (<= 65 535): a product with more than 65 535 x 128 rows walks them with a
+    stride instead of failing to launch (such very tall shapes reach it when the streaming kernel's 32-bit offsets do not hold)."""
+    from phoregen_amd import hip
+    lib = hip.lib()
+    M, K, N = 65535 * 128 + 300, 8, 4
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    W, b = torch.randn(N, K, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    Y = torch.full((M, N), float('nan'), device=DEV)
+    p = hip.PgGemm()
+    p.X, p.ldx, p.K1, p.W, p.ldw, p.bias = X.data_ptr(), K, K, W.data_ptr(), K, b.data_ptr()
+    p.out_scale, p.act, p.Y, p.ldy, p.M, p.N = 1.0, hip.ACT_NONE, Y.data_ptr(), N, M, N
+    hip.check(lib.pg_gemm(C.byref(p), hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y).all()
+    for sl in (slice(0, 1000), slice(65535 * 128 - 500, 65535 * 128 + 300), slice(4_000_000, 4_001_000)):
+        ref = X[sl].double() @ W.double().t() + b.double()
+        assert rel_err(Y[sl].cpu(), ref.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize('M,N,gather,bias,K1,K2', [
     (64, 128, True, True, 128, 0), (100, 256, False, True, 128, 0), (4096 + 13, 128, True, False, 128, 0),
     (9001, 256, True, True, 128, 0), (64 * 130 + 63, 256, False, False, 128, 0), (203720, 128, True, True, 128, 0),

@@ -154,3 +154,30 @@ def test_config4_full_batch_equals_single_graph_runs(model):
                 ref = make_oracle(0).forward(**one)
                 errs = [rel_err(alone[i], ref[i]) for i in range(3)]
                 assert max(errs) <= 2e-5, errs
+
+
+def test_guidance_normalisation_of_a_tail_batch(model):
+    """sample_job_shard(guidance_norm=...): the guidance energies are means over the graphs of a call.  5 graphs in batches of 4
+    leave a tail batch of one graph: with 'batch_size' (default, partition-invariant) that graph is sampled as
+    `guidance_batch=4`, with 'actual' (the reference loop's behaviour for its last batch, sample_all.py:88) as `guidance_batch=1`
+    -- and the two differ (a stronger drift in the second)."""
+    from phoregen_amd.parallel import sample_job_shard
+    job = _job(n_phores=2, samples=3, seed=11)
+    opt = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}]
+    ids = torch.arange(5)
+    steps = 6
+    by_size = sample_job_shard(model, job, ids, batch_size=4, seed=7, num_steps=steps, pos_guidance_opt=opt)
+    actual = sample_job_shard(model, job, ids, batch_size=4, seed=7, num_steps=steps, pos_guidance_opt=opt, guidance_norm='actual')
+    n4 = int(job.num_atoms[:4].sum())
+    # the first (full) batch is the same in both (the guidance kernel's per-graph means are atomic sums: equal up to their order)
+    assert float((by_size[1][:n4] - actual[1][:n4]).abs().max()) <= 1e-6 * max(1.0, float(actual[1].abs().max()))
+    gid = torch.tensor([4])
+    hp, pp, pn, bp, na, centers = job.batch_inputs(gid)
+    for norm, got in ((4, by_size), (1, actual)):
+        r = model.sample_batch(hp, pp, pn, bp, na, centers, pos_guidance_opt=opt, rng='device', seed=7, return_traj=False,
+                               num_steps=steps, graph_ids=gid, guidance_batch=norm)
+        assert torch.equal(r['pred'][0].argmax(-1), got[0][n4:].argmax(-1))
+        assert float((r['pred'][1] - got[1][n4:]).abs().max()) <= 1e-6 * max(1.0, float(got[1].abs().max()))
+    assert float((by_size[1][n4:] - actual[1][n4:]).abs().max()) > 1e-6
+    with pytest.raises(ValueError):
+        sample_job_shard(model, job, ids, batch_size=4, guidance_norm='mean')
