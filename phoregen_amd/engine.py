@@ -42,6 +42,7 @@ class Engine:
         self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
         self.group_knn = os.environ.get('PG_KNN_GROUP', '1') != '0'            # neighbour slots partitioned by source kind
         self.merge_knn_lists = os.environ.get('PG_KNN_MERGE', '1') != '0'      # ligand + pharmacophore targets of a knn sub-layer in one launch
+        self.merge_knn_always = os.environ.get('PG_KNN_MERGE', '1') == '2'     # ... also below the batch size where it pays (tests)
         # the next layer's first-layer blocks, triplet queries and bond-node rows (everything in front of its triplet kernel that does
         # not depend on the new coordinates) run on lane 2 during this layer's position updates
         self.layer_ahead = os.environ.get('PG_LAYER_AHEAD', '1') != '0'
@@ -249,7 +250,8 @@ class Engine:
         # fused knn form with two target lists (ligand + pharmacophore targets, different feature weights): ONE launch, the
         # persistent workgroups split between the lists in proportion to their sizes (PgSegAttn.seg_ids2)
         merged = fused and knn and len(h_dst_lists) == 2 and self.merge_knn_lists and all(n > 0 for _, n, _ in h_dst_lists) and \
-            sum(n for _, n, _ in h_dst_lists) >= 3 * 256 * 12      # (>= 3 node rounds of the persistent grid; smaller batches: measured slower)
+            (self.merge_knn_always or sum(n for _, n, _ in h_dst_lists) >= 3 * 256 * 12)   # (>= 3 node rounds of the persistent grid;
+                                                                                           #  smaller batches: measured slower)
         lists = [h_dst_lists[0]] if merged else h_dst_lists
         for seg_ids, n_seg, is_lig in lists:
             if not fused:

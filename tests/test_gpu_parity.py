@@ -729,8 +729,16 @@ def test_engine_variants_agree(model):
             assert all(torch.equal(a, b) for a, b in zip(base, again))
     layer_by_layer = run({'PG_LAYER_AHEAD': '0'})     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
     assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
-    two_launches = run({'PG_KNN_MERGE': '0'})         # ligand / pharmacophore targets of a knn sub-layer as two launches: same bits per node
-    assert all(torch.equal(a, b) for a, b in zip(base, two_launches))
+    two_launches = run({'PG_KNN_MERGE': '0'})         # ligand / pharmacophore targets of a knn sub-layer as two launches ...
+    one_launch = run({'PG_KNN_MERGE': '2'})           # ... or as one launch with the workgroups split between the lists (the default only
+    assert all(torch.equal(a, b) for a, b in zip(base, two_launches))     # from ~60 graphs up): same bits per node either way
+    assert all(torch.equal(a, b) for a, b in zip(base, one_launch))
+    old_dbg = hip.lib().pg_debug_force_generic_seg(1)  # the one-pass fallback takes a two-list call list after list
+    try:
+        generic_two_lists = run({'PG_KNN_MERGE': '2'})
+    finally:
+        hip.lib().pg_debug_force_generic_seg(old_dbg)
+    assert max(rel_err(a, b) for a, b in zip(generic_two_lists, base)) <= 2e-5
     for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run(gemm_mode=0)):
         assert max(rel_err(a, b) for a, b in zip(variant, base)) <= 2e-5
 

@@ -1,8 +1,11 @@
 """Does the kind of kernel that runs BEFORE the triplet kernel change the triplet kernel's own duration (clock / power state)?
 Per repetition: N GEMM launches of one kind (a bond-row product, 203 720 x 256 x 128), then the triplet kernel between two events.
-Prints the mean triplet time after: nothing, fp32-MFMA GEMMs, split-bf16 GEMMs, an HBM copy of the same bytes."""
+Prints the mean triplet time after: nothing, fp32-MFMA GEMMs, split-bf16 GEMMs, an HBM copy of the same bytes.
+NEEDS a library built WITH the experiment kernel gemm_emu_bf16x6.hip (commit 3a8c0f7 of this repository had it as the default; there
+`pg_debug_gemm_streaming(2)` selected the fp32-MFMA streaming kernel): with the product library both GEMM kinds are the fp32 kernel.
+Recorded output: profiles/r03_micro_clock_after_bf16_mfma.txt."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from bench import ligphore_workload
