@@ -145,11 +145,26 @@ class BatchPlan:
         self._cpu_sig = (bn, bp, ei_ref)
         self.ws = None   # engine workspace, attached lazily
 
+    @staticmethod
+    def _ident(*tensors):
+        """Identity of the caller's index tensors: same storage, same shape, no in-place write since."""
+        return tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, str(t.device), t.dtype) for t in tensors)
+
     def matches(self, batch_node, batch_phore, edge_index):
+        """Is this the topology the plan was built for?  The same tensor objects as last time (same storage, unmodified) answer
+        without touching their contents; otherwise the contents are compared on the host -- for device tensors that is a
+        device -> host copy which WAITS for everything enqueued before it (a training loop that calls compute_loss on the same
+        batch object every step would otherwise drain the GPU once per step: 142 ms of a 258 ms step were spent in that wait)."""
+        ident = self._ident(batch_node, batch_phore, edge_index)
+        if ident == getattr(self, '_last_ident', None):
+            return True
         bn, bp, ei = self._cpu_sig
-        return (batch_node.numel() == bn.numel() and batch_phore.numel() == bp.numel() and
+        same = (batch_node.numel() == bn.numel() and batch_phore.numel() == bp.numel() and
                 edge_index.shape == ei.shape and torch.equal(batch_node.cpu(), bn) and
                 torch.equal(batch_phore.cpu(), bp) and torch.equal(edge_index.cpu(), ei))
+        if same:
+            self._last_ident = ident
+        return same
 
 
 def make_edge_data(num_atoms, device=None):

@@ -220,7 +220,9 @@ class UnfoldFn(torch.autograd.Function):
         if idl is None:
             sel += 1.0
         else:
-            sel[idl] = 1.0
+            # (index_fill_, not `sel[idl] = 1.0`: indexed assignment of a Python scalar uploads it with a BLOCKING host -> device
+            # copy that waits for everything enqueued before it -- 22 such waits were 149 ms of a 258 ms training step)
+            sel.index_fill_(0, idl, 1.0)
         g3 = g3 * sel
         gswn = (g3 * b2.view(1, 16, 8)).sum(-1)
         gb2 = (g3 * swn.view(-1, 16, 1)).sum(0).reshape(128)
