@@ -80,9 +80,12 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
   const float* const my_wf_k = list2 ? p.Wf_k2 : p.Wf_k;
   const float* const my_wf_v = list2 ? p.Wf_v2 : p.Wf_v;
   for (int i = tid; i < 128; i += THREADS) { bpk[i] = p.ln_bk[i]; bpv[i] = p.ln_bv[i]; }
-  for (int i = tid; i < NSTEP * 512; i += THREADS) { wf_k[i] = my_wf_k[i]; wf_v[i] = my_wf_v[i]; }
+  for (int i = tid; i < NSTEP * 128; i += THREADS) {       // (16-byte copies: the fill is what a small-batch launch waits for)
+    reinterpret_cast<f4*>(wf_k)[i] = reinterpret_cast<const f4*>(my_wf_k)[i];
+    reinterpret_cast<f4*>(wf_v)[i] = reinterpret_cast<const f4*>(my_wf_v)[i];
+  }
   if constexpr (POS) {
-    for (int i = tid; i < 2048; i += THREADS) w2xv[i] = p.W2xv_l[i];
+    for (int i = tid; i < 512; i += THREADS) reinterpret_cast<f4*>(w2xv)[i] = reinterpret_cast<const f4*>(p.W2xv_l)[i];
     for (int i = tid; i < 16; i += THREADS) b2xv[i] = p.b2xv[i];
   }
   if constexpr (FUSED) {
@@ -503,6 +506,11 @@ bool node_attn_fused_request(const PgSegAttn* p) {
 }
 
 int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  // the weight tables go to LDS in 16-byte pieces
+  if ((((size_t)p->Wf_k | (size_t)p->Wf_v | (size_t)p->Wf_k2 | (size_t)p->Wf_v2 | (size_t)p->W2xv_l) & 15) != 0) {
+    set_error("pg_seg_attn: Wf_k / Wf_v / W2xv_l must be 16-byte aligned");
+    return PG_ERR_ARG;
+  }
   return node_attn_fused_request(p) ? launch_node_attn_t<true>(t, p, st) : launch_node_attn_t<false>(t, p, st);
 }
 

@@ -661,6 +661,23 @@ def test_full_size_batch_equals_single_graph_runs(model, oracle):
     assert all(torch.isfinite(o).all() for o in out)
 
 
+def test_mid_size_batch_equals_single_graph_runs(model):
+    """70 graphs: the batch size at which BOTH size-dependent schedule choices of the engine are on (one launch for the two knn
+    target lists from ~60 graphs up, next-layer products one layer ahead below ~100 graphs): slices of the batched forward equal
+    single-graph forwards, as at full size."""
+    inp, na, nph = _headline_inputs(70, seed=77)
+    with torch.no_grad():
+        out = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in inp.items()})[:3]]
+        eng = model._engine
+        assert eng.layer_ahead and eng.plan.n_bond < 160000 and eng.plan.n_ctx >= 3 * 256 * 12     # both choices active
+        for gi in (0, 33, 69):
+            one, (n0, n, e0, e) = _slice_graph(inp, na, nph, gi)
+            alone = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in one.items()})[:3]]
+            assert rel_err(out[0][n0:n0 + n], alone[0]) <= 1e-6
+            assert rel_err(out[1][n0:n0 + n], alone[1]) <= 1e-6
+            assert rel_err(out[2][e0:e0 + e], alone[2]) <= 1e-6
+
+
 def test_knn_group_by_kind_is_a_stable_partition(model):
     """pg_knn_group_by_kind: per node the valid neighbour slots become [ligand sources..., pharmacophore sources...], each kind
     in its original (distance) order, the gate values move with their neighbours, slots past the degree are untouched."""
