@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
-from .packing import HEAD_SCALE, ModelPack
+from .packing import HEAD_SCALE, NODE1_PARTS, NODE2_PARTS, PHORE_PARTS, ModelPack
 
 _SMEAR_OFF = (0., 1., 1.25, 1.5, 1.75, 2., 2.25, 2.5, 2.75, 3., 3.5, 4., 4.5, 5., 5.5, 6., 7., 8., 9., 10.)
 
@@ -78,6 +78,47 @@ class LinearFn(torch.autograd.Function):
 
 def linear(X, W, b=None):
     return LinearFn.apply(X, W, b)
+
+
+class ColumnBlocksFn(torch.autograd.Function):
+    """Y = X W^T + b computed ONCE for the fused first-layer columns of a layer, handed out as the consumers' column blocks
+    (views with the wide row stride: every kernel of the C ABI takes a leading dimension).  The backward assembles the
+    blocks' gradients into one wide buffer (one concatenation) and runs ONE data-gradient and ONE weight-gradient product --
+    instead of a GEMM pair per consumer plus the accumulation of their input gradients (9 consumers of h per layer)."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, sizes):
+        X, W = _rowmajor(X), _rowmajor(W)
+        Y = torch.empty(X.shape[0], W.shape[0], dtype=torch.float32, device=X.device)
+        if X.shape[0]:
+            _gemm_raw(X, W, Y, b.contiguous())
+        ctx.save_for_backward(X, W)
+        ctx.sizes = sizes
+        return Y.split(sizes, 1)
+
+    @staticmethod
+    def backward(ctx, *gYs):
+        X, W = ctx.saved_tensors
+        M, (N, K) = X.shape[0], W.shape
+        gY = torch.cat([g if g is not None else torch.zeros(M, n, dtype=torch.float32, device=X.device)
+                        for g, n in zip(gYs, ctx.sizes)], 1)
+        gX = torch.empty_like(X)
+        if M:
+            _gemm_raw(gY, W.t().contiguous(), gX)
+        buf = torch.zeros(N * K + N, dtype=torch.float32, device=W.device)
+        gW, gb = buf[:N * K].view(N, K), buf[N * K:]
+        hip.check(hip.lib().pg_gemm_wgrad(gY.data_ptr(), gY.stride(0), X.data_ptr(), X.stride(0), M, N, K,
+                                          gW.data_ptr(), gW.stride(0), gb.data_ptr(), _st()), 'pg_gemm_wgrad')
+        return gX, gW, gb, None
+
+
+def column_blocks(X, W, b, sizes):
+    """blk(c0, c1) -> columns [c0, c1) of Y = X W^T + b; the ranges are the consecutive ones of the given sizes."""
+    out, c0 = {}, 0
+    for y, n in zip(ColumnBlocksFn.apply(X, W, b, tuple(sizes)), sizes):
+        out[(c0, c0 + n)] = y
+        c0 += n
+    return lambda c0, c1: out[(c0, c1)]
 
 
 class LinearGatherAddFn(torch.autograd.Function):
@@ -436,7 +477,7 @@ class TrainForward:
         h_ctx = torch.zeros(n, h_phore.shape[1], dtype=torch.float32, device=self.dev).index_copy(0, p.phore2ctx_long, h_phore.float())
         x_ctx = torch.zeros(n, 3, dtype=torch.float32, device=self.dev).index_copy(0, p.phore2ctx_long, pos_phore.float())
         hp = linear(h_ctx, pk.W_pe, pk.b_pe)
-        Yp = lambda c0, c1: linear(hp, pk.W_ph[c0:c1], pk.b_ph[c0:c1])
+        Yp = column_blocks(hp, pk.W_ph, pk.b_ph, PHORE_PARTS)
         max_rows = int(p.g_nph.max()) if p.n_graphs else 0
         enc = self._attention(hip.SEG_PHORE, pk.PH, Yp, x_ctx, [(p.phore2ctx, p.n_phore, False)], max_rows=max_rows,
                               need_gx=False)
@@ -510,11 +551,10 @@ class TrainForward:
             G = gaussian_smearing((x.index_select(0, bsrc) - x.index_select(0, bdst)).pow(2).sum(-1).clamp(min=1e-24).sqrt())   # [E,20]
 
             # first-layer blocks of the three feature sub-layers (15 x 128 columns of W_node1), one GEMM per consumer
-            if os.environ.get('PG_WIDE_GEMM') == '1':      # A/B knob: one wide GEMM + column views (padded slice gradients)
-                Y1w = linear(h, L.W_node1, L.b_node1)
-                Y1 = lambda c0, c1: Y1w[:, c0:c1]
-            else:
-                Y1 = lambda c0, c1: linear(h, L.W_node1[c0:c1], L.b_node1[c0:c1])
+            if os.environ.get('PG_WIDE_GEMM', '1') != '0':      # one wide GEMM, one adjoint pair (ColumnBlocksFn)
+                Y1 = column_blocks(h, L.W_node1, L.b_node1, NODE1_PARTS)
+            else:                                               # A/B knob: one GEMM (and one adjoint pair) per consumer
+                Y1 = lambda c0, c1: linear(h, *L.node1_parts[(c0, c1)])
             aggE = self._attention(hip.SEG_KNN_NODE, L.NE, Y1, x, both, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
             CsB = linear_gather_add(hb, L.NB.W_hb, Y1(7 * 128, 9 * 128), p.bond_src)
             aggB = self._attention(hip.SEG_BOND_NODE, L.NB, lambda c0, c1: Y1(640 + c0, 640 + c1), x, lig, Ysrc=CsB,
@@ -523,7 +563,7 @@ class TrainForward:
             a = L.TB
             P = linear_gather_add(torch.cat([hb, G], -1), a.W_hbg, Y1(10 * 128, 12 * 128), p.bond_src,
                                   Y1(12 * 128, 14 * 128), p.bond_dst)
-            Q = linear(G, torch.cat([a.Wg2_k.t(), a.Wg2_v.t()], 0))                    # smear(d_ji) columns, per segment
+            Q = linear(G, a.W_g2)                                                      # smear(d_ji) columns, per segment
             qhid = linear_gather_add(hb, a.W_q_hb, Y1(14 * 128, 15 * 128), p.bond_dst)
             qT = linear(LnReluFn.apply(qhid, a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
             U = FoldFn.apply(qT, a.W2k_l, None, E)
@@ -537,11 +577,10 @@ class TrainForward:
             hb_new = hb + UnfoldFn.apply(S, swn, a.W2v_l, a.b2v, None, E)
             h_new = h + linear(aggE + aggB, L.W_lin, L.b_lin)
             # coordinate updates from h', h_bond' and the old geometry (uni_denoiser.py:291-296)
-            if os.environ.get('PG_WIDE_GEMM') == '1':
-                Y2w = linear(h_new, L.W_node2, L.b_node2)
-                Y2 = lambda c0, c1: Y2w[:, c0:c1]
+            if os.environ.get('PG_WIDE_GEMM', '1') != '0':
+                Y2 = column_blocks(h_new, L.W_node2, L.b_node2, NODE2_PARTS)
             else:
-                Y2 = lambda c0, c1: linear(h_new, L.W_node2[c0:c1], L.b_node2[c0:c1])
+                Y2 = lambda c0, c1: linear(h_new, *L.node2_parts[(c0, c1)])
             dxe = self._attention(hip.SEG_KNN_POS, L.PE, Y2, x, lig, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
             CsB2 = linear_gather_add(hb_new, L.PB.W_hb, Y2(7 * 128, 9 * 128), p.bond_src)
             dxb = self._attention(hip.SEG_BOND_POS, L.PB, lambda c0, c1: Y2(640 + c0, 640 + c1), x, lig, Ysrc=CsB2,
