@@ -47,5 +47,23 @@ step()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print('step enqueue time %.1f ms, + %.1f ms until the device is idle' % ((t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3))
+# the same step by phase: host time to enqueue each phase, and how far behind the device is when the phase has been enqueued
+ph = []
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+opt.zero_grad(set_to_none=True)
+loss, _ = model.compute_loss(batch)
+ph.append(('forward', time.perf_counter()))
+loss.backward()
+ph.append(('backward', time.perf_counter()))
+opt.step()
+ph.append(('adam', time.perf_counter()))
+torch.cuda.synchronize()
+t_end = time.perf_counter()
+prev = t0
+for name, t in ph:
+    print('  %-9s enqueued in %6.1f ms (host)' % (name, (t - prev) * 1e3))
+    prev = t
+print('  device idle %.1f ms after the last enqueue' % ((t_end - prev) * 1e3))
 for k, (n, dt) in sorted(slow.items(), key=lambda kv: -kv[1][1]):
     print('%8.1f ms  %3d x  %s' % (dt * 1e3, n, k))
