@@ -727,16 +727,26 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           for (int r = 0; r < 4; ++r) L.sGF[(4 * g + r) * FS + 16 * ft + m] = gfeat[ft][r];
         wave_lds_sync();
       }
+      // knn: d d = sum_i d feat[i] * smear_i(d) * (off_i - d).  The smear values are the row's features and already sit in the
+      // feature tile; the 20 terms are spread over the row's 4 lanes (g = 0..3) and added up across them
+      float gd_row = 0.f;
+      if constexpr (T::KNN) {
+        const int base = geo.src_lig ? 0 : 20;
+        const float* gf = L.sGF + m * FS + base;
+        const float* ff = L.sF + m * FS + base;
+#pragma unroll
+        for (int i5 = 0; i5 < 5; ++i5) {
+          const int i = 4 * i5 + g;
+          gd_row = fmaf(gf[i] * ff[i], kSmearOff[i] - geo.d, gd_row);
+        }
+        gd_row += __shfl_xor(gd_row, 16);
+        gd_row += __shfl_xor(gd_row, 32);
+      }
       if (g == 0 && rk.valid && gr.gx && !PG_ABL(1)) {
         const float* gf = L.sGF + m * FS;
         float grel[3] = {0.f, 0.f, 0.f};
         if constexpr (T::KNN) {
-          const int base = geo.src_lig ? 0 : 20;
-          float gd = 0.f;
-          for (int i = 0; i < 20; ++i) {
-            const float tt = geo.d - kSmearOff[i];
-            gd += gf[base + i] * expf(-0.5f * tt * tt) * (-tt);
-          }
+          const float gd = gd_row;
           const float sc = geo.d > 0.f ? gd / geo.d : 0.f;
           const float g0 = gf[40], g1 = gf[41], g2 = gf[42];
           float gns[3], gnd[3];
