@@ -226,6 +226,82 @@ def test_folded_layernorm_rewrite_is_exact_for_every_weight_profile(profile):
     assert float((mine - ref).abs().max()) <= 1e-9 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize('profile', ['default', 'gamma_signed'])
+def test_stacked_packing_equals_layer_by_layer_packing(profile):
+    """The training path packs the six layers at once (packing.LayerPack on a list of prefixes: stacked parameters, one pass of
+    tensor ops) and differentiates through the packing; the sampler packs layer by layer.  Both give the same kernel-layout
+    tensors (to rounding: a batched product replaces a matrix-vector one), the per-layer views are what the kernels can read
+    (unit inner stride, contiguous 128-row slabs), and the gradient of a random functional of ALL packed tensors reaches the
+    parameters identically through either route."""
+    m = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0, profile=profile).double()
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and 'transition' not in k) for k, v in m.state_dict().items()}
+    ref = packing.ModelPack({k: v.detach() for k, v in sd.items()}, 6)
+    one = packing.ModelPack(sd, 6, detach=False)
+    gen = torch.Generator().manual_seed(0)
+    pairs = []
+
+    def walk(a, b, path):
+        if torch.is_tensor(a):
+            assert a.shape == b.shape, path
+            assert torch.allclose(a, b.detach(), rtol=1e-12, atol=1e-14), path
+            assert b.stride(-1) == 1 or b.numel() <= 1, path
+            pairs.append((path, b))
+        elif isinstance(a, dict):
+            for k in a:
+                walk(a[k], b[k], f'{path}[{k}]')
+        elif isinstance(a, (tuple, list)):
+            for i, (x, y) in enumerate(zip(a, b)):
+                walk(x, y, f'{path}[{i}]')
+        elif hasattr(a, '__dict__'):
+            for k, v in vars(a).items():
+                if hasattr(b, k) and getattr(b, k) is not None:
+                    walk(v, getattr(b, k), f'{path}.{k}')
+    ref.gate = None
+    walk(ref, one, 'pk')
+    assert len(pairs) > 300
+    for L in one.layers:
+        assert L.W_node1.shape == (1920, 128) and L.W_node1.is_contiguous() and L.W_node2.shape == (1280, 128)
+        for (c0, c1), (w, b) in list(L.node1_parts.items()) + list(L.node2_parts.items()):
+            assert w.shape == (c1 - c0, 128) and w.is_contiguous() and b.shape == (c1 - c0,)
+    # gradient through the stacked route == gradient through the layer-by-layer route (same random cotangents)
+    cot = {path: torch.randn(t.shape, generator=gen, dtype=t.dtype) for path, t in pairs if t.requires_grad}
+    names = [k for k, v in sd.items() if v.requires_grad]
+    sd2 = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in sd.items()}
+    two = packing.ModelPack.__new__(packing.ModelPack)
+    two.layers = [packing.LayerPack(sd2, f'denoiser.base_block.{l}') for l in range(6)]
+    two.PH, b_ph = packing.pack_phore(sd2)
+    two.W_ph, two.b_ph = packing.fuse_blocks(b_ph)
+    two.ph_parts = packing._parts(two.W_ph, two.b_ph, packing.PHORE_PARTS)
+    pairs2 = {}
+
+    def walk2(b, path):
+        if torch.is_tensor(b):
+            pairs2[path] = b
+        elif isinstance(b, dict):
+            for k in b:
+                walk2(b[k], f'{path}[{k}]')
+        elif isinstance(b, (tuple, list)):
+            for i, y in enumerate(b):
+                walk2(y, f'{path}[{i}]')
+        elif hasattr(b, '__dict__'):
+            for k, v in vars(b).items():
+                walk2(v, f'{path}.{k}')
+    walk2(two, 'pk')
+    loss2 = sum((pairs2[path] * c).sum() for path, c in cot.items() if path in pairs2)
+    missing = [path for path in cot if path not in pairs2]
+    assert all(not path.startswith('pk.layers') and not path.startswith('pk.PH') for path in missing), missing[:5]
+    loss1 = sum((t * cot[path]).sum() for path, t in pairs if t.requires_grad and path in pairs2)
+    g_one = torch.autograd.grad(loss1, [sd[k] for k in names], allow_unused=True)
+    g_two = torch.autograd.grad(loss2, [sd2[k] for k in names], allow_unused=True)
+    n_checked = 0
+    for k, a, b in zip(names, g_one, g_two):
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert torch.allclose(a, b, rtol=1e-9, atol=1e-12), k
+            n_checked += 1
+    assert n_checked > 400
+
+
 def test_phore_parser_matches_reference(tmp_path):
     """phoregen_amd.data.parse_phore_file against datasets/get_phore_data.py run on a shipped .phore file."""
     from phoregen_amd.data import parse_phore_file
