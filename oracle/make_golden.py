@@ -297,18 +297,26 @@ def g_posterior(model):
     save('g_posterior', **arrays)
 
 
-def g6_compute_loss(model, name, seed, n_atoms, n_phore):
+def g6_compute_loss(model, name, seed, n_atoms, n_phore, bond_len_loss=False):
     """G6: the reference's compute_loss (diffusion.py:249-352) + backward on a synthetic HeteroData batch; the draws of
-    sample_time / add_noise are recorded (torch.randint, Tensor.normal_, torch.rand_like)."""
+    sample_time / add_noise are recorded (torch.randint, Tensor.normal_, torch.rand_like).  `bond_len_loss`: the run has the
+    config flag on (diffusion.py:286-290,333,341) and the molecule's bonds `edge_index` = the directed pairs with a bond class > 0."""
     from torch_geometric.data import Batch
     from oracle.make_inputs import synthetic_train_batch
     d = synthetic_train_batch(seed, n_atoms, n_phore)
+    if bond_len_loss:
+        d['edge_index'] = d['f_edge_index'][:, d['f_edge_attr'] > 0]
+        assert d['edge_index'].size(1) >= 8
     data = Batch()
     object.__setattr__(data, 'num_graphs', len(n_atoms))
     data['ligand'].x, data['ligand'].pos = d['ligand_x'], d['ligand_pos']
     data['ligand'].batch, data['ligand'].ptr = d['ligand_batch'], d['ligand_ptr']
     e = data['ligand', 'ligand']
     e.f_edge_index, e.f_edge_attr, e.f_edge_attr_batch = d['f_edge_index'], d['f_edge_attr'], d['f_edge_batch']
+    if bond_len_loss:
+        e.edge_index = d['edge_index']
+    flag_before = model.bond_len_loss
+    model.bond_len_loss = bond_len_loss
     ph = data['phore']
     ph.x, ph.pos, ph.norm, ph.batch = d['phore_x'], d['phore_pos'], d['phore_norm'], d['phore_batch']
     seed_all(seed)
@@ -326,6 +334,7 @@ def g6_compute_loss(model, name, seed, n_atoms, n_phore):
             loss, info = model.compute_loss(data)
     finally:
         torch.Tensor.normal_ = orig_normal
+        model.bond_len_loss = flag_before
     loss.backward()
     draws = {n: [t for (nn_, t) in tape.tape if nn_ == n] for n in ('randint', 'rand_like')}
     assert len(draws['randint']) == 1 and len(draws['rand_like']) == 2 and len(normal_draws) == 1, \
@@ -393,6 +402,10 @@ def profile_fixtures(profile):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'len':        # only the bond_len_loss fixture (added in round 3)
+        model, cfg = build_model(seed=0)
+        g6_compute_loss(model, 'g6_loss_len', seed=67, n_atoms=[7, 10, 5], n_phore=[9, 14, 6], bond_len_loss=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'profiles':
         for prof in ('gamma_signed', 'trained_like'):
             profile_fixtures(prof)
@@ -411,6 +424,7 @@ if __name__ == '__main__':
     g5_sample(model, 'g5_sample_full25', seed=2034, n_atoms=[8, 6], n_steps=25, t_total=25)
     g6_compute_loss(model, 'g6_loss_a', seed=61, n_atoms=[6, 9], n_phore=[7, 12])
     g6_compute_loss(model, 'g6_loss_b', seed=64, n_atoms=[11, 4, 8], n_phore=[23, 9, 15])
+    g6_compute_loss(model, 'g6_loss_len', seed=67, n_atoms=[7, 10, 5], n_phore=[9, 14, 6], bond_len_loss=True)
     g5_sample(model, 'g5_sample_guid3', seed=2035, n_atoms=[6, 7], n_steps=3, t_total=3,
               guidance=[{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}])
     for prof in ('gamma_signed', 'trained_like'):

@@ -411,12 +411,13 @@ class Oracle:
         return v, x[mask_l], bond, self.atom_count(hp, batch_phore, h_phore, B)
 
     # ---- training objective (diffusion.py:249-352) with an explicit noise source ----
-    def compute_loss(self, b, rng, loss_weight=(1., 100., 100.), count_factor=1.):
+    def compute_loss(self, b, rng, loss_weight=(1., 100., 100.), count_factor=1., bond_len_loss=False):
         """`b`: dict with the Appendix-G fields (ligand_x [N] int64, ligand_pos, ligand_batch, ligand_ptr,
         f_edge_index [2,E] (any order of the complete directed graph), f_edge_attr [E], f_edge_batch, phore_*).
         `rng` provides .randint(high, n), .randn(shape), .rand(shape) in the reference's draw order:
         sample_time (diffusion.py:138-145), pos noise (transition.py:28-41), node Gumbel uniforms, edge Gumbel uniforms
-        (transition.py:245-263, common.py:425-431).  Returns (loss, dict)."""
+        (transition.py:245-263, common.py:425-431).  `bond_len_loss` (config flag, diffusion.py:286-290,333,341): the MSE of the
+        predicted against the true lengths of the molecule's bonds `b['edge_index']` [2, n_bonds] joins the loss.  Returns (loss, dict)."""
         B = int(b['ligand_ptr'].numel() - 1)
         ts = rng.randint(self.T, B // 2 + 1)
         t = torch.cat([ts, self.T - ts - 1])[:B]
@@ -451,6 +452,12 @@ class Oracle:
         true = ((b['ligand_ptr'][1:] - b['ligand_ptr'][:-1]).float() - self.min_atom) / (self.max_atom - self.min_atom)
         loss_count = qd_loss(true.unsqueeze(-1), c_l, c_u, factor=count_factor)
         loss = loss_pos + loss_node + loss_edge + loss_count
+        if bond_len_loss:                                                                      # diffusion.py:286-290
+            src, dst = b['edge_index']
+            true_len = torch.norm(pos0[src] - pos0[dst], dim=-1)
+            pred_len = torch.norm(pred_pos[src] - pred_pos[dst], dim=-1)
+            loss_len = F.mse_loss(pred_len, true_len)
+            loss = loss + loss_len                                                             # diffusion.py:333
 
         def acc(true_cls, logits, batch):                                                      # common.py:284-297
             bad = torch.zeros(B).index_add(0, batch, (logits.argmax(-1) != true_cls).float())
@@ -458,6 +465,8 @@ class Oracle:
         info = dict(loss=loss.item(), loss_pos=loss_pos.item(), loss_node=loss_node.item(), loss_count=loss_count.item(),
                     loss_edge=loss_edge.item(), node_acc=acc(b['ligand_x'], pred_node, bn),
                     edge_acc=acc(b['f_edge_attr'], pred_edge, be))
+        if bond_len_loss:
+            info['loss_len'] = loss_len.item()                                                 # diffusion.py:341
         return loss, info
 
     # ---- sampler (diffusion.py:391-525) with an explicit noise source ----

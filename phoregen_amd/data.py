@@ -46,11 +46,14 @@ class TrainBatch:
     datasets/phoregen.py:356-384 + DataLoader(follow_batch=['f_edge_attr']), run/run.py:96-101)."""
 
     def __init__(self, ligand_x, ligand_pos, ligand_batch, ligand_ptr, f_edge_index, f_edge_attr, f_edge_batch,
-                 phore_x, phore_pos, phore_norm, phore_batch):
+                 phore_x, phore_pos, phore_norm, phore_batch, edge_index=None):
+        """`edge_index` [2, n_bonds]: the molecule's bonds (`data['ligand', 'ligand'].edge_index`), read only by the
+        `bond_len_loss` term of compute_loss (diffusion.py:286-290)."""
         self.num_graphs = int(ligand_ptr.numel() - 1)
+        bonds = {} if edge_index is None else {'edge_index': edge_index}
         self._stores = {'ligand': _Store(x=ligand_x, pos=ligand_pos, batch=ligand_batch, ptr=ligand_ptr),
                         ('ligand', 'ligand'): _Store(f_edge_index=f_edge_index, f_edge_attr=f_edge_attr,
-                                                     f_edge_attr_batch=f_edge_batch),
+                                                     f_edge_attr_batch=f_edge_batch, **bonds),
                         'phore': _Store(x=phore_x, pos=phore_pos, norm=phore_norm, batch=phore_batch)}
 
     def __getitem__(self, key):

@@ -72,10 +72,7 @@ class PhoreDiff(nn.Module):
         self.config, self.data_name = config, data_name
         self.num_node_types = config.num_atom_classes
         self.num_edge_types = config.num_bond_classes
-        self.bond_len_loss = config.bond_len_loss
-        if self.bond_len_loss:
-            raise NotImplementedError('phoregen_amd: bond_len_loss=True (the loss_len term of diffusion.py:286-290,333,341) is '
-                                      'not implemented; both shipped YAMLs set it to False')
+        self.bond_len_loss = config.bond_len_loss          # the loss_len term of compute_loss (diffusion.py:286-290,333,341)
         self.bond_diffusion = config.bond_diffusion
         self.bond_net_type = config.bond_net_type
         self.count_pred_type = config.count_pred_type
@@ -257,6 +254,13 @@ class PhoreDiff(nn.Module):
         true = ((ptr[1:] - ptr[:-1]).float() - self.min_atom) / (self.max_atom - self.min_atom)
         loss_count = self.compute_count_loss(true.unsqueeze(-1), (c_l, c_u))
         loss = loss_pos + loss_node + loss_edge + loss_count
+        loss_len = None
+        if self.bond_len_loss:                                                                 # diffusion.py:286-290,333
+            src, dst = e.edge_index.to(dev)
+            true_len = torch.norm(pos0.index_select(0, src) - pos0.index_select(0, dst), dim=-1)
+            pred_len = torch.norm(pred_pos.index_select(0, src) - pred_pos.index_select(0, dst), dim=-1)
+            loss_len = F.mse_loss(pred_len, true_len)
+            loss = loss + loss_len
 
         def acc(true_cls, logits, batch):                                                      # common.py:284-297
             bad = torch.zeros(B, device=dev).index_add(0, batch, (logits.argmax(-1) != true_cls).float())
@@ -266,7 +270,8 @@ class PhoreDiff(nn.Module):
         # same values, converted when first read, so `loss.backward()` can be enqueued while the forward still runs
         info = _LazyFloats({'loss': loss.detach(), 'loss_pos': loss_pos.detach(), 'loss_node': loss_node.detach(),
                             'loss_count': loss_count.detach(), 'loss_edge': loss_edge.detach(),
-                            'node_acc': acc(x_cls, pred_node.detach(), bn), 'edge_acc': acc(e_cls, pred_edge.detach(), be)})
+                            'node_acc': acc(x_cls, pred_node.detach(), bn), 'edge_acc': acc(e_cls, pred_edge.detach(), be),
+                            **({'loss_len': loss_len.detach()} if loss_len is not None else {})})   # diffusion.py:341
         return loss, info
 
     def compute_count_loss(self, true_norm, pred_count, a=0.05, s=160, nd=15, epsilon=1e-12):

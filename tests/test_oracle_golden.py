@@ -177,11 +177,11 @@ def test_g5_sampler(name):
 
 def _train_batch(g):
     keys = ('ligand_x', 'ligand_pos', 'ligand_batch', 'ligand_ptr', 'f_edge_index', 'f_edge_attr', 'f_edge_batch',
-            'phore_x', 'phore_pos', 'phore_norm', 'phore_batch')
+            'phore_x', 'phore_pos', 'phore_norm', 'phore_batch') + (('edge_index',) if 'edge_index' in g.files else ())
     return {k: t(g[k]) for k in keys}
 
 
-@pytest.mark.parametrize('name', ['g6_loss_a', 'g6_loss_b', 'g6_loss_a_gamma_signed', 'g6_loss_a_trained_like'])
+@pytest.mark.parametrize('name', ['g6_loss_a', 'g6_loss_b', 'g6_loss_a_gamma_signed', 'g6_loss_a_trained_like', 'g6_loss_len'])
 def test_compute_loss_and_gradients_match_reference(name):
     """G6: loss terms and every parameter-gradient norm of the reference's compute_loss + backward
     (diffusion.py:249-352), replaying its recorded draws through the oracle's autograd."""
@@ -192,8 +192,9 @@ def test_compute_loss_and_gradients_match_reference(name):
     for k in names:
         orc.sd[k].requires_grad_(True)
     rng = po.TrainTapeRng(t(g['time_draw']), t(g['pos_noise']), t(g['u_node']), t(g['u_edge']))
-    loss, info = orc.compute_loss(_train_batch(g), rng)
+    loss, info = orc.compute_loss(_train_batch(g), rng, bond_len_loss='edge_index' in g.files)   # g6_loss_len: config flag on
     ref = dict(zip([str(k) for k in g['info_keys']], g['info_vals']))
+    assert set(info) == set(ref)
     assert abs(float(loss) - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
     for k, v in ref.items():
         assert abs(info[k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, info[k], v)
