@@ -198,6 +198,10 @@ typedef struct {
    * split between the two lists in proportion to their sizes, so that the two lists finish together instead of each rounding
    * its own number of node rounds up (one launch instead of two).  n_seg2 = 0: one list. */
   const int* seg_ids2; int n_seg2; const float* Wf_k2; const float* Wf_v2;
+  /* PG_SEG_TRIPLET with tri_iters, optional: persistent workgroups of the staged kernel (0 = one per CU, 256).  A small batch
+   * leaves some CUs to the launches that run beside the triplet kernel on other streams: 16 graphs of the headline shape 3.76 ->
+   * 3.57 ms per step with 200 workgroups (the results do not depend on it: the queue hands out the same segments). */
+  int tri_grid;
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 

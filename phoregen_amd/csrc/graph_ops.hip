@@ -322,7 +322,7 @@ __global__ void atom_count_kernel(const float* s_all, const float* s_l, const ui
 using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
-extern "C" int pg_abi_version(void) { return 4; }
+extern "C" int pg_abi_version(void) { return 5; }
 
 extern "C" int pg_embed_ctx(const PgTopo* t, const float* h_node_pert, const float* pos_pert, const int64_t* time_step,
                             const float* W_node, const float* t_off, const float* t_coeff, const float* h_phore_emb,

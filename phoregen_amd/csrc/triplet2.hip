@@ -464,7 +464,8 @@ template <int THREADS, int MAXT, bool TRAIN = false>
 static int launch_t2(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   const size_t lds = t2_lds_floats() * sizeof(float);
   if (int rc = reserve_lds(reinterpret_cast<const void*>(triplet2_kernel<THREADS, MAXT, TRAIN>), lds, "pg_seg_attn(triplet, staged)")) return rc;
-  hipLaunchKernelGGL((triplet2_kernel<THREADS, MAXT, TRAIN>), dim3(kNumCU), dim3(THREADS), lds, st, *t, *p);
+  const int grid = (p->tri_grid > 0 && p->tri_grid < kNumCU) ? p->tri_grid : kNumCU;      // persistent workgroups pulling from the queue
+  hipLaunchKernelGGL((triplet2_kernel<THREADS, MAXT, TRAIN>), dim3(grid), dim3(THREADS), lds, st, *t, *p);
   return check_launch("pg_seg_attn(triplet, staged)");
 }
 

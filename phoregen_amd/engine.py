@@ -46,6 +46,7 @@ class Engine:
         # the next layer's first-layer blocks, triplet queries and bond-node rows (everything in front of its triplet kernel that does
         # not depend on the new coordinates) run on lane 2 during this layer's position updates
         self.layer_ahead = os.environ.get('PG_LAYER_AHEAD', '1') != '0'
+        self.tri_grid = int(os.environ.get('PG_TRI_GRID', '-1'))               # persistent triplet workgroups (-1: by batch size)
         # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -370,6 +371,10 @@ class Engine:
         # 3.93 -> 3.83 ms, 32 graphs 5.94 -> 5.67, 64 graphs 10.55 -> 10.36, 128 graphs 20.12 -> 20.17 (the triplet kernel then
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
         ahead = self.layer_ahead and self.multi_stream and E < 160000
+        # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
+        # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 200 workgroups, 32 graphs 5.87 -> 5.78 with 224; from 64 graphs
+        # up the full grid is fastest)
+        tri_grid = self.tri_grid if self.tri_grid >= 0 else ((200 if E < 40000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
 
         def first_layer_gemm(L, h_in):
             # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
@@ -437,7 +442,7 @@ class Engine:
             self._seg(prog, hip.SEG_TRIPLET, E, p.tri_order, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
                       ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
                       W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks,
-                      **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter,
+                      **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter, tri_grid=tri_grid,
                               Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
             if last:                                   # lane 3 (the triplet queries) has been joined: the bond head takes it

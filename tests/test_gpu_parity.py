@@ -746,6 +746,8 @@ def test_engine_variants_agree(model):
             assert all(torch.equal(a, b) for a, b in zip(base, again))
     layer_by_layer = run({'PG_LAYER_AHEAD': '0'})     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
     assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
+    for grid in ('0', '96', '200'):                   # persistent triplet workgroups (small batches leave CUs to the side lanes):
+        assert all(torch.equal(a, b) for a, b in zip(base, run({'PG_TRI_GRID': grid})))     # the queue hands out the same segments
     two_launches = run({'PG_KNN_MERGE': '0'})         # ligand / pharmacophore targets of a knn sub-layer as two launches ...
     one_launch = run({'PG_KNN_MERGE': '2'})           # ... or as one launch with the workgroups split between the lists (the default only
     assert all(torch.equal(a, b) for a, b in zip(base, two_launches))     # from ~60 graphs up): same bits per node either way
