@@ -251,8 +251,9 @@ class Engine:
         # fused knn form with two target lists (ligand + pharmacophore targets, different feature weights): ONE launch, the
         # persistent workgroups split between the lists in proportion to their sizes (PgSegAttn.seg_ids2)
         merged = fused and knn and len(h_dst_lists) == 2 and self.merge_knn_lists and all(n > 0 for _, n, _ in h_dst_lists) and \
-            (self.merge_knn_always or sum(n for _, n, _ in h_dst_lists) >= 3 * 256 * 12)   # (>= 3 node rounds of the persistent grid;
-                                                                                           #  smaller batches: measured slower)
+            (self.merge_knn_always or sum(n for _, n, _ in h_dst_lists) >= 2500)   # (measured on the headline shape, with the triplet
+                                                                                   #  grid below: 16 graphs = 1 920 nodes slower
+                                                                                   #  merged, 24 / 32 graphs 3 % faster, 48+ equal)
         lists = [h_dst_lists[0]] if merged else h_dst_lists
         for seg_ids, n_seg, is_lig in lists:
             if not fused:
@@ -372,9 +373,9 @@ class Engine:
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
         ahead = self.layer_ahead and self.multi_stream and E < 160000
         # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
-        # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 200 workgroups, 32 graphs 5.87 -> 5.78 with 224; from 64 graphs
-        # up the full grid is fastest)
-        tri_grid = self.tri_grid if self.tri_grid >= 0 else ((200 if E < 40000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
+        # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 192 workgroups, 24 / 32 graphs 4.9 -> 4.7 / 5.87 -> 5.61 with
+        # 224 and the merged knn launch; 48 graphs equal either way, from 64 graphs up the full grid is fastest)
+        tri_grid = self.tri_grid if self.tri_grid >= 0 else ((192 if E < 30000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
 
         def first_layer_gemm(L, h_in):
             # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
