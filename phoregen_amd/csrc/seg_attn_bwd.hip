@@ -423,9 +423,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         }
         if (row_m < n_rows) aK_raw = *reinterpret_cast<const f4*>(arow + row_m * 16 + 4 * g);
       }
-      // the Csrc rows of BOTH paths are requested here: with one wave per SIMD each dependent round trip is exposed
-      // (not in the knn forms: they are out of registers as it is)
-      constexpr bool PRE = !T::KNN;
+      // the Csrc rows of BOTH paths are requested here: with one wave per SIMD each dependent round trip is exposed (the knn
+      // forms are out of registers either way -- they spill ~430 / ~570 with or without these 64 -- and are 4 % faster with them)
+      constexpr bool PRE = true;
       f4 pre[2][PRE ? 8 : 1];
       if constexpr (PRE) {
         const float* pk = p.Csrc_k + (size_t)rk.csrc * p.ld_csrc + 4 * g;
