@@ -572,12 +572,15 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           if (m == r) L.sR[4 * g + r] = v;
         }
         if (g == 0) L.sR[16 + m] = rs;
-        // z^T tile to LDS for the products contracted over rows
+        // z^T tile to LDS for the product contracted over rows (d U on the key path, d W2xv on the value path of the pos modes:
+        // the value path of the feature modes has no such product)
+        if (kp || T::POS) {
 #pragma unroll
-        for (int tq = 0; tq < 8; ++tq) {
-          const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
+          for (int tq = 0; tq < 8; ++tq) {
+            const f4 bt = *reinterpret_cast<const f4*>(bp + 16 * tq + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = fmaxf(fmaf(bt[r], sg, hid[tq][r]), 0.f);
+            for (int r = 0; r < 4; ++r) L.sT[(16 * tq + 4 * g + r) * 17 + m] = fmaxf(fmaf(bt[r], sg, hid[tq][r]), 0.f);
+          }
         }
         wave_lds_sync();
         const float grs = L.sR[m];
