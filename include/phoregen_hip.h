@@ -259,6 +259,12 @@ int pg_guidance_grad(const PgTopo* t, const float* x_lig /*[n_lig,3]*/, const fl
 int pg_gemm_wgrad(const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* gW, int ldgw,
                   float* gb, void* stream);
 
+/* out[ctx(a)][0:ncol] (=) sum of Y[e][0:ncol] over the bond rows e whose source (by_src != 0) or target (by_src == 0) is ligand
+ * atom a; rows of `out` are context nodes (pharmacophore rows are not written).  Adjoint of pg_gemm's gathered operand
+ * add1[idx1[r]] with idx1 = PgTopo.bond_src / bond_dst (reference: the h_k / h_j columns of the concatenated first layers,
+ * models/uni_denoiser.py:43-59,141-155,190-201).  ncol, ldy, ldo multiples of 4; rows 16-byte aligned. */
+int pg_bond_rows_sum(const PgTopo* t, const float* Y, int ldy, int ncol, int by_src, float* out, int ldo, void* stream);
+
 /* Y = ReLU(LayerNorm_128(X) * gamma + beta) and its adjoint (the LayerNorm+ReLU between the two Linear layers of
  * models/common.py:99-119 MLPs, used where the forward keeps it fused into pg_gemm's operand load).
  * gX (=), ggamma / gbeta (+=). */

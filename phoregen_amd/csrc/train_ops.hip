@@ -176,9 +176,55 @@ __global__ __launch_bounds__(256) void fold_wgrad_kernel(const float* X, int ldx
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// out[ctx(a)][c] = sum of Y[e][c] over the bond rows e that leave (by_src) or reach (by dst) ligand atom a: the adjoint of a
+// gathered operand of pg_gemm (Y[e] += A[bond_src[e]] / A[bond_dst[e]]).  One wave per atom walks its n - 1 rows through the
+// graph's edge-id table (8 rows in flight, 16 bytes per lane): every row is read once, nothing is atomic -- torch's index_add_
+// on the same 167 MB took 141 us per call, 30 calls per training step.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bond_rows_sum_kernel(PgTopo t, const float* Y, int ldy, int ncol, int by_src, float* out,
+                                                            int ldo) {
+  const int lane = threadIdx.x & 63;
+  for (int a = blockIdx.x * 4 + (threadIdx.x >> 6); a < t.n_lig; a += gridDim.x * 4) {
+    const int ctx = t.lig2ctx[a];
+    const int gi = t.ctx_graph[ctx];
+    const int n = t.g_nlig[gi], la = ctx - (t.g_ctx_off[gi] + t.g_nph[gi]);
+    const int* eid_g = t.eid + t.g_eid_off[gi];
+    for (int c = 4 * lane; c < ncol; c += 256) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int b0 = 0; b0 < n; b0 += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = b0 + u;
+          const bool ok = b < n && b != la;
+          const int e = ok ? (by_src ? eid_g[la * n + b] : eid_g[b * n + la]) : 0;
+          v[u] = ok ? *reinterpret_cast<const f4*>(Y + (size_t)e * ldy + c) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      *reinterpret_cast<f4*>(out + (size_t)ctx * ldo + c) = acc;
+    }
+  }
+}
+
 }  // namespace pg
 
 using namespace pg;
+
+extern "C" int pg_bond_rows_sum(const PgTopo* t, const float* Y, int ldy, int ncol, int by_src, float* out, int ldo, void* stream) {
+  if (!t || !Y || !out) { set_error("pg_bond_rows_sum: null argument"); return PG_ERR_ARG; }
+  if ((ncol & 3) || (ldy & 3) || (ldo & 3) || ((size_t)Y & 15) || ((size_t)out & 15)) {
+    set_error("pg_bond_rows_sum: columns and leading dimensions must be multiples of 4 floats, 16-byte aligned rows");
+    return PG_ERR_ARG;
+  }
+  if (t->n_lig <= 0 || ncol <= 0) return PG_OK;
+  int blocks = (t->n_lig + 3) / 4;
+  if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
+  hipLaunchKernelGGL(bond_rows_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *t, Y, ldy, ncol, by_src, out, ldo);
+  return check_launch("pg_bond_rows_sum");
+}
 
 extern "C" int pg_gemm_wgrad(const float* dY, int ldy, const float* X, int ldx, int M, int N, int K, float* gW, int ldgw,
                              float* gb, void* stream) {

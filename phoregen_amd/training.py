@@ -140,7 +140,9 @@ class LinearGatherAddFn(torch.autograd.Function):
     halves, in pg_gemm's epilogue (no materialised gathers)."""
 
     @staticmethod
-    def forward(ctx, X, W, A1, i1, A2, i2):
+    def forward(ctx, X, W, A1, i1, A2, i2, topo=None, kinds=None):
+        """`topo`, `kinds` (a 'src' / 'dst' tag per gathered operand): i1 / i2 are the plan's bond_src / bond_dst, so the adjoint of
+        the gathers is a walk over the edge-id table (pg_bond_rows_sum) instead of an atomic index_add_."""
         X, W, A1 = _rowmajor(X), _rowmajor(W), _rowmajor(A1)
         A2 = _rowmajor(A2) if A2 is not None else None
         M, K = X.shape
@@ -159,6 +161,7 @@ class LinearGatherAddFn(torch.autograd.Function):
             hip.check(hip.lib().pg_gemm(C.byref(g), _st()), 'pg_gemm')
         ctx.save_for_backward(X, W, i1, i2 if i2 is not None else i1)
         ctx.shapes = (A1.shape, None if A2 is None else A2.shape)
+        ctx.topo, ctx.kinds = topo, kinds
         return Y
 
     @staticmethod
@@ -171,13 +174,23 @@ class LinearGatherAddFn(torch.autograd.Function):
             _dgrad(gY, W, gX)
         gW, _ = _wgrad(gY, X, N, K, False)
         s1, s2 = ctx.shapes
-        gA1 = torch.zeros(s1, dtype=torch.float32, device=gY.device).index_add_(0, i1.long(), gY)
-        gA2 = None if s2 is None else torch.zeros(s2, dtype=torch.float32, device=gY.device).index_add_(0, i2.long(), gY)
-        return gX, gW, gA1, None, gA2, None
+
+        def gathered_adjoint(shape, idx, kind):
+            out = torch.zeros(shape, dtype=torch.float32, device=gY.device)
+            if ctx.topo is not None and kind is not None and os.environ.get('PG_ROWS_SUM', '1') != '0' and shape[1] % 4 == 0 and \
+                    gY.stride(0) % 4 == 0:
+                hip.check(hip.lib().pg_bond_rows_sum(ctx.topo, gY.data_ptr(), gY.stride(0), shape[1], 1 if kind == 'src' else 0,
+                                                     out.data_ptr(), out.stride(0), _st()), 'pg_bond_rows_sum')
+                return out
+            return out.index_add_(0, idx.long(), gY)
+        kinds = ctx.kinds or (None, None)
+        gA1 = gathered_adjoint(s1, i1, kinds[0])
+        gA2 = None if s2 is None else gathered_adjoint(s2, i2, kinds[1])
+        return gX, gW, gA1, None, gA2, None, None, None
 
 
-def linear_gather_add(X, W, A1, i1, A2=None, i2=None):
-    return LinearGatherAddFn.apply(X, W, A1, i1, A2, i2)
+def linear_gather_add(X, W, A1, i1, A2=None, i2=None, topo=None, kinds=None):
+    return LinearGatherAddFn.apply(X, W, A1, i1, A2, i2, topo, kinds)
 
 
 class LnReluFn(torch.autograd.Function):
@@ -568,15 +581,15 @@ class TrainForward:
             else:                                               # A/B knob: one GEMM (and one adjoint pair) per consumer
                 Y1 = lambda c0, c1: linear(h, *L.node1_parts[(c0, c1)])
             aggE = self._attention(hip.SEG_KNN_NODE, L.NE, Y1, x, both, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
-            CsB = linear_gather_add(hb, L.NB.W_hb, Y1(7 * 128, 9 * 128), p.bond_src)
+            CsB = linear_gather_add(hb, L.NB.W_hb, Y1(7 * 128, 9 * 128), p.bond_src, topo=p.topo_ref, kinds=('src',))
             aggB = self._attention(hip.SEG_BOND_NODE, L.NB, lambda c0, c1: Y1(640 + c0, 640 + c1), x, lig, Ysrc=CsB,
                                    max_rows=max_lig)
             # bond update over triplets (uni_denoiser.py:101-165)
             a = L.TB
             P = linear_gather_add(torch.cat([hb, G], -1), a.W_hbg, Y1(10 * 128, 12 * 128), p.bond_src,
-                                  Y1(12 * 128, 14 * 128), p.bond_dst)
+                                  Y1(12 * 128, 14 * 128), p.bond_dst, topo=p.topo_ref, kinds=('src', 'dst'))
             Q = linear(G, a.W_g2)                                                      # smear(d_ji) columns, per segment
-            qhid = linear_gather_add(hb, a.W_q_hb, Y1(14 * 128, 15 * 128), p.bond_dst)
+            qhid = linear_gather_add(hb, a.W_q_hb, Y1(14 * 128, 15 * 128), p.bond_dst, topo=p.topo_ref, kinds=('dst',))
             qT = linear(LnReluFn.apply(qhid, a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
             U = FoldFn.apply(qT, a.W2k_l, None, E)
             cfg = dict(mode=hip.SEG_TRIPLET, n_seg=E, seg_ids=None, k=self.k, topo=p.topo_ref, n_out_rows=E,
@@ -594,7 +607,7 @@ class TrainForward:
             else:
                 Y2 = lambda c0, c1: linear(h_new, *L.node2_parts[(c0, c1)])
             dxe = self._attention(hip.SEG_KNN_POS, L.PE, Y2, x, lig, nrm=nrm, ew=ew, nbr=nbr, deg=deg, max_rows=self.k)
-            CsB2 = linear_gather_add(hb_new, L.PB.W_hb, Y2(7 * 128, 9 * 128), p.bond_src)
+            CsB2 = linear_gather_add(hb_new, L.PB.W_hb, Y2(7 * 128, 9 * 128), p.bond_src, topo=p.topo_ref, kinds=('src',))
             dxb = self._attention(hip.SEG_BOND_POS, L.PB, lambda c0, c1: Y2(640 + c0, 640 + c1), x, lig, Ysrc=CsB2,
                                   max_rows=max_lig)
             x = x + (dxe + dxb) * is_lig.to(x.dtype)

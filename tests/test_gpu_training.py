@@ -63,6 +63,31 @@ def test_dense_adjoints_match_torch():
         assert rel_err(a.cpu(), r.cpu()) < 2e-5
 
 
+def test_bond_rows_sum_matches_index_add():
+    """pg_bond_rows_sum (adjoint of pg_gemm's gathered operand over the plan's bond_src / bond_dst) against torch's index_add on
+    ragged ligands (1 .. 33 atoms: a graph without bonds, tile boundaries), 256 and 128 columns, a strided input."""
+    from phoregen_amd import hip
+    from phoregen_amd.plan import BatchPlan, make_edge_data
+    lib, DEV = hip.lib(), torch.device('cuda')
+    na, nph = torch.tensor([5, 1, 17, 33, 2, 16]), torch.tensor([4, 9, 3, 12, 7, 5])
+    ei, be = make_edge_data(na)
+    B = na.numel()
+    plan = BatchPlan(torch.repeat_interleave(torch.arange(B), na), torch.repeat_interleave(torch.arange(B), nph), ei, be, B, DEV)
+    g = torch.Generator().manual_seed(4)
+    for ncol, ld in ((256, 256), (128, 384)):
+        Y = torch.randn(plan.n_bond, ld, generator=g).to(DEV)
+        for by_src, idx in ((1, plan.bond_src), (0, plan.bond_dst)):
+            out = torch.full((plan.n_ctx, ncol), 7.0, device=DEV)
+            hip.check(lib.pg_bond_rows_sum(plan.topo_ref, Y.data_ptr(), Y.stride(0), ncol, by_src, out.data_ptr(), out.stride(0),
+                                           hip.stream_ptr()))
+            ref = torch.zeros(plan.n_ctx, ncol, dtype=torch.float64, device=DEV).index_add_(0, idx.long(), Y[:, :ncol].double())
+            lig = plan.lig2ctx_long
+            assert float((out[lig].double() - ref[lig]).abs().max()) <= 1e-5 * float(ref.abs().max())
+            mask = torch.ones(plan.n_ctx, dtype=torch.bool, device=DEV)
+            mask[lig] = False
+            assert bool((out[mask] == 7.0).all())                                  # pharmacophore rows are not written
+
+
 def test_fold_unfold_adjoints_match_dense_einsum():
     from phoregen_amd import training as tr
     from phoregen_amd.packing import lane_fixed_w2
