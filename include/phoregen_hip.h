@@ -297,6 +297,11 @@ int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* g,
  * (adjoint of pg_attn_fold_query w.r.t. the weights with X = q, T = dU; of pg_attn_unfold_value with X = dout, T = S) */
 int pg_attn_fold_wgrad(const float* X, int ldx, const float* T, int n, const int* ids, float* gW2_l, void* stream);
 
+/* the bias side of pg_attn_unfold_value's adjoint over the rows `ids` (NULL: all n):
+ * gswn[s, h] (=) sum_d gout[s, 8h+d] * b2v[8h+d];  gb2v[c] (+=) sum_s gout[s, c] * swn[s, c >> 3]  (rows outside `ids`: untouched) */
+int pg_attn_unfold_bias_grad(const float* gout, int ldg, const float* swn, const float* b2v, int n, const int* ids,
+                             float* gswn /*[.,16]*/, float* gb2v /*[128]*/, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,9 +209,51 @@ __global__ __launch_bounds__(256) void bond_rows_sum_kernel(PgTopo t, const floa
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the bias side of the value unfold's adjoint (out[s, 8h+d] = ... + b2v[8h+d] * swn[s, h]):
+//   gswn[s, h] (=) sum_d gout[s, 8h+d] * b2v[8h+d]          gb2v[c] (+=) sum_s gout[s, c] * swn[s, c >> 3]
+// over the rows `ids` (all n rows if NULL).  One wave per row, lane = channels lane and lane + 64; d b2v is summed per
+// workgroup before it is added.  (Five elementwise / reduction passes over [n, 128] tensors in the tensor-op form.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unfold_bias_grad_kernel(const float* gout, int ldg, const float* swn, const float* b2v, int n,
+                                                               const int* ids, float* gswn, float* gb2v) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float b0 = b2v[lane], b1 = b2v[64 + lane];
+  float a0 = 0.f, a1 = 0.f;
+  for (int si = blockIdx.x * 4 + w; si < n; si += gridDim.x * 4) {
+    const int s = ids ? ids[si] : si;
+    const float v0 = gout[(size_t)s * ldg + lane], v1 = gout[(size_t)s * ldg + 64 + lane];
+    const float sw0 = swn[(size_t)s * 16 + (lane >> 3)], sw1 = swn[(size_t)s * 16 + 8 + (lane >> 3)];
+    a0 = fmaf(v0, sw0, a0);
+    a1 = fmaf(v1, sw1, a1);
+    float p0 = v0 * b0, p1 = v1 * b1;
+#pragma unroll
+    for (int o = 1; o <= 4; o <<= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+    if ((lane & 7) == 0) {
+      gswn[(size_t)s * 16 + (lane >> 3)] = p0;
+      gswn[(size_t)s * 16 + 8 + (lane >> 3)] = p1;
+    }
+  }
+  __shared__ float red[4][128];
+  red[w][lane] = a0;
+  red[w][64 + lane] = a1;
+  __syncthreads();
+  if (threadIdx.x < 128) atomicAdd(gb2v + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 }  // namespace pg
 
 using namespace pg;
+
+extern "C" int pg_attn_unfold_bias_grad(const float* gout, int ldg, const float* swn, const float* b2v, int n, const int* ids,
+                                        float* gswn, float* gb2v, void* stream) {
+  if (n <= 0) return PG_OK;
+  if (!gout || !swn || !b2v || !gswn || !gb2v) { set_error("pg_attn_unfold_bias_grad: null argument"); return PG_ERR_ARG; }
+  int blocks = (n + 3) / 4;
+  if (blocks > 4 * kNumCU) blocks = 4 * kNumCU;
+  hipLaunchKernelGGL(unfold_bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gout, ldg, swn, b2v, n, ids, gswn, gb2v);
+  return check_launch("pg_attn_unfold_bias_grad");
+}
 
 extern "C" int pg_bond_rows_sum(const PgTopo* t, const float* Y, int ldy, int ncol, int by_src, float* out, int ldo, void* stream) {
   if (!t || !Y || !out) { set_error("pg_bond_rows_sum: null argument"); return PG_ERR_ARG; }

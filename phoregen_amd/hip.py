@@ -85,6 +85,7 @@ _PROTOS = {
     'pg_attn_fold_query': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_ip, c_fp, C.c_void_p]),
     'pg_attn_unfold_value': (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, C.c_int, C.c_void_p]),
     'pg_apply_dx': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
+    'pg_attn_unfold_bias_grad': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, c_ip, c_fp, c_fp, C.c_void_p]),
     'pg_bond_rows_sum': (C.c_int, [C.POINTER(PgTopo), c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_void_p]),
     'pg_rows_linear': (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_ip, c_fp, C.c_int,
                                  C.c_void_p]),

@@ -280,18 +280,13 @@ class UnfoldFn(torch.autograd.Function):
         gout = _rowmajor(gout)
         gS = torch.empty_like(S)
         _fold(gout, W2_l, ctx.ids, ctx.n_ids, gS)
-        g3 = gout.reshape(-1, 16, 8)
-        sel = torch.zeros(S.shape[0], 1, 1, dtype=torch.float32, device=S.device)
-        idl = ctx.ids.long() if ctx.ids is not None else None
-        if idl is None:
-            sel += 1.0
-        else:
-            # (index_fill_, not `sel[idl] = 1.0`: indexed assignment of a Python scalar uploads it with a BLOCKING host -> device
-            # copy that waits for everything enqueued before it -- 22 such waits were 149 ms of a 258 ms training step)
-            sel.index_fill_(0, idl, 1.0)
-        g3 = g3 * sel
-        gswn = (g3 * b2.view(1, 16, 8)).sum(-1)
-        gb2 = (g3 * swn.view(-1, 16, 1)).sum(0).reshape(128)
+        # bias side: gswn[s, h] = sum_d gout[s, 8h+d] b2[8h+d], gb2[c] = sum_s gout[s, c] swn[s, c >> 3] over the rows `ids` -- one
+        # launch (five elementwise / reduction passes over [n, 128] in tensor ops; an indexed assignment of a Python scalar there
+        # once cost 149 ms per step: it uploads the scalar with a BLOCKING copy)
+        gswn = (torch.zeros_like if ctx.ids is not None else torch.empty_like)(swn)
+        gb2 = torch.zeros_like(b2)
+        hip.check(hip.lib().pg_attn_unfold_bias_grad(gout.data_ptr(), gout.stride(0), swn.data_ptr(), b2.data_ptr(), ctx.n_ids,
+                                                     hip.ptr(ctx.ids), gswn.data_ptr(), gb2.data_ptr(), _st()), 'pg_attn_unfold_bias_grad')
         return gS, gswn, _fold_wgrad(gout, S, ctx.ids, ctx.n_ids, W2_l), gb2, None, None
 
 
