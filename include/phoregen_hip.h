@@ -179,7 +179,9 @@ typedef struct {
   const float* resid; float* out;            /* triplet: out[e,:] = resid[e,:] + update           */
   float* dx;                 /* pos modes: [n_ctx,3]                                              */
   int accumulate_dx;         /* pos modes: dx += instead of =                                     */
-  float* alpha; int alpha_rows; /* triplet S-form, optional: softmax weights out [n_bond][alpha_rows][16] (training)  */
+  float* alpha; int alpha_rows; /* optional (training): triplet S-form and the node-update modes of csrc/node_attn.hip write the
+                                   softmax weights (x gate) [segments][alpha_rows][16]; its position modes write the logits and the
+                                   value scalars of every row [segments][alpha_rows][32] -- what PgSegAttnGrad.alpha takes         */
   /* PG_SEG_PHORE, optional: the scalar edge feature given explicitly instead of computed as |x_dst - x_src| (the standalone
    * NodeUpdateLayer.forward(h, edge_feat, edge_index) of models/uni_denoiser.py:40-72 receives it from its caller):
    * efeat[efeat_off[g] + src_local * p_g + dst_local] for graph g with p_g nodes = the order of
@@ -285,7 +287,8 @@ typedef struct {
   float* gW2xv_l; float* gb2xv;            /* (+=) pos modes                                                         */
   float* gx; float* gnrm;                  /* (+=) [n_ctx,3]; NULL = not needed (pharmacophore encoder)              */
   float* gew;                              /* (=) knn modes [n_ctx,k]                                                */
-  const float* alpha; int alpha_rows;      /* triplet, optional: softmax weights of the forward [n_bond][alpha_rows][16] (PgSegAttn.alpha) */
+  const float* alpha; int alpha_rows;      /* optional, from the forward (PgSegAttn.alpha): triplet / node-update modes: softmax weights
+                                              [segments][alpha_rows][16]; position modes: logits | value scalars [..][alpha_rows][32] */
   const float* S; const float* swn;        /* ... with the forward's S / swn: one pass instead of two                */
   float* rowbuf; int rowbuf_rows; int grid;/* scratch: grid * pg_seg_attn_bwd_waves(mode) * rowbuf_rows * 48 floats,
                                               rowbuf_rows >= rows of the largest segment; grid = workgroups to launch */

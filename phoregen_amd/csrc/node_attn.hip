@@ -294,6 +294,19 @@ __global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTop
       }
     }
 
+    if constexpr (POS) {
+      if (p.alpha) {                     // training: logits and value scalars of every row (32 floats per row), read back by the
+        float* ap = p.alpha + (size_t)seg * p.alpha_rows * 32 + m;      // adjoint instead of recomputing both MLPs for them
+#pragma unroll
+        for (int tile = 0; tile < MAXT; ++tile)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kr = tile * 16 + 4 * g + r;
+            if (kr < p.alpha_rows) { ap[kr * 32] = lg[tile][r]; ap[kr * 32 + 16] = vv[tile][r]; }
+          }
+      }
+    }
+
     // ======================= softmax over all rows, head m =======================
     float mx = NA_NEG;
 #pragma unroll

@@ -312,7 +312,17 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     PROF_T0();
     PROF(0);   // segment setup
     // =============================== pass 1: logits and tv of every row ===============================
-    for (int tile = 0; tile < ((OP || PG_ABL(32)) ? 0 : n_tiles); ++tile) {
+    // position modes with the forward's per-row logits / value scalars at hand (PgSegAttnGrad.alpha, 32 floats per row): copied
+    // into the row buffer instead of recomputing both MLPs of every row for them
+    const bool have_lt = T::POS && !OP && gr.alpha != nullptr;
+    if (have_lt) {
+      const float* src = gr.alpha + (size_t)s.seg * gr.alpha_rows * 32;
+      for (int r = g; r < n_rows; r += 4) {
+        rb[r * ROWBUF + m] = src[r * 32 + m];
+        rb[r * ROWBUF + 16 + m] = src[r * 32 + 16 + m];
+      }
+    }
+    for (int tile = 0; tile < ((OP || have_lt || PG_ABL(32)) ? 0 : n_tiles); ++tile) {
       const RowInfo rk = row_info<MODE>(t, p, s, tile * 16 + m);
       float feat[NS];
       RowGeo<MODE> geo;

@@ -323,11 +323,12 @@ class SegCoreFn(torch.autograd.Function):
         tf = cfg.get('tri_fwd')
         alpha = None
         onepass = os.environ.get('PG_TRI_ONEPASS', '1') != '0'
-        if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_BOND_NODE) and onepass and \
-                (cfg['k'] <= 32 if cfg['mode'] == hip.SEG_KNN_NODE else cfg['max_rows'] <= 80):
-            # the two-pass node kernels run (csrc/node_attn.hip): they can hand alpha x gate to a one-pass adjoint
+        if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_BOND_NODE, hip.SEG_KNN_POS, hip.SEG_BOND_POS) and onepass and \
+                (cfg['k'] <= 32 if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS) else cfg['max_rows'] <= 80):
+            # the two-pass node kernels run (csrc/node_attn.hip): they hand alpha x gate to a one-pass adjoint (node update), or
+            # the logits and value scalars of every row to the adjoint's softmax step (position update: 32 floats per row)
             arows = (cfg['max_rows'] + 15) // 16 * 16
-            alpha = torch.empty(n_rows * arows * 16, dtype=torch.float32, device=dev)
+            alpha = torch.empty(n_rows * arows * (32 if pos else 16), dtype=torch.float32, device=dev)
             s.alpha, s.alpha_rows = alpha.data_ptr(), arows
             ctx.alpha_rows = arows
         if tf is not None:
@@ -343,7 +344,7 @@ class SegCoreFn(torch.autograd.Function):
                 ctx.alpha_rows = arows
         ctx.has_alpha = alpha is not None
         if alpha is not None:
-            ctx.save_for_backward(alpha, out[0], out[1])
+            ctx.save_for_backward(alpha, *out)
         hip.check(lib.pg_seg_attn(cfg['topo'], C.byref(s), _st()), 'pg_seg_attn')
         ctx.cfg, ctx.tensors, ctx.pos = cfg, tensors, pos
         return out if not pos else out[0]
@@ -411,10 +412,13 @@ class SegCoreFn(torch.autograd.Function):
         rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
         g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
         if getattr(ctx, 'has_alpha', False):
-            a_, S_, sw_ = ctx.saved_tensors
+            a_ = ctx.saved_tensors[0]
             g.alpha, g.alpha_rows = a_.data_ptr(), ctx.alpha_rows
-            g.S, g.swn = S_.data_ptr(), sw_.data_ptr()
-            keep += [a_, S_, sw_]
+            keep.append(a_)
+            if not pos:
+                S_, sw_ = ctx.saved_tensors[1:3]
+                g.S, g.swn = S_.data_ptr(), sw_.data_ptr()
+                keep += [S_, sw_]
         s = SegCoreFn._struct(cfg, t)
         hip.check(lib.pg_seg_attn_bwd(cfg['topo'], C.byref(s), C.byref(g), _st()), 'pg_seg_attn_bwd')
         # first-layer blocks: the k|v target halves live in Ydst[:, 0:256], the source halves in Ysrc[:, 0:256]
