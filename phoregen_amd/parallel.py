@@ -235,13 +235,17 @@ class GradientBuckets:
             if self.average and world > 1:
                 flat /= world
             off = 0
+            dst, src = [], []
             for p in b:
                 g = flat[off:off + p.numel()].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
-                    p.grad.copy_(g)
+                    dst.append(p.grad)
+                    src.append(g)
                 off += p.numel()
+            if dst:
+                torch._foreach_copy_(dst, src)          # one multi-tensor launch per bucket instead of one copy per parameter
             n_elems += off
             self.absent[bi] = {id(p) for p in b} - self.fired[bi]
             self.flat[bi], self.work[bi], self.fired[bi] = None, None, set()
