@@ -872,9 +872,12 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       for (int i = tid; i < ((n + 15) & ~15) * 3; i += blockDim.x) L.accX[i] = 0.f;
       __syncthreads();
       const int n_tiles_j = (n + 15) >> 4;
-      for (int base = 0; base < n; base += NW) {
-        const int il = base + wave;
-        if (il < n && il != lj) {
+      // the atom's n - 1 segments j -> i (i != j) are dealt out densely: n slots with the diagonal left idle cost a whole round of
+      // NW segments whenever n = 1 mod NW
+      for (int base = 0; base < n - 1; base += NW) {
+        const int qs = base + wave;
+        const int il = qs < lj ? qs : qs + 1;
+        if (qs < n - 1) {
           Seg<MODE> s;
           s.seg = eid_g[lj * n + il];
           s.n_rows = s.n = n;
