@@ -407,7 +407,10 @@ class SegCoreFn(torch.autograd.Function):
         g.gW2xv_l, g.gb2xv = hip.ptr(gW2), hip.ptr(gb2)
         g.gx, g.gnrm, g.gew = hip.ptr(gx), hip.ptr(gnrm), hip.ptr(gew)
         waves = lib.pg_seg_attn_bwd_waves(cfg['mode'])
-        grid = max(1, min((cfg['n_seg'] + waves - 1) // waves, 1024))
+        # one persistent workgroup per CU (the adjoints hold a CU's LDS / registers alone): every workgroup stages its weight tables and
+        # flushes its weight-gradient accumulators (hundreds of atomics per wave) ONCE, and no partial last round of workgroups is
+        # left -- training step 179.5 ms with 1 024 workgroups, 171-173 with 512, 168 with 256 (320: 205, 8 192: 206)
+        grid = max(1, min((cfg['n_seg'] + waves - 1) // waves, int(os.environ.get('PG_BWD_GRID', '256'))))
         rows = (cfg['max_rows'] + 15) // 16 * 16
         rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
         g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
