@@ -912,18 +912,33 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   // ---------------- flush the weight-gradient accumulators ----------------
   PROF_FLUSH();
   __syncthreads();
+  // d Wf: the NW waves' accumulators are added up through LDS first (every workgroup-wide value is then ONE global atomic instead of
+  // NW: the flush of all workgroups goes to the same 2 x F x 128 addresses, and with one atomic per wave it was still 5 ms of a
+  // 168 ms training step).  Chunk = one float4 per lane: (path a, feature tile ft, channel tile tq); 8 chunks per barrier pair.
+  if constexpr (NSTEP > 0) {
+    constexpr int NCH = 2 * NF * 8, BATCH = 8;
+    float* const red = lds_raw;                                   // the kernel's LDS is free now
 #pragma unroll
-  for (int ft = 0; ft < NF; ++ft) {
-    const int f = 16 * ft + m;
-    if (NSTEP > 0 && f < F) {
+    for (int c0 = 0; c0 < NCH; c0 += BATCH) {
 #pragma unroll
-      for (int tq = 0; tq < 8; ++tq)
+      for (int j = 0; j < BATCH; ++j) {
+        const int ch = c0 + j;                                    // compile-time after unrolling: a = ch / (NF * 8), ft, tq
+        *reinterpret_cast<f4*>(red + ((size_t)(j * NW + wave) * 64 + lane) * 4) = gwf_acc[ch / (NF * 8)][(ch / 8) % NF][ch % 8];
+      }
+      __syncthreads();
+      for (int j = wave; j < BATCH; j += NW) {                    // wave w sums and flushes chunks w, w + NW, ... of the batch
+        const int ch = c0 + j, a = ch / (NF * 8), ft = (ch / 8) % NF, tq = ch % 8;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int idx = ((f >> 2) * 8 + tq) * 64 + (f & 3) * 16 + 4 * g + r;       // lane-fixed layout of the forward weights
-          atomicAdd(gr.gWf_k + idx, gwf_acc[0][ft][tq][r]);
-          atomicAdd(gr.gWf_v + idx, gwf_acc[1][ft][tq][r]);
+        for (int w2 = 0; w2 < NW; ++w2) v += *reinterpret_cast<const f4*>(red + ((size_t)(j * NW + w2) * 64 + lane) * 4);
+        const int f = 16 * ft + m;
+        if (f < F) {
+          float* dst = (a == 0 ? gr.gWf_k : gr.gWf_v) + ((f >> 2) * 8 + tq) * 64 + (f & 3) * 16 + 4 * g;   // lane-fixed layout of the forward weights
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
         }
+      }
+      __syncthreads();
     }
   }
   atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1);
