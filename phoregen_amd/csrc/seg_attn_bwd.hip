@@ -943,11 +943,18 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   }
   atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1);
   atomicAdd(gr.gbv + lane, gbv0); atomicAdd(gr.gbv + 64 + lane, gbv1);
-  if constexpr (T::POS) {
+  if constexpr (T::POS) {                                           // d W2xv: the same way, one batch of 8 chunks
+    float* const red = lds_raw;
 #pragma unroll
-    for (int tq = 0; tq < 8; ++tq)
+    for (int tq = 0; tq < 8; ++tq) *reinterpret_cast<f4*>(red + ((size_t)(tq * NW + wave) * 64 + lane) * 4) = gw2_acc[tq];
+    __syncthreads();
+    for (int tq = wave; tq < 8; tq += NW) {
+      f4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(gr.gW2xv_l + (tq * 4 + r) * 64 + lane, gw2_acc[tq][r]);
+      for (int w2 = 0; w2 < NW; ++w2) v += *reinterpret_cast<const f4*>(red + ((size_t)(tq * NW + w2) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(gr.gW2xv_l + (tq * 4 + r) * 64 + lane, v[r]);
+    }
   }
   if constexpr (T::POS) {
     gbx_acc += __shfl_xor(gbx_acc, 16);
