@@ -25,31 +25,43 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const float* dY, int ld
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float colsum = 0.f;
   const int lr = tid >> 2, lc = (tid & 3) * 16;          // loader: row lr, 16 consecutive columns from lc (4 x float4)
-  const bool vecY = (ldy & 3) == 0 && ((size_t)dY & 15) == 0 && n0 + 64 <= N;
-  const bool vecX = (ldx & 3) == 0 && ((size_t)X & 15) == 0 && k0 + 64 <= K;
-  for (int row0 = blockIdx.z * R; row0 < M; row0 += gridDim.z * R) {
+  const bool vecY = (ldy & 3) == 0 && ((size_t)dY & 15) == 0;      // 16-byte loads wherever a whole float4 lies inside the matrix
+  const bool vecX = (ldx & 3) == 0 && ((size_t)X & 15) == 0;
+  // software pipeline: the next chunk's rows are requested before the products of the current one are issued (the loads of a chunk
+  // are a full HBM round trip; with one chunk in flight the matrix pipe idled for most of it: 45-57 TF/s -> see tools/bench_wgrad.py)
+  f4 vy[4], vx[4];
+  auto fetch = [&](int row0) {
     const int row = row0 + lr;
     const bool in = row < M;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = lc + 4 * q;
-      f4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      vy[q] = (f4){0.f, 0.f, 0.f, 0.f};
+      vx[q] = (f4){0.f, 0.f, 0.f, 0.f};
       if (in) {
-        if (vecY) vy = *reinterpret_cast<const f4*>(dY + (size_t)row * ldy + n0 + c);
+        if (vecY && n0 + c + 4 <= N) vy[q] = *reinterpret_cast<const f4*>(dY + (size_t)row * ldy + n0 + c);
         else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (n0 + c + j < N) vy[j] = dY[(size_t)row * ldy + n0 + c + j];
+          for (int j = 0; j < 4; ++j) if (n0 + c + j < N) vy[q][j] = dY[(size_t)row * ldy + n0 + c + j];
         }
-        if (vecX) vx = *reinterpret_cast<const f4*>(X + (size_t)row * ldx + k0 + c);
+        if (vecX && k0 + c + 4 <= K) vx[q] = *reinterpret_cast<const f4*>(X + (size_t)row * ldx + k0 + c);
         else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (k0 + c + j < K) vx[j] = X[(size_t)row * ldx + k0 + c + j];
+          for (int j = 0; j < 4; ++j) if (k0 + c + j < K) vx[q][j] = X[(size_t)row * ldx + k0 + c + j];
         }
       }
-      *reinterpret_cast<f4*>(&sdY[lr][c]) = vy;
-      *reinterpret_cast<f4*>(&sX[lr][c]) = vx;
+    }
+  };
+  const int step = gridDim.z * R;
+  if ((int)(blockIdx.z * R) < M) fetch(blockIdx.z * R);
+  for (int row0 = blockIdx.z * R; row0 < M; row0 += step) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<f4*>(&sdY[lr][lc + 4 * q]) = vy[q];
+      *reinterpret_cast<f4*>(&sX[lr][lc + 4 * q]) = vx[q];
     }
     __syncthreads();
+    if (row0 + step < M) fetch(row0 + step);
     if (gb && blockIdx.y == 0 && tid < 64) {
 #pragma unroll 8
       for (int r = 0; r < R; ++r) colsum += sdY[r][tid];
