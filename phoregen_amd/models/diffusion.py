@@ -256,7 +256,11 @@ class PhoreDiff(nn.Module):
         loss = loss_pos + loss_node + loss_edge + loss_count
         loss_len = None
         if self.bond_len_loss:                                                                 # diffusion.py:286-290,333
-            src, dst = e.edge_index.to(dev)
+            bonds = getattr(e, 'edge_index', None) if not isinstance(e, dict) else e.get('edge_index')
+            if bonds is None:
+                raise ValueError("phoregen_amd: config.bond_len_loss is set, but the batch has no data['ligand','ligand'].edge_index "
+                                 '(the bonds of the molecule; TrainBatch(..., edge_index=...))')
+            src, dst = bonds.to(dev)
             true_len = torch.norm(pos0.index_select(0, src) - pos0.index_select(0, dst), dim=-1)
             pred_len = torch.norm(pred_pos.index_select(0, src) - pred_pos.index_select(0, dst), dim=-1)
             loss_len = F.mse_loss(pred_len, true_len)

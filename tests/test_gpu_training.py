@@ -295,6 +295,14 @@ def test_gradients_with_a_maximum_size_ligand(model):
         assert err < GRAD_TOL, (k, err)
 
 
+def test_bond_len_loss_needs_the_bond_list(model, monkeypatch):
+    """`bond_len_loss=True` reads `data['ligand','ligand'].edge_index` (diffusion.py:287): a batch without it is refused by name."""
+    g = golden('g6_loss_a')
+    monkeypatch.setattr(model, 'bond_len_loss', True)
+    with pytest.raises(ValueError, match='edge_index'):
+        model.compute_loss(_batch(g), draws=_draws(g))
+
+
 def test_validation_pass_without_grad(model):
     """run/run.py evaluates with compute_loss under torch.no_grad(): same loss as the training-mode call, nothing retained."""
     g = golden('g6_loss_a')
