@@ -158,7 +158,8 @@ typedef struct {
   /* factored first layer */
   const float* Csrc_k; const float* Csrc_v; int ld_csrc;
   const float* Cdst_k; const float* Cdst_v; int ld_cdst;
-  const float* Wf_k; const float* Wf_v;  /* lane-fixed [F/4][8][64] feature weights               */
+  const float* Wf_k; const float* Wf_v;  /* lane-fixed [F/4][8][64] feature weights; node modes: 16-byte aligned (as are Wf_k2,
+                                            Wf_v2 and W2xv_l: the tables go to LDS in 16-byte pieces; PG_ERR_ARG otherwise) */
   const float* Wg2_k; const float* Wg2_v;/* triplet: [20][128] weights of smear(d_ji)             */
   const float* G;                        /* triplet: [n_bond,20] from pg_bond_smear               */
   const float* ln_gk; const float* ln_bk; const float* ln_gv; const float* ln_bv;
@@ -204,6 +205,10 @@ typedef struct {
    * leaves some CUs to the launches that run beside the triplet kernel on other streams: 16 graphs of the headline shape 3.76 ->
    * 3.57 ms per step with 200 workgroups (the results do not depend on it: the queue hands out the same segments). */
   int tri_grid;
+  /* fused node-target modes (ABI 6): 0 = one persistent 12-wave workgroup per CU with the W2k table in LDS (large batches);
+   * 1 = 4-wave workgroups, a node per wave, W2k streamed through L2 (small batches: a launch of a few hundred nodes spreads over
+   * the whole chip).  Same arithmetic per node, bit for bit. */
+  int small_wg;
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 
@@ -216,6 +221,14 @@ int pg_attn_unfold_value(const float* S, const float* swn, const float* W2v_l, c
 
 /* x_new[i] = x[i] + (dx1[i] + dx2[i]) * is_lig[i]   (uni_denoiser.py:295-296) */
 int pg_apply_dx(const PgTopo* t, const float* x, const float* dx1, const float* dx2, float* x_new, void* stream);
+
+/* Everything of a layer that depends on the coordinates only, as ONE launch (the arithmetic of pg_apply_dx, pg_bond_smear and
+ * pg_lig_normals, bit for bit): x_new = x + (dx1 + dx2) * is_lig  (uni_denoiser.py:295-296), then FROM x_new the bond-length
+ * smearing G[n_bond,20] (uni_denoiser.py:128,137) and the direction vectors nrm[n_ctx,3] (common.py:300-314) the next layer reads.
+ * dx1 == dx2 == NULL: no update (x_new unused; G / nrm from x).  G == NULL / nrm == NULL: that product is skipped.
+ * nrm_phore_ctx [n_ctx,3]: the pharmacophore normals in ctx row order (rows of ligand atoms unused). */
+int pg_layer_geom(const PgTopo* t, const float* x, const float* dx1, const float* dx2, const float* nrm_phore_ctx,
+                  float* x_new, float* nrm, float* G, void* stream);
 
 /* small per-row linear: Y[r, 0:n_out] = W[n_out,K] . X[rows ? rows[r] : r, 0:K] + b   (n_out <= 16, K <= 256) */
 int pg_rows_linear(const float* X, int ldx, int K, const float* W, const float* b, int n_out, int M,

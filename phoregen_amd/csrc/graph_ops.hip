@@ -296,6 +296,90 @@ __global__ void apply_dx_kernel(int n_ctx, const uint8_t* is_lig, const float* x
   x_new[idx] = x[idx] + (dx1[idx] + dx2[idx]) * m;
 }
 
+// ------------------------------------------------------------------------------------------------
+// everything of a layer that depends on the coordinates only, in ONE launch: x' = x + mask (dx1 + dx2)  (uni_denoiser.py:295-296, the
+// arithmetic of apply_dx_kernel), then from x': the bond-length smearing of the next layer (bond_smear_kernel) and the direction
+// vectors (lig_normals_kernel).  Three 5 us launches on three lanes cost two cross-lane event hops (20-30 us each) in front of every
+// triplet kernel of a small batch; as one launch they sit on the bond chain's own stream.
+// Grid (graph, part): every workgroup of a graph forms the graph's new ligand coordinates in LDS (<= 512 atoms), part 0 writes x'; the
+// graph's bond rows and atoms are dealt out over the parts.  dx1 == nullptr: no update (layer 0: x' = x, nothing written).
+// G == nullptr / nrm == nullptr: that product is not wanted (last layer: the update alone).
+// ------------------------------------------------------------------------------------------------
+constexpr int GEOM_THREADS = 512;
+
+__device__ void wave_knn3_lds(const float* xl, int count, int self, int* out_slots) {
+  // wave_knn(k = 3) on coordinates staged in LDS (candidate c = ligand atom c of the graph): same keys, same order
+  const int lane = threadIdx.x & 63;
+  unsigned long long key[KNN_MAXC];
+  const float xs[3] = {xl[self * 3], xl[self * 3 + 1], xl[self * 3 + 2]};
+#pragma unroll
+  for (int i = 0; i < KNN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    key[i] = ~0ull;
+    if (c < count && c != self) {
+      const float d2 = dist2_rn(xl + c * 3, xs);
+      key[i] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
+    }
+  }
+  const int deg = min(3, count - 1);
+  for (int s = 0; s < 3; ++s) {
+    unsigned long long best = key[0];
+#pragma unroll
+    for (int i = 1; i < KNN_MAXC; ++i) best = key[i] < best ? key[i] : best;
+    best = wave_min_u64(best);
+    const int c = (int)(best & 0xffffffffu);
+    if (s < deg) {
+#pragma unroll
+      for (int i = 0; i < KNN_MAXC; ++i)
+        if (key[i] == best) key[i] = ~0ull;
+    }
+    if (lane == 0) out_slots[s] = s < deg ? c : -1;
+  }
+}
+
+__global__ __launch_bounds__(GEOM_THREADS) void layer_geom_kernel(PgTopo t, const float* x, const float* dx1, const float* dx2,
+                                                                  const float* nrm_phore_ctx, float* x_new, float* nrm, float* G) {
+  __shared__ float xl[64 * KNN_MAXC * 3];
+  __shared__ int slots[GEOM_THREADS / 64][4];
+  const int g = blockIdx.x, part = blockIdx.y, n_part = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int first = t.g_ctx_off[g], nph = t.g_nph[g], n = t.g_nlig[g];
+  const int lig0 = first + nph;
+  for (int i = tid; i < (nph + n) * 3; i += GEOM_THREADS) {
+    const int idx = first * 3 + i;
+    float v = x[idx];
+    if (dx1) {
+      const float m = t.ctx_is_lig[idx / 3] ? 1.f : 0.f;
+      v = v + (dx1[idx] + dx2[idx]) * m;
+      if (part == 0) x_new[idx] = v;
+    }
+    if (i >= nph * 3) xl[i - nph * 3] = v;
+    else if (nrm && part == 0) nrm[idx] = nrm_phore_ctx[idx];
+  }
+  __syncthreads();
+  if (G) {
+    const int e0 = t.g_bond_off[g], n_el = n * (n - 1) * 20;
+    for (int idx = part * GEOM_THREADS + tid; idx < n_el; idx += n_part * GEOM_THREADS) {
+      const int e = e0 + idx / 20, i = idx % 20;
+      const int s = t.bond_src[e] - lig0, d = t.bond_dst[e] - lig0;
+      const float ddx = xl[d * 3] - xl[s * 3], ddy = xl[d * 3 + 1] - xl[s * 3 + 1], ddz = xl[d * 3 + 2] - xl[s * 3 + 2];
+      G[(size_t)e0 * 20 + idx] = smear(sqrtf(ddx * ddx + ddy * ddy + ddz * ddz), i);
+    }
+  }
+  if (nrm) {
+    constexpr int WAVES = GEOM_THREADS / 64;
+    for (int a = part * WAVES + wave; a < n; a += n_part * WAVES) {
+      wave_knn3_lds(xl, n, a, slots[wave]);
+      const int d = min(3, n - 1);
+      if (lane < 3) {
+        float s = 0.f;
+        for (int i = 0; i < d; ++i) s += xl[slots[wave][i] * 3 + lane];       // scatter(mean): sum in edge order / count
+        nrm[(lig0 + a) * 3 + lane] = s / (float)max(d, 1) - xl[a * 3 + lane];
+      }
+    }
+  }
+}
+
 // per-graph means of the two count heads (models/diffusion.py:148-159); one block per graph
 __global__ void atom_count_kernel(const float* s_all, const float* s_l, const uint8_t* is_ex, const int* phore_graph,
                                   int n_phore, float* count_l, float* count_u) {
@@ -322,7 +406,7 @@ __global__ void atom_count_kernel(const float* s_all, const float* s_l, const ui
 using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
-extern "C" int pg_abi_version(void) { return 5; }
+extern "C" int pg_abi_version(void) { return 6; }
 
 extern "C" int pg_embed_ctx(const PgTopo* t, const float* h_node_pert, const float* pos_pert, const int64_t* time_step,
                             const float* W_node, const float* t_off, const float* t_coeff, const float* h_phore_emb,
@@ -406,6 +490,23 @@ extern "C" int pg_apply_dx(const PgTopo* t, const float* x, const float* dx1, co
   hipLaunchKernelGGL(apply_dx_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t->n_ctx,
                      t->ctx_is_lig, x, dx1, dx2, x_new);
   return check_launch("pg_apply_dx");
+}
+
+extern "C" int pg_layer_geom(const PgTopo* t, const float* x, const float* dx1, const float* dx2, const float* nrm_phore_ctx,
+                             float* x_new, float* nrm, float* G, void* stream) {
+  if (t->n_graphs == 0) return PG_OK;
+  if (t->max_nlig > 64 * KNN_MAXC) { set_error("pg_layer_geom: ligand of %d atoms (limit %d)", t->max_nlig, 64 * KNN_MAXC); return PG_ERR_ARG; }
+  if ((dx1 == nullptr) != (dx2 == nullptr) || (dx1 && !x_new) || (nrm && !nrm_phore_ctx)) {
+    set_error("pg_layer_geom: dx1 / dx2 / x_new come together; nrm needs nrm_phore_ctx");
+    return PG_ERR_ARG;
+  }
+  // enough workgroups for the chip at any batch size: the parts of a graph share its bond rows and atoms
+  int parts = (2 * kNumCU + t->n_graphs - 1) / t->n_graphs;
+  parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+  if (!G && !nrm) parts = 1;
+  hipLaunchKernelGGL(layer_geom_kernel, dim3(t->n_graphs, parts), dim3(GEOM_THREADS), 0, (hipStream_t)stream, *t, x, dx1, dx2,
+                     nrm_phore_ctx, x_new, nrm, G);
+  return check_launch("pg_layer_geom");
 }
 
 extern "C" int pg_atom_count(const float* s_all, const float* s_l, const uint8_t* is_ex, const int* phore_graph,

@@ -13,12 +13,25 @@ Data flow of one layer (reference: AttentionLayerO2TwoUpdateNodeGeneral.forward,
   Y2   = h' @ W_node2^T; same for the two position sub-layers;  x' = x + mask * (dx_knn + dx_bond)
 """
 import ctypes as C
-import os
 
 import torch
 
-from . import hip
+from . import hip, options
 from .packing import HEAD_SCALE, ModelPack
+
+
+_SIDE_STREAMS = {}
+
+
+def side_streams(device_index, stream_set=0):
+    """The three side lanes of a device, shared by every Engine of the process: the runtime maps HIP streams onto a handful of
+    hardware queues (4 by default), and streams that share a queue serialise -- an Engine that created its own streams made the
+    lanes of every later Engine slower (measured: a second model's 16-graph step 3.4 -> 5.4 ms)."""
+    key = (device_index, stream_set)
+    if key not in _SIDE_STREAMS:
+        with torch.cuda.device(device_index):
+            _SIDE_STREAMS[key] = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    return _SIDE_STREAMS[key]
 
 
 def _f(*shape, device, zero=False):
@@ -33,27 +46,37 @@ class Engine:
         self._keep = []          # ctypes structs / tensors referenced by raw pointer
         self.debug = None
         self.timers = None
+        self.trace = None        # list: when set, `_run` brackets every launch with HIP events on its lane (tools/event_timeline.py)
         self.tri_calls = []      # indices of the triplet launches in the forward program (profiling)
         # independent sub-layer chains of a layer run on side streams ("lanes" 1, 2) next to the triplet chain (lane 0):
-        # kernels of different chains interleave on the CUs, so one chain's load/store phases meet another's MFMA phases
-        self.multi_stream = os.environ.get('PG_STREAMS', '1') != '0'
-        self.row_subsets = os.environ.get('PG_ROW_SUBSETS', '0') != '0'
-        self.staged_triplet = os.environ.get('PG_TRI_STAGED', '1') != '0'      # csrc/triplet2.hip (0: the gather kernel)
-        self.fused_node = os.environ.get('PG_NODE_FUSED', '1') != '0'          # node attention folds / unfolds in-kernel
-        self.group_knn = os.environ.get('PG_KNN_GROUP', '1') != '0'            # neighbour slots partitioned by source kind
-        self.merge_knn_lists = os.environ.get('PG_KNN_MERGE', '1') != '0'      # ligand + pharmacophore targets of a knn sub-layer in one launch
-        self.merge_knn_always = os.environ.get('PG_KNN_MERGE', '1') == '2'     # ... also below the batch size where it pays (tests)
+        # kernels of different chains interleave on the CUs, so one chain's load/store phases meet another's MFMA phases.
+        # The variants below are read from phoregen_amd.options when an Engine is built (defaults = the product; tests and tools
+        # switch them with options.override(...), the ambient environment only counts under PHOREGEN_DEBUG=1)
+        o = options.snapshot()
+        self.multi_stream = o['streams']
+        self.row_subsets = o['row_subsets']
+        self.staged_triplet = o['tri_staged']          # csrc/triplet2.hip (False: the gather kernel)
+        self.fused_node = o['node_fused']              # node attention folds / unfolds in-kernel
+        self.group_knn = o['knn_group']                # neighbour slots partitioned by source kind
+        self.merge_knn_lists = o['knn_merge'] != 'never'      # ligand + pharmacophore targets of a knn sub-layer in one launch
+        self.merge_knn_always = o['knn_merge'] == 'always'    # ... also below the batch size where it pays (tests)
         # the next layer's first-layer blocks, triplet queries and bond-node rows (everything in front of its triplet kernel that does
         # not depend on the new coordinates) run on lane 2 during this layer's position updates
-        self.layer_ahead = os.environ.get('PG_LAYER_AHEAD', '1') != '0'
-        self.tri_grid = int(os.environ.get('PG_TRI_GRID', '-1'))               # persistent triplet workgroups (-1: by batch size)
-        # hipGraph replay of the forward launch list (PG_GRAPH=1). Off by default: measured on MI355X it buys nothing, a step
+        self.layer_ahead = o['layer_ahead']
+        self.tri_grid = o['tri_grid']                  # persistent triplet workgroups (-1: by batch size)
+        # apply_dx + bond smearing + direction vectors as one launch on lane 0: small batches (measured, same box: 16 graphs 3.52 -> 3.40 ms
+        # per step, 32 graphs 5.69 -> 5.43; 128 graphs 20.20 -> 20.28: there the three launches hide beside the first-layer GEMM)
+        self.fused_geom = o['fused_geom'] == 'always' or (o['fused_geom'] == 'auto' and self.plan.n_bond < 160000)
+        self.small_node = o['small_node']
+        self.small_node_below = o['small_node_below']
+        # hipGraph replay of the forward launch list.  Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
-        self.graph_mode = os.environ.get('PG_GRAPH', '0')
+        self.graph_mode = '1' if o['graph'] else '0'
         self._graph = None
         self._lane = 0
         self._side = None
+        self.stream_set = 0      # (experiments: a second set of side lanes)
         self._alloc()
         if full:
             self.prog_phore = self._build_phore_program()
@@ -70,6 +93,7 @@ class Engine:
         w.in_t = torch.zeros(p.n_graphs, dtype=torch.int64, device=d)
         w.h_phore_ctx, w.x_phore_ctx = _f(n, 18, device=d, zero=True), _f(n, 3, device=d, zero=True)
         w.pos_phore, w.phore_norm = _f(p.n_phore, 3, device=d), _f(p.n_phore, 3, device=d)
+        w.nrm_phore_ctx = _f(n, 3, device=d, zero=True)          # phore_norm in ctx row order (pg_layer_geom)
         w.is_ex = torch.zeros(p.n_phore, dtype=torch.uint8, device=d)
         w.hp_ctx, w.Yp = _f(n, 128, device=d), _f(n, 640, device=d)
         w.enc_ctx = _f(n, 128, device=d, zero=True)
@@ -84,9 +108,10 @@ class Engine:
         w.deg = torch.zeros(n, dtype=torch.int32, device=d)
         w.ew, w.nrm, w.G = _f(n, k, device=d), _f(n, 3, device=d), _f(E, 20, device=d)
         w.Y1, w.Y2 = _f(n, 1920, device=d), _f(n, 1280, device=d)
-        w.q = [_f(n, 128, device=d) for _ in range(2)]                 # per concurrent chain (knn / bond)
-        w.U, w.S = [_f(n, 2048, device=d) for _ in range(2)], [_f(n, 2048, device=d) for _ in range(2)]
-        w.swn = [_f(n, 16, device=d) for _ in range(2)]
+        # per concurrent chain: 0 knn, 1 bond, 2 the bond-node sub-layer launched one layer ahead, 3 (q only) the knn-node query ahead
+        w.q = [_f(n, 128, device=d) for _ in range(4)]
+        w.U, w.S = [_f(n, 2048, device=d) for _ in range(3)], [_f(n, 2048, device=d) for _ in range(3)]
+        w.swn = [_f(n, 16, device=d) for _ in range(3)]
         w.aggE, w.aggB = _f(n, 128, device=d, zero=True), _f(n, 128, device=d, zero=True)
         w.lin_tmp = _f(n, 128, device=d)
         w.CsB, w.P = _f(E, 256, device=d), _f(E, 256, device=d)     # (CsB: bond-pos edge rows)
@@ -238,10 +263,10 @@ class Engine:
             self._gemm(prog, qh, 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
 
     def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None, buf=0, extra=None,
-                        query_done=False):
+                        query_done=False, qbuf=None):
         """Shared tail of the four node-target sub-layers.  Y[:, col0 + 128*b] blocks: k_dst, v_dst, k_src, v_src, q_hid."""
         w, p, n = self.ws, self.plan, self.plan.n_ctx
-        wq, wU, wS, wsw = w.q[buf], w.U[buf], w.S[buf], w.swn[buf]
+        wq, wU, wS, wsw = w.q[buf if qbuf is None else qbuf], w.U[buf], w.S[buf], w.swn[buf]
         blk = lambda b: Y[:, col0 + 128 * b: col0 + 128 * (b + 1)]
         if not query_done:
             self._query_gemm(prog, a, Y, col0, h_dst_lists, buf)
@@ -255,6 +280,10 @@ class Engine:
                                                                                    #  grid below: 16 graphs = 1 920 nodes slower
                                                                                    #  merged, 24 / 32 graphs 3 % faster, 48+ equal)
         lists = [h_dst_lists[0]] if merged else h_dst_lists
+        # small batches: 4-wave workgroups, a node per wave, no 64 KB W2k table per workgroup (PgSegAttn.small_wg).  Below ~3 000
+        # target nodes the 12-wave persistent form does not fill one round of the chip
+        n_targets = sum(n for _, n, _ in h_dst_lists)
+        small = fused and (self.small_node == 'always' or (self.small_node == 'auto' and n_targets < self.small_node_below))
         for seg_ids, n_seg, is_lig in lists:
             if not fused:
                 self._call(prog, self.lib.pg_attn_fold_query, wq.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
@@ -275,7 +304,7 @@ class Engine:
             else:
                 kw.update(S=wS, swn=wsw)
             if fused:      # (U / S / swn stay attached as scratch for the one-pass fallback inside pg_seg_attn)
-                kw.update(q=wq, W2k_l=a.W2k_l)
+                kw.update(q=wq, W2k_l=a.W2k_l, small_wg=int(small))
                 if not pos:
                     assert out.stride(0) == 128
                     kw.update(W2v_l=a.W2v_l, b2v=a.b2v, out=out)
@@ -311,6 +340,7 @@ class Engine:
         w.x_phore_ctx.index_copy_(0, p.phore2ctx_long, pos_phore.float())
         w.pos_phore.copy_(pos_phore)
         w.phore_norm.copy_(phore_norm)
+        w.nrm_phore_ctx.index_copy_(0, p.phore2ctx_long, phore_norm.float())
         w.is_ex.copy_((h_phore[:, ex_col] == 1).to(torch.uint8))
         self._run(self.prog_phore)
         torch.index_select(w.enc_ctx, 0, p.phore2ctx_long, out=w.hp_emb)
@@ -372,6 +402,7 @@ class Engine:
         # 3.93 -> 3.83 ms, 32 graphs 5.94 -> 5.67, 64 graphs 10.55 -> 10.36, 128 graphs 20.12 -> 20.17 (the triplet kernel then
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
         ahead = self.layer_ahead and self.multi_stream and E < 160000
+        chain_q = self.multi_stream and E < 160000         # small batches: the Q rows on the bond chain's own lane
         # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
         # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 192 workgroups, 24 / 32 graphs 4.9 -> 4.7 / 5.87 -> 5.61 with
         # 224 and the merged knn launch; 48 graphs equal either way, from 64 graphs up the full grid is fastest)
@@ -397,15 +428,22 @@ class Engine:
             nxt = 1 - cur
             hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
             pre = ahead and li > 0            # Y1, the triplet queries and the bond-node rows of this layer were launched by the previous one
-            # direction vectors (read by the knn attention, lane 1) and bond-length smearing (read by the P product on lane 0 and
-            # the Q rows on lane 2) depend on x only: they run beside the first-layer GEMM instead of in front of it
-            self._fork(prog, (1, 3))
-            self._lane = 1
-            self._call(prog, lib.pg_lig_normals, t, xc.data_ptr(), w.phore_norm.data_ptr(), p.phore2ctx.data_ptr(),
-                       w.nrm.data_ptr())
-            self._lane = 3
-            self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
-            self._lane = 0
+            if self.fused_geom:
+                # direction vectors and bond-length smearing of this layer came with the previous layer's coordinate update (ONE
+                # launch on lane 0, pg_layer_geom); layer 0 forms them from the embedded coordinates the same way
+                if li == 0:
+                    self._call(prog, lib.pg_layer_geom, t, xc.data_ptr(), None, None, w.nrm_phore_ctx.data_ptr(), None,
+                               w.nrm.data_ptr(), w.G.data_ptr())
+            else:
+                # direction vectors (read by the knn attention, lane 1) and bond-length smearing (read by the P product on lane 0 and
+                # the Q rows on lane 2) depend on x only: they run beside the first-layer GEMM instead of in front of it
+                self._fork(prog, (1, 3))
+                self._lane = 1
+                self._call(prog, lib.pg_lig_normals, t, xc.data_ptr(), w.phore_norm.data_ptr(), p.phore2ctx.data_ptr(),
+                           w.nrm.data_ptr())
+                self._lane = 3
+                self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
+                self._lane = 0
             if pre:
                 self._sync(prog, 0, (2,))              # lane 2 carried them through the previous layer's position updates
             else:
@@ -413,8 +451,9 @@ class Engine:
             if li == 0 and pre_join:
                 self._join(prog, pre_join)
             self._fork(prog, (1, 2, 3))
-            self._sync(prog, 0, (3,))                  # the smearing (alone on lane 3 so far) is read by P on lane 0
-            self._sync(prog, 2, (3,))                  # ... and by the Q rows on lane 2; the queries on lane 3 do not wait for it
+            if not self.fused_geom:
+                self._sync(prog, 0, (3,))              # the smearing (alone on lane 3 so far) is read by P on lane 0
+                self._sync(prog, 2, (3,))              # ... and by the Q rows on lane 2; the queries on lane 3 do not wait for it
             last = heads is not None and li == n_layers - 1
             # Launch order of a layer.  Lane 0 carries the bond chain (P -> triplet -> bond position update), lane 1 the node
             # chain (knn attention -> lin_node -> second first-layer GEMM -> knn position update), lane 2 the Q rows and the
@@ -428,15 +467,20 @@ class Engine:
             self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
                        add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
                        **({} if staged else dict(add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)))
-            self._lane = 2
-            if staged:   # the per-segment constant of the triplet MLPs as rows: Wg2 . smear(d_ji) + (target half)[j]
+            # the per-segment constant of the triplet MLPs as rows: Wg2 . smear(d_ji) + (target half)[j].  Small batches: behind P on
+            # lane 0 (a 25 us product costs less there than the two cross-lane hops around it on a side lane)
+            q_lane = 0 if (chain_q and self.fused_geom) else 2
+            self._lane = q_lane
+            if staged:
                 self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=w.Y1[:, 12 * 128:14 * 128], idx1=p.bond_src)
-                self._sync(prog, 0, (2,))              # lane 0 (the triplet kernel) waits for the Q rows, not for all of lane 2
+                if q_lane != 0:
+                    self._sync(prog, 0, (2,))          # lane 0 (the triplet kernel) waits for the Q rows, not for all of lane 2
             if not pre:
                 self._lane = 3                                                          # triplet queries
                 triplet_queries(L, hbc)
             self._lane = 0
-            self._join(prog, (3,))
+            if not pre:                                # (pre: lane 3 carries the bond-node attention, which lin_node waits for)
+                self._join(prog, (3,))
             a = L.TB
             self._event(prog, 'triplet', True)
             self.tri_calls.append(len(prog))
@@ -451,20 +495,28 @@ class Engine:
                 self._lane = 3
                 heads[0](hbn)
             # ---- node update over bond edges (:284)                                   [lane 2]
+            # (the sub-layer reads no coordinates: from layer 1 on a small batch has launched it during the previous layer's position
+            #  updates, see below)
             self._lane = 2
             if not pre:
                 bond_node_rows(L, hbc)
-            self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=1)
+                self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=1)
             # ---- node update over knn edges (:281), then h' = h + lin_node(aggE + aggB) (:288)   [lane 1]
             self._lane = 1
-            self._query_gemm(prog, L.NE, w.Y1, 0, both, 0)
-            self._event(prog, 'knn_node', True)       # (both launches of the sub-layer: ligand targets, pharmacophore targets)
-            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0, query_done=True)
+            if not pre:
+                self._query_gemm(prog, L.NE, w.Y1, 0, both, 0)
+            self._event(prog, 'knn_node', True)       # (the launches of the sub-layer: ligand targets, pharmacophore targets)
+            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0, query_done=True,
+                                 qbuf=3 if pre else None)
             self._event(prog, 'knn_node', False)
-            self._sync(prog, 1, (2,))                  # aggB
+            if pre:
+                self._wait(prog, 1, bn_done)           # aggB: the bond-node attention launched one layer ahead (lane 3)
+            else:
+                self._sync(prog, 1, (2,))              # aggB
             # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~17 us)
             self._gemm(prog, w.aggE, 128, L.W_lin2[:, :128], w.lin_tmp, n, 128, bias=L.b_lin, add1=hc)
             self._gemm(prog, w.aggB, 128, L.W_lin2[:, 128:], hn, n, 128, add1=w.lin_tmp)
+            self._mark(prog, f'A{li}', w.aggE, w.aggB, lane=1)      # (the next layer's bond-node attention may overwrite aggB from here on)
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
             # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
             # only for ligand atoms
@@ -491,11 +543,19 @@ class Engine:
                 #      every reader of this layer's Y1 has run), its triplet queries and bond-node rows (h_bond' is final, the
                 #      triplet kernel has read qT): they fill lane 2 during this layer's position updates instead of standing in
                 #      front of the next triplet kernel.  (Forked from lane 0 like the node head, for the same reason.)
+                #      The bond-node sub-layer and the knn-node query read no coordinates either: they go along (lane 3 behind the
+                #      bond position update's query; lin_node of the next layer is what waits for it, not its triplet kernel).
                 Ln = pk.layers[li + 1]
                 self._lane = 2
                 first_layer_gemm(Ln, hn)
+                y1_done = self._record(prog, 2)
                 triplet_queries(Ln, hbn)
+                self._query_gemm(prog, Ln.NE, w.Y1, 0, both, 3)
+                self._lane = 3
+                self._wait(prog, 3, y1_done)
                 bond_node_rows(Ln, hbn)
+                self._node_attention(prog, hip.SEG_BOND_NODE, Ln.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=2)
+                bn_done = self._record(prog, 3)
             self._lane = 1
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
@@ -503,8 +563,13 @@ class Engine:
             self._wait(prog, 0, q_done)
             self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1, query_done=True)
             self._join(prog, (1,))
-            self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
-            self._mark(prog, f'L{li}', hn, hbn, xn, w.aggE, w.aggB, w.dxe, w.dxb, w.nrm, hbc)
+            if self.fused_geom:      # x' = x + dx, and from x' the next layer's smearing + direction vectors (last layer: the update alone)
+                more = li + 1 < n_layers
+                self._call(prog, lib.pg_layer_geom, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), w.nrm_phore_ctx.data_ptr(),
+                           xn.data_ptr(), w.nrm.data_ptr() if more else None, w.G.data_ptr() if more else None)
+            else:
+                self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
+            self._mark(prog, f'L{li}', hn, hbn, xn, w.dxe, w.dxb, hbc)
             cur = nxt
         if heads is not None:
             self._join(prog, (2, 3))
@@ -513,11 +578,32 @@ class Engine:
     def _run(self, prog):
         cur = torch.cuda.current_stream()
         if self._side is None:
-            self._side = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+            self._side = side_streams(cur.device_index, self.stream_set)
         streams = [cur] + self._side
         sp = [st.cuda_stream for st in streams]
+        if self.trace is not None:
+            return self._run_traced(prog, streams, sp)
         for fn, args, lane in prog:
             rc = fn(streams) if lane < 0 else fn(*args, sp[lane])
+            if rc:
+                hip.check(rc, fn.__name__)
+
+    def _run_traced(self, prog, streams, sp):
+        """`_run` with a timing event before and after every launch, on the launch's lane: the step's timeline as the device sees
+        it without a profiler attached (a kernel-trace profiler adds device-side latency to every dispatch)."""
+        for fn, args, lane in prog:
+            if lane < 0:
+                rc = fn(streams)
+            else:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(streams[lane])
+                rc = fn(*args, sp[lane])
+                b.record(streams[lane])
+                what = fn.__name__
+                if what in ('pg_gemm', 'pg_seg_attn'):
+                    s = args[-1]._obj
+                    what += f'[{s.M}x{s.N}x{s.K1}+{s.K2}]' if what == 'pg_gemm' else f'[mode {s.mode}, {s.n_seg}+{s.n_seg2}]'
+                self.trace.append((what, lane, a, b))
             if rc:
                 hip.check(rc, fn.__name__)
 
@@ -577,6 +663,7 @@ def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, b
     w.x[0].copy_(x)
     w.hb[0].copy_(h_bond if plan.edge_identity else h_bond.index_select(0, plan.edge_ref_long))   # internal bond order
     w.phore_norm.copy_(phore_norm)
+    w.nrm_phore_ctx.index_copy_(0, plan.phore2ctx_long, phore_norm.float())
     prog = []
     eng._denoiser_program(prog, [(plan.lig2ctx, plan.n_lig, True)],
                           [(plan.lig2ctx, plan.n_lig, True), (plan.phore2ctx, plan.n_phore, False)])

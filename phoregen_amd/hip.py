@@ -46,7 +46,7 @@ class PgSegAttn(C.Structure):
                 ('S', c_fp), ('swn', c_fp), ('resid', c_fp), ('out', c_fp), ('dx', c_fp),
                 ('accumulate_dx', C.c_int), ('alpha', c_fp), ('alpha_rows', C.c_int), ('efeat', c_fp), ('efeat_off', c_ip),
                 ('tri_iters', c_ip), ('n_tri_iters', C.c_int), ('tri_counter', c_ip),
-                ('seg_ids2', c_ip), ('n_seg2', C.c_int), ('Wf_k2', c_fp), ('Wf_v2', c_fp), ('tri_grid', C.c_int)]
+                ('seg_ids2', c_ip), ('n_seg2', C.c_int), ('Wf_k2', c_fp), ('Wf_v2', c_fp), ('tri_grid', C.c_int), ('small_wg', C.c_int)]
 
 
 class PgSegAttnGrad(C.Structure):
@@ -85,6 +85,7 @@ _PROTOS = {
     'pg_attn_fold_query': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, c_ip, c_fp, C.c_void_p]),
     'pg_attn_unfold_value': (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, C.c_int, C.c_void_p]),
     'pg_apply_dx': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
+    'pg_layer_geom': (C.c_int, [C.POINTER(PgTopo), c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
     'pg_attn_unfold_bias_grad': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, c_ip, c_fp, c_fp, C.c_void_p]),
     'pg_bond_rows_sum': (C.c_int, [C.POINTER(PgTopo), c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, C.c_void_p]),
     'pg_rows_linear': (C.c_int, [c_fp, C.c_int, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_ip, c_fp, C.c_int,
@@ -113,7 +114,9 @@ def load_library(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or os.environ.get('PHOREGEN_HIP_LIB') or LIB_PATH       # (PHOREGEN_HIP_LIB: an experiment build, tools/)
+    if path is None and os.environ.get('PHOREGEN_DEBUG') == '1':      # an instrumented / ablation build (tools/): only on explicit request
+        path = os.environ.get('PHOREGEN_HIP_LIB')
+    path = path or LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(f'phoregen_amd: HIP extension not built: {path} is missing. '
                            f'Run `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '

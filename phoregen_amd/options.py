@@ -1,0 +1,70 @@
+"""Variant switches of the engine and of the training path.
+
+The values in `DEFAULTS` are the product.  They change in two ways only: `options.override(...)` (a context manager; the tests and
+the measurement tools use it), or -- with `PHOREGEN_DEBUG=1` in the environment, for profiling a stock `bench.py` run from a shell
+script -- through the `PG_*` variables listed in `_ENV`.  Without `PHOREGEN_DEBUG=1` the ambient environment cannot change which
+kernels a model runs.  None of the variants routes around the HIP library.
+"""
+import contextlib
+import os
+
+DEFAULTS = dict(
+    streams=True,         # four lanes (HIP streams) per layer; False: one stream
+    row_subsets=False,    # first-layer blocks only on the rows that read them
+    tri_staged=True,      # csrc/triplet2.hip (False: the gather kernel, triplet.hip)
+    node_fused=True,      # node attention folds the query / unfolds the value in-kernel
+    knn_group=True,       # neighbour slots partitioned by source kind
+    knn_merge='auto',     # ligand + pharmacophore targets of a knn sub-layer in one launch: 'auto' by batch size, 'never', 'always'
+    layer_ahead=True,     # small batches: the next layer's x-independent products inside this layer's position phase
+    tri_grid=-1,          # persistent workgroups of the staged triplet kernel (-1: by batch size)
+    graph=False,          # hipGraph replay of the forward launch list
+    fused_geom='auto',    # coordinate update + bond smearing + direction vectors as one launch on the bond chain's lane (pg_layer_geom):
+                          # 'auto' = small batches (below ~100 graphs of the headline shape), 'never', 'always'
+    small_node='never',   # node attention in 4-wave workgroups: 'auto' by batch size, 'never', 'always'
+    small_node_below=3072,  # ... 'auto': launches with fewer target nodes than this
+    dgrad_mm=True,        # training: input gradients through the library GEMM
+    rows_sum=True,        # training: pg_bond_rows_sum instead of atomic index_add_
+    tri_onepass=True,     # training: one-pass triplet / node adjoints fed by the forward's softmax weights
+    wide_gemm=True,       # training: one wide first-layer GEMM per layer (ColumnBlocksFn)
+    bwd_grid=256,         # training: persistent workgroups of pg_seg_attn_bwd (one per CU)
+)
+
+_tri = lambda v: {'0': 'never', '1': 'auto', '2': 'always'}[v]
+_flag = lambda v: v != '0'
+_ENV = {
+    'PG_STREAMS': ('streams', _flag), 'PG_ROW_SUBSETS': ('row_subsets', _flag), 'PG_TRI_STAGED': ('tri_staged', _flag),
+    'PG_NODE_FUSED': ('node_fused', _flag), 'PG_KNN_GROUP': ('knn_group', _flag), 'PG_KNN_MERGE': ('knn_merge', _tri),
+    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_TRI_GRID': ('tri_grid', int), 'PG_GRAPH': ('graph', _flag),
+    'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_SMALL_NODE': ('small_node', _tri), 'PG_SMALL_NODE_BELOW': ('small_node_below', int), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
+    'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int),
+}
+_overrides = {}
+
+
+def get(name):
+    if name in _overrides:
+        return _overrides[name]
+    if os.environ.get('PHOREGEN_DEBUG') == '1':
+        for var, (key, conv) in _ENV.items():
+            if key == name and var in os.environ:
+                return conv(os.environ[var])
+    return DEFAULTS[name]
+
+
+def snapshot():
+    return {k: get(k) for k in DEFAULTS}
+
+
+@contextlib.contextmanager
+def override(**kw):
+    """Run a block with other variants (an Engine reads them when it is built, the training path per call)."""
+    unknown = set(kw) - set(DEFAULTS)
+    if unknown:
+        raise KeyError(f'phoregen_amd.options: unknown switch(es) {sorted(unknown)}')
+    old = dict(_overrides)
+    _overrides.update(kw)
+    try:
+        yield
+    finally:
+        _overrides.clear()
+        _overrides.update(old)

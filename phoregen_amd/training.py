@@ -11,12 +11,11 @@ itself) is composed from elementwise tensor ops here; the kNN searches stay in t
 No CPU fallback: every entry point raises without the library / a GPU.
 """
 import ctypes as C
-import os
 
 import torch
 import torch.nn.functional as F
 
-from . import hip
+from . import hip, options
 from .packing import HEAD_SCALE, NODE1_PARTS, NODE2_PARTS, PHORE_PARTS, ModelPack
 
 _SMEAR_OFF = (0., 1., 1.25, 1.5, 1.75, 2., 2.25, 2.5, 2.75, 3., 3.5, 4., 4.5, 5., 5.5, 6., 7., 8., 9., 10.)
@@ -35,7 +34,7 @@ def _dgrad(gY, W, gX):
     hipBLASLt through torch.mm), which needs no transposed copy of W and runs the K = 256 ... 1920 contractions of the adjoint
     pass at about twice the rate of the tiled pg_gemm fallback (the streaming pg_gemm kernel covers K = 128 only; training
     step 195 -> 188 ms).  `PG_DGRAD_MM=0`: pg_gemm on W^T, as before."""
-    if os.environ.get('PG_DGRAD_MM', '1') != '0':
+    if options.get('dgrad_mm'):
         torch.mm(gY, W, out=gX)
     else:
         _gemm_raw(gY, W.t().contiguous(), gX)
@@ -177,7 +176,7 @@ class LinearGatherAddFn(torch.autograd.Function):
 
         def gathered_adjoint(shape, idx, kind):
             out = torch.zeros(shape, dtype=torch.float32, device=gY.device)
-            if ctx.topo is not None and kind is not None and os.environ.get('PG_ROWS_SUM', '1') != '0' and shape[1] % 4 == 0 and \
+            if ctx.topo is not None and kind is not None and options.get('rows_sum') and shape[1] % 4 == 0 and \
                     gY.stride(0) % 4 == 0:
                 hip.check(hip.lib().pg_bond_rows_sum(ctx.topo, gY.data_ptr(), gY.stride(0), shape[1], 1 if kind == 'src' else 0,
                                                      out.data_ptr(), out.stride(0), _st()), 'pg_bond_rows_sum')
@@ -322,7 +321,7 @@ class SegCoreFn(torch.autograd.Function):
             s.S, s.swn = out[0].data_ptr(), out[1].data_ptr()
         tf = cfg.get('tri_fwd')
         alpha = None
-        onepass = os.environ.get('PG_TRI_ONEPASS', '1') != '0'
+        onepass = options.get('tri_onepass')
         if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_BOND_NODE, hip.SEG_KNN_POS, hip.SEG_BOND_POS) and onepass and \
                 (cfg['k'] <= 32 if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS) else cfg['max_rows'] <= 80):
             # the two-pass node kernels run (csrc/node_attn.hip): they hand alpha x gate to a one-pass adjoint (node update), or
@@ -334,7 +333,7 @@ class SegCoreFn(torch.autograd.Function):
         if tf is not None:
             for k in ('q', 'W2k_l', 'W2v_l', 'b2v', 'Wg2_k', 'Wg2_v', 'G', 'seg_ids', 'seg_chunks'):
                 setattr(s, k, tf[k].data_ptr())
-            if tf.get('n_tri_iters') and os.environ.get('PG_TRI_STAGED', '1') != '0':
+            if tf.get('n_tri_iters') and options.get('tri_staged'):
                 # source-atom groups of the plan: the LDS-staged kernel (csrc/triplet2.hip, training form) takes the launch
                 s.tri_iters, s.n_tri_iters, s.tri_counter = tf['tri_iters'].data_ptr(), tf['n_tri_iters'], tf['tri_counter'].data_ptr()
             if cfg['max_rows'] <= 80 and onepass:   # the tuned kernel runs: it can hand the softmax weights to the adjoint
@@ -410,7 +409,7 @@ class SegCoreFn(torch.autograd.Function):
         # one persistent workgroup per CU (the adjoints hold a CU's LDS / registers alone): every workgroup stages its weight tables and
         # flushes its weight-gradient accumulators (hundreds of atomics per wave) ONCE, and no partial last round of workgroups is
         # left -- training step 179.5 ms with 1 024 workgroups, 171-173 with 512, 168 with 256 (320: 205, 8 192: 206)
-        grid = max(1, min((cfg['n_seg'] + waves - 1) // waves, int(os.environ.get('PG_BWD_GRID', '256'))))
+        grid = max(1, min((cfg['n_seg'] + waves - 1) // waves, options.get('bwd_grid')))
         rows = (cfg['max_rows'] + 15) // 16 * 16
         rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
         g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
@@ -578,7 +577,7 @@ class TrainForward:
             G = gaussian_smearing((x.index_select(0, bsrc) - x.index_select(0, bdst)).pow(2).sum(-1).clamp(min=1e-24).sqrt())   # [E,20]
 
             # first-layer blocks of the three feature sub-layers (15 x 128 columns of W_node1), one GEMM per consumer
-            if os.environ.get('PG_WIDE_GEMM', '1') != '0':      # one wide GEMM, one adjoint pair (ColumnBlocksFn)
+            if options.get('wide_gemm'):      # one wide GEMM, one adjoint pair (ColumnBlocksFn)
                 Y1 = column_blocks(h, L.W_node1, L.b_node1, NODE1_PARTS)
             else:                                               # A/B knob: one GEMM (and one adjoint pair) per consumer
                 Y1 = lambda c0, c1: linear(h, *L.node1_parts[(c0, c1)])
@@ -604,7 +603,7 @@ class TrainForward:
             hb_new = hb + UnfoldFn.apply(S, swn, a.W2v_l, a.b2v, None, E)
             h_new = h + linear(aggE + aggB, L.W_lin, L.b_lin)
             # coordinate updates from h', h_bond' and the old geometry (uni_denoiser.py:291-296)
-            if os.environ.get('PG_WIDE_GEMM', '1') != '0':
+            if options.get('wide_gemm'):
                 Y2 = column_blocks(h_new, L.W_node2, L.b_node2, NODE2_PARTS)
             else:
                 Y2 = lambda c0, c1: linear(h_new, *L.node2_parts[(c0, c1)])

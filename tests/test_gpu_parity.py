@@ -289,7 +289,8 @@ def test_forward_against_reference_golden(name):
     assert np.array_equal(mine_src, ref_ei[0]) and np.array_equal(mine_dst, ref_ei[1])
     ew_flat = torch.cat([ew[i, :deg[i]] for i in range(nbr.size(0))])
     errs = {'e_w': rel_err(ew_flat, g['L0_in_e_w'][:, 0]), 'phore_enc': rel_err(eng.ws.hp_emb.cpu(), g['phore_enc'])}
-    hn, hbn, xn, aggE, aggB, dxe, dxb, nrm, hbc = (a.cpu() for a in dbg['L0'])
+    hn, hbn, xn, dxe, dxb, hbc = (a.cpu() for a in dbg['L0'])
+    aggE, aggB = (a.cpu() for a in dbg['A0'])
     inv = plan.edge_int_long.cpu()                       # bond rows inside the engine are in the plan's internal order
     hbn, hbc = hbn[inv], hbc[inv]
     errs.update(L0_node_edge=rel_err(aggE, g['L0_node_edge']), L0_node_bond=rel_err(aggB, g['L0_node_bond']),
@@ -721,44 +722,49 @@ def test_engine_variants_agree(model):
     inp, _, _ = _headline_inputs(12, seed=9)
     dev_inp = {k: v.to(DEV) for k, v in inp.items()}
 
-    def run(env=None, gemm_mode=None):
-        old_env = {k: os.environ.get(k) for k in (env or {})}
-        os.environ.update(env or {})
+    def run(gemm_mode=None, **switches):
+        from phoregen_amd import options
         old_mode = hip.lib().pg_debug_gemm_streaming(gemm_mode) if gemm_mode is not None else None
         try:
             model._engine = None                      # the switches are read when an Engine is built
-            with torch.no_grad():
+            with options.override(**switches), torch.no_grad():
                 return [o.cpu().clone() for o in model(**dev_inp)[:3]]
         finally:
-            for k, v in old_env.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             if old_mode is not None:
                 hip.lib().pg_debug_gemm_streaming(old_mode)
             model._engine = None
     base = run()
-    serial = run({'PG_STREAMS': '0'})
+    serial = run(streams=False)
     assert all(torch.equal(a, b) for a, b in zip(base, serial))
-    replay = run({'PG_GRAPH': '1'})                   # hipGraph capture of the four-lane launch list
+    replay = run(graph=True)                   # hipGraph capture of the four-lane launch list
     assert all(torch.equal(a, b) for a, b in zip(base, replay))
     with torch.no_grad():                             # the four-lane launch list is race-free: repeated runs give the same bits
         for _ in range(6):
             again = [o.cpu() for o in model(**dev_inp)[:3]]
             assert all(torch.equal(a, b) for a, b in zip(base, again))
-    layer_by_layer = run({'PG_LAYER_AHEAD': '0'})     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
+    # the coordinate-only kernels as three launches on three lanes (pg_apply_dx, pg_bond_smear, pg_lig_normals) instead of pg_layer_geom
+    assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never')))
+    assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never', streams=False)))
+    layer_by_layer = run(layer_ahead=False)     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
     assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
-    for grid in ('0', '96', '200'):                   # persistent triplet workgroups (small batches leave CUs to the side lanes):
-        assert all(torch.equal(a, b) for a, b in zip(base, run({'PG_TRI_GRID': grid})))     # the queue hands out the same segments
-    two_launches = run({'PG_KNN_MERGE': '0'})         # ligand / pharmacophore targets of a knn sub-layer as two launches ...
-    one_launch = run({'PG_KNN_MERGE': '2'})           # ... or as one launch with the workgroups split between the lists (the default only
+    for grid in (0, 96, 200):                   # persistent triplet workgroups (small batches leave CUs to the side lanes):
+        assert all(torch.equal(a, b) for a, b in zip(base, run(tri_grid=grid)))     # the queue hands out the same segments
+    two_launches = run(knn_merge='never')         # ligand / pharmacophore targets of a knn sub-layer as two launches ...
+    one_launch = run(knn_merge='always')           # ... or as one launch with the workgroups split between the lists (the default only
     assert all(torch.equal(a, b) for a, b in zip(base, two_launches))     # from ~60 graphs up): same bits per node either way
     assert all(torch.equal(a, b) for a, b in zip(base, one_launch))
+    # node attention in 4-wave workgroups with W2k streamed through L2 (small batches) or in persistent 12-wave workgroups with W2k
+    # in LDS (large ones): the same arithmetic per node
+    for kw in (dict(small_node='always'), dict(small_node='never'), dict(small_node='always', knn_merge='always'),
+               dict(small_node='never', knn_merge='never')):
+        assert all(torch.equal(a, b) for a, b in zip(base, run(**kw))), kw
     old_dbg = hip.lib().pg_debug_force_generic_seg(1)  # the one-pass fallback takes a two-list call list after list
     try:
-        generic_two_lists = run({'PG_KNN_MERGE': '2'})
+        generic_two_lists = run(knn_merge='always')
     finally:
         hip.lib().pg_debug_force_generic_seg(old_dbg)
     assert max(rel_err(a, b) for a, b in zip(generic_two_lists, base)) <= 2e-5
-    for variant in (run({'PG_NODE_FUSED': '0'}), run({'PG_TRI_STAGED': '0'}), run(gemm_mode=0)):
+    for variant in (run(node_fused=False), run(tri_staged=False), run(gemm_mode=0)):
         assert max(rel_err(a, b) for a, b in zip(variant, base)) <= 2e-5
 
 

@@ -13,7 +13,7 @@ for B in (1, 10, 30):
     args = (hp.repeat(B, 1), pp.repeat(B, 1), pn.repeat(B, 1), bp, na, torch.zeros(B, 3))
     out = {}
     for mode in ('0', '1'):
-        os.environ['PG_GRAPH'] = mode
+        os.environ['PHOREGEN_DEBUG'], os.environ['PG_GRAPH'] = '1', mode
         model._engine = None
         r = model.sample_batch(*args, rng='device', seed=11, num_steps=20)      # warm
         torch.cuda.synchronize(); t0 = time.perf_counter()

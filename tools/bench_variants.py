@@ -1,0 +1,36 @@
+"""ms per sampler step for several batch sizes and engine variants in ONE process (same box, alternating runs).
+usage: bench_variants.py 16,32,128 "base" "fused_geom=False" "tri_grid=224,knn_merge='always'" ...   (options.override keywords)"""
+import sys, time, torch
+sys.path.insert(0, '/root/repo')
+from bench import ligphore_workload
+from phoregen_amd import options
+from phoregen_amd.config import default_model_config
+from phoregen_amd.models.diffusion import PhoreDiff
+from phoregen_amd.weights import init_deterministic_
+
+Gs = [int(g) for g in sys.argv[1].split(',')]
+variants = sys.argv[2:] or ['base']
+model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to('cuda')
+W, K, R = 8, 30, 3
+for G in Gs:
+    w = ligphore_workload(G)
+    for rep in range(2):                                   # every variant twice, alternating
+        for v in variants:
+            kw = {} if v == 'base' else eval('dict(%s)' % v)
+            with options.override(**kw):
+                model._engine = None
+                st = model.begin_sampling(w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'], w['num_atoms'],
+                                          torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + R * K)
+                for i in range(W):
+                    model.reverse_step(st, i, 999 - i)
+                ts = []
+                for r in range(R):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(W + r * K, W + (r + 1) * K):
+                        model.reverse_step(st, i, 999 - i)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0) / K * 1e3)
+                print(f'G={G:4d} {v:40s} {sorted(ts)[1]:7.3f} ms/step   blocks {["%.3f" % t for t in ts]}', flush=True)
+                del st
+                model._engine = None

@@ -3,4 +3,4 @@
 # and prints the split of one training step (GPU box)
 set -e
 cd $GRAFT_REPO_ROOT/phoregen_amd/csrc && make -j8 EXTRA=-DPG_BWD_PROF OUT=../_lib_prof > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT && PHOREGEN_HIP_LIB=phoregen_amd/_lib_prof/libphoregen_hip.so python3 tools/prof_bwd.py
+cd $GRAFT_REPO_ROOT && PHOREGEN_DEBUG=1 PHOREGEN_HIP_LIB=phoregen_amd/_lib_prof/libphoregen_hip.so python3 tools/prof_bwd.py

@@ -5,7 +5,7 @@
 tag=${1:-r03}; pat=${2:-triplet2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for mode in streams serial; do
-  if [ $mode = serial ]; then export PG_STREAMS=0; else unset PG_STREAMS; fi
+  if [ $mode = serial ]; then export PHOREGEN_DEBUG=1 PG_STREAMS=0; else unset PG_STREAMS; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_$mode -- python3 bench.py --no-cpu-baseline --steps 20 --repeats 1 > gpurun_out/${tag}_bench_$mode.json 2> gpurun_out/${tag}_prof_$mode.log
   find gpurun_out/${tag}_prof_$mode -name "*.csv" ! -name "*kernel_stats.csv" -delete
 done

@@ -7,7 +7,7 @@ steps=8
 warmup=2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/traffic_${tag}
-export PG_STREAMS=0
+export PHOREGEN_DEBUG=1 PG_STREAMS=0
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/traffic_${tag}/$c -- python3 bench.py --no-cpu-baseline --steps $steps --warmup $warmup --repeats 1 > gpurun_out/traffic_${tag}/$c.log 2>&1 \
     || { echo "rocprofv3 --pmc $c failed:"; tail -20 gpurun_out/traffic_${tag}/$c.log; exit 1; }
