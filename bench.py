@@ -7,7 +7,7 @@ config 3) on N MI355X GPUs.
 A "step" is one iteration of the reverse-diffusion loop (models/diffusion.py:432-517): denoiser forward + categorical
 posteriors + Gaussian posterior + trajectory write, on synthetic graphs of the LigPhore shape and deterministic
 random-init weights, inputs resident in HBM.  Graphs are independent: by default ONE 128-graph batch is partitioned over the
-N ranks by n^3 (strong scaling, the figure SURVEY.md 8(d) and the ">= 6x at 8 GPUs" target refer to; `--weak` gives every rank
+N ranks by the fitted step cost (strong scaling, the figure SURVEY.md 8(d) and the ">= 6x at 8 GPUs" target refer to; `--weak` gives every rank
 its own 128-graph batch instead), no collective inside the loop; the only collective is the final gather of `pred` over RCCL,
 exercised after the timed region.  Prints ONE JSON line on rank 0.
 """
@@ -93,7 +93,7 @@ def triplet_tiles(n_at):
 
 
 def knn_node_mfma(eng):
-    """16x16x4 MFMAs one knn-node sub-layer (csrc/node_attn.hip, both launches: ligand + pharmacophore targets) EXECUTES on the
+    """16x16x4 MFMAs one knn-node sub-layer (csrc/node_attn.hip: ligand + pharmacophore targets, as one merged launch or two) EXECUTES on the
     engine's current neighbour lists: per 16-row tile and pass 8 x (2 + 5 [tile has ligand sources] + 5 [tile has pharmacophore
     sources]) first-layer steps + 32 for the logits / the value aggregate; two passes.  (The neighbour slots are partitioned by
     source kind, ligand atoms first: pg_knn_group_by_kind.)"""
@@ -111,6 +111,63 @@ def knn_node_mfma(eng):
         has_p = in_tile & (deg > n_l) & (torch.minimum(deg, torch.tensor(t0 + 16, device=deg.device)) > n_l)
         total += int((in_tile.long() * (8 * 2 + 32) + has_l.long() * 40 + has_p.long() * 40).sum())
     return 2 * total
+
+
+def executed_flops(eng):
+    """fp32 FLOPs the launches of ONE denoiser forward EXECUTE on the matrix / vector pipes, by kernel class, from the engine's own
+    launch list and neighbour lists (the numerator of `step_roofline.exec_frac`):
+      gemm      2 M N K of every pg_gemm / pg_rows_linear launch (their fused epilogues are not counted);
+      triplet   112 MFMA 16x16x4 per 16-row tile + query fold / value unfold per segment, padding rows included;
+      knn_node  knn_node_mfma() x 2048 + fold / unfold per node;  knn_pos: both MLP paths in the key layout + the 16-column
+                value product per tile, fold per ligand atom;  bond_node / bond_pos: 64 MFMA per 16-row tile of the ligand
+                (no feature columns) + fold (/ unfold);
+      gate      80 MFMA per context node (2 tiles x 5 steps x 8).
+    Elementwise kernels (embeddings, knn search, geometry, posteriors) execute no matrix work and are left out."""
+    import ctypes as C
+    from phoregen_amd import hip
+    p, w, lib = eng.plan, eng.ws, eng.lib
+    out = dict(gemm=0, triplet=0, knn_node=0, knn_pos=0, bond_node=0, bond_pos=0, gate=80 * 2048 * p.n_ctx)
+    n_at = p.num_atoms
+    tri_tiles = int((triplet_tiles(n_at) * n_at * (n_at - 1)).sum())
+    node_tiles = int((((n_at + 15) // 16) * n_at).sum())             # bond modes: a ligand atom walks ceil(n / 16) tiles
+    fold = 2 * 128 * 128
+    # knn-pos tiles: ligand targets only, first-layer steps per tile as in knn_node_mfma
+    deg = w.deg.long()
+    k = w.nbr.size(1)
+    valid = torch.arange(k, device=deg.device)[None, :] < deg[:, None]
+    is_lig = torch.zeros(p.n_ctx, dtype=torch.bool, device=deg.device)
+    is_lig[p.lig2ctx_long] = True
+    n_l = (is_lig[w.nbr.long().clamp(min=0)] & valid).sum(1)
+    pos_mfma = 0
+    for t0 in range(0, k, 16):
+        in_tile = (deg > t0) & is_lig
+        has_l = in_tile & (n_l > t0)
+        has_p = in_tile & (deg > n_l) & (torch.minimum(deg, torch.tensor(t0 + 16, device=deg.device)) > n_l)
+        pos_mfma += int((in_tile.long() * 2 * (16 + 32) + has_l.long() * 80 + has_p.long() * 80).sum())
+    knn_mf = knn_node_mfma(eng)
+    for fn, args, lane in eng.prog_fwd:
+        if lane < 0:
+            continue
+        if fn is lib.pg_gemm:
+            g = args[0]._obj
+            out['gemm'] += 2 * g.M * g.N * (g.K1 + g.K2)
+        elif fn is lib.pg_rows_linear:
+            out['gemm'] += 2 * args[6] * args[5] * args[2]
+        elif fn is lib.pg_seg_attn:
+            sa = args[1]._obj
+            if sa.mode == hip.SEG_TRIPLET:
+                out['triplet'] += tri_tiles * 112 * 2048 + p.n_bond * 2 * fold
+            elif sa.mode == hip.SEG_KNN_NODE:            # (one or two launches per sub-layer: counted once per sub-layer below)
+                out['knn_node'] += (sa.n_seg + sa.n_seg2) * 2 * fold
+            elif sa.mode == hip.SEG_KNN_POS:
+                out['knn_pos'] += pos_mfma * 2048 + sa.n_seg * fold
+            elif sa.mode == hip.SEG_BOND_NODE:
+                out['bond_node'] += node_tiles * 64 * 2048 + sa.n_seg * 2 * fold
+            elif sa.mode == hip.SEG_BOND_POS:
+                out['bond_pos'] += node_tiles * 64 * 2048 + sa.n_seg * fold
+    out['knn_node'] += len(eng.pack.layers) * knn_mf * 2048
+    out['total'] = sum(out.values())
+    return out
 
 
 def algorithmic_counts(n_at, n_ph, knn=32, H=128):
@@ -230,7 +287,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--weak', action='store_true',
                     help='weak scaling only: --graphs graphs PER GPU (default: strong scaling, SURVEY.md 8d: ONE batch of '
-                         '--graphs graphs partitioned over the ranks by n^3 cost; a weak-scaling figure is added for N > 1)')
+                         '--graphs graphs partitioned over the ranks by the fitted step cost; a weak-scaling figure is added for N > 1)')
     ap.add_argument('--strong', action='store_true', help='(default) kept for compatibility')
     ap.add_argument('--train', action='store_true',
                     help='BASELINE config 5 instead: one compute_loss forward + backward + Adam step on 256 synthetic pairs '
@@ -305,16 +362,18 @@ def main():
                 st.eng.timers = None
         if time_triplet:
             run.knn_ms, run.knn_mfma = knn, knn_node_mfma(st.eng)
+            run.exec_flops = executed_flops(st.eng)
+            run.knn_launches = 1 if any(a[1]._obj.mode == 0 and a[1]._obj.n_seg2 > 0 for f, a, l in st.eng.prog_fwd if l >= 0 and f is st.eng.lib.pg_seg_attn) else 2
         return times, tri, model.finish_sampling(st)
 
-    # ---- strong scaling (headline): ONE batch of --graphs graphs, partitioned over the ranks by n^3 cost ----
+    # ---- strong scaling (headline): ONE batch of --graphs graphs, partitioned over the ranks by phoregen_amd.parallel.graph_cost ----
     full = ligphore_workload(args.graphs, seed=1234, fixed_shape=args.fixed_shape)
     if args.weak:
         work = ligphore_workload(args.graphs, seed=1234 + rank, fixed_shape=args.fixed_shape)   # each rank: its own graphs
         mine = torch.arange(args.graphs) + rank * args.graphs
         total_graphs = world * args.graphs
     else:
-        mine = partition_graphs(full['num_atoms'], world)[rank]
+        mine = partition_graphs(full['num_atoms'], world, full['n_phore'])[rank]
         work = subset_workload(full, mine) if world > 1 else full
         total_graphs = args.graphs
     counts = algorithmic_counts(work['num_atoms'], work['n_phore'])
@@ -352,7 +411,7 @@ def main():
             'scaling': 'weak' if args.weak else 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'BASELINE.json configs[2]: ONE batch of {args.graphs} LigPhore-shaped graphs '
                                    '(n~N(40,6) atoms, p~N(107,30) pharmacophore nodes)' +
-                                   (' per GPU' if args.weak else f', partitioned over {world} GPU(s) by n^3 cost') +
+                                   (' per GPU' if args.weak else f', partitioned over {world} GPU(s) by the fitted step cost') +
                                    ', steps t=999.. of the 1000-step sampler, device Philox noise, trajectory written',
                        'graphs_total': total_graphs, 'graphs_rank0': int(work['num_atoms'].numel()), 'fixed_shape': args.fixed_shape,
                        'n_ctx': counts['n_all'], 'n_lig': counts['n_lig'], 'e_knn': counts['e_knn'], 'e_bond': counts['e_bond'],
@@ -374,17 +433,23 @@ def main():
                          'share_of_step': (6 * tri_avg_ms) / (dt / K * 1e3) if tri_ms else None},
             # the kernel furthest below its roofline (round-2 review): the knn-node attention sub-layer, both launches of a layer
             'roofline_knn_node': (lambda ms, mf: {
-                'kernel': 'knn-node attention (pg_seg_attn PG_SEG_KNN_NODE fused form, node_attn_kernel<true,false,2,768,true>, '
-                          '2 launches per layer: ligand targets + pharmacophore targets), rank 0',
+                'kernel': 'knn-node attention (pg_seg_attn PG_SEG_KNN_NODE fused form, node_attn_kernel<true,false,2,768,true,true>), '
+                          + ('ONE launch per layer serving the ligand and the pharmacophore target lists' if run.knn_launches == 1 else
+                             '2 launches per layer: ligand targets, pharmacophore targets') + ', rank 0',
                 'bound': 'mfma', 'peak': peak_tf, 'unit': 'TFLOP/s', 'avg_sublayer_ms': ms, 'sublayers_timed': len(run.knn_ms),
                 'flops_per_sublayer': mf * 2048 + 2 * 2 * 128 * 128 * counts['n_all'],
                 'achieved': (mf * 2048 + 2 * 2 * 128 * 128 * counts['n_all']) / (ms * 1e-3) / 1e12,
                 'frac': (mf * 2048 + 2 * 2 * 128 * 128 * counts['n_all']) / (ms * 1e-3) / 1e12 / peak_tf,
                 'note': 'achieved = fp32 FLOPs EXECUTED (16x16x4 MFMAs counted from the current neighbour lists, kind-uniform tiles '
-                        'skip the other kind\'s distance columns, + query fold / value unfold per node) / mean duration of the two '
-                        'launches (HIP events on their lane); inside the four-lane step, other lanes run beside it'})(
+                        'skip the other kind\'s distance columns, + query fold / value unfold per node) / mean duration of the '
+                        'sub-layer (HIP events on its lane around its launch(es)); inside the four-lane step, other lanes run beside it'})(
                 sum(run.knn_ms) / max(len(run.knn_ms), 1), run.knn_mfma) if getattr(run, 'knn_ms', None) else None,
-            'step_roofline': {'flops_alg_survey': counts['flops_step'], 'bytes_alg': counts['bytes_step'],
+            'step_roofline': {'flops_executed': run.exec_flops['total'], 'flops_executed_by_kernel': run.exec_flops,
+                              'exec_frac': run.exec_flops['total'] / (dt / K) / (peak_tf * 1e12),
+                              'exec_note': 'fp32 FLOPs EXECUTED by all launches of a step (bench.executed_flops: GEMMs 2MNK from the launch '
+                                           'list, attention kernels by MFMA count incl. padding rows + fold / unfold) / step time / fp32 '
+                                           'MFMA peak: the utilisation of the whole step, rank 0',
+                              'flops_alg_survey': counts['flops_step'], 'bytes_alg': counts['bytes_step'],
                               'survey_mfma_frac': counts['flops_step'] / (dt / K) / (peak_tf * 1e12),
                               'hbm_frac': counts['bytes_step'] / (dt / K) / 8e12,
                               'note': 'rank-0 share of the batch; survey_mfma_frac uses SURVEY 8d FLOPs (unfolded form) and is not a '
@@ -392,12 +457,13 @@ def main():
             'weak_scaling': weak,
             'final_gather_ms': gather_ms,
         }
-        if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(full)
+        if not args.no_cpu_baseline:           # rank 0, after the timed region, at every world size (the other ranks wait at the
+            line['cpu_baseline'] = cpu_baseline(full)      # final barrier below)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                  # (rank 0 times the CPU baseline after the timed region; the others wait here)
         dist.destroy_process_group()
 
 

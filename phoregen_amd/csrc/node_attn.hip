@@ -498,10 +498,12 @@ static int launch_na(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   return check_launch("pg_seg_attn(node)");
 }
 
-template <bool FUSED, bool SMALL>
+// FORM (fused): 0 = 12-wave persistent workgroups, W2k in LDS; 1 = 4-wave workgroups, W2k through L2 (small batches);
+// 2 = 8-wave persistent workgroups, W2k in LDS (256 registers per lane: no spills, two waves per SIMD)
+template <bool FUSED, int FORM>
 static int launch_node_attn_t(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
-  constexpr int TH = (FUSED && !SMALL) ? 768 : 256;
-  constexpr bool WL = FUSED && !SMALL;
+  constexpr int TH = !FUSED ? 256 : (FORM == 0 ? 768 : (FORM == 1 ? 256 : 512));
+  constexpr bool WL = FUSED && FORM != 1;
   const bool knn = p->mode == PG_SEG_KNN_NODE || p->mode == PG_SEG_KNN_POS;
   const bool pos = p->mode == PG_SEG_KNN_POS || p->mode == PG_SEG_BOND_POS;
   if (knn) {
@@ -533,8 +535,10 @@ int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
     set_error("pg_seg_attn: Wf_k / Wf_v / W2xv_l must be 16-byte aligned");
     return PG_ERR_ARG;
   }
-  if (!node_attn_fused_request(p)) return launch_node_attn_t<false, false>(t, p, st);
-  return p->small_wg ? launch_node_attn_t<true, true>(t, p, st) : launch_node_attn_t<true, false>(t, p, st);
+  if (!node_attn_fused_request(p)) return launch_node_attn_t<false, 0>(t, p, st);
+  if (p->small_wg == 1) return launch_node_attn_t<true, 1>(t, p, st);
+  if (p->small_wg == 2) return launch_node_attn_t<true, 2>(t, p, st);
+  return launch_node_attn_t<true, 0>(t, p, st);
 }
 
 }  // namespace pg

@@ -31,6 +31,15 @@ namespace pg {
 
 typedef float t2_f2 __attribute__((ext_vector_type(2)));
 
+// -DPG_DEGRADE_BITS=n (tools/degraded_build_check.sh, never the product build): the activations that enter the second-layer
+// products lose their n lowest mantissa bits -- a deliberately less precise kernel, to show that the aggregate parity guard
+// (tests/helpers.py AGG_MEDIAN_BOUND) fails on a uniform precision regression that the per-step bounds let through
+#ifdef PG_DEGRADE_BITS
+#define T2_DEGRADE(v) __builtin_bit_cast(float, __builtin_bit_cast(unsigned, (v)) & (0xffffffffu << PG_DEGRADE_BITS))
+#else
+#define T2_DEGRADE(v) (v)
+#endif
+
 constexpr int T2_ROW = 260;          // floats per staged row: P_k[128] | P_v[128] | 4 (bank spread of the b128 key-layout reads)
 constexpr int T2_ROWS = 80;          // staged rows per workgroup
 constexpr int T2_XS = 96;            // ligand atoms whose coordinates are staged
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
             for (int tq = 0; tq < 8; ++tq) {
               const f4 bt = *reinterpret_cast<const f4*>(bk + 16 * tq + 4 * g);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) acc4[r] = mfma16(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f), U[tq][r], acc4[r]);
+              for (int r = 0; r < 4; ++r) acc4[r] = mfma16(T2_DEGRADE(fmaxf(fmaf(bt[r], sigma, hid[tq][r]), 0.f)), U[tq][r], acc4[r]);
             }
             f4 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
 #pragma unroll
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
           for (int tq = 0; tq < 8; ++tq) {
             const float bt = bv[m * 8 + tq];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hv[tq][r] = fmaxf(fmaf(bt, sg[r], hv[tq][r]), 0.f);
+            for (int r = 0; r < 4; ++r) hv[tq][r] = T2_DEGRADE(fmaxf(fmaf(bt, sg[r], hv[tq][r]), 0.f));
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r)            // r outer: 8 independent accumulator chains

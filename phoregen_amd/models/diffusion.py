@@ -174,6 +174,19 @@ class PhoreDiff(nn.Module):
         self.packed()
         if self._plan is None or not self._plan.matches(batch_node, batch_phore, edge_index):
             self._plan = BatchPlan(batch_node, batch_phore, edge_index, batch_edge, time_step.numel(), self._device())
+        floats = (h_node_pert, pos_pert, h_edge_pert, h_phore, pos_phore, phore_norm)
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                        any(torch.is_tensor(a) and a.requires_grad for a in floats)):
+            # the reference's forward is differentiable (diffusion.py:175-246, used under autograd by :267): with gradients being
+            # recorded the same kernels run with their hand-written HIP adjoints on the tape (phoregen_amd/training.py), so a
+            # caller's own loss on these outputs reaches the parameters (and pos_pert / h_node_pert).  Under torch.no_grad()
+            # (sampling) the pre-built launch list below runs instead.
+            from ..training import TrainForward
+            dev = self._device()
+            params = {**dict(self.named_buffers()), **dict(self.named_parameters())}
+            tf = TrainForward(params, self._plan, knn_k=self.denoiser.k, num_layers=self.denoiser.num_layers, ex_col=self.ex_col)
+            return tf.forward(h_node_pert.to(dev), pos_pert.to(dev), h_edge_pert.to(dev), time_step.to(dev), h_phore.to(dev).float(),
+                              pos_phore.to(dev).float(), phore_norm.to(dev).float(), batch_phore.to(dev))
         eng = self.engine_for(self._plan)
         eng.encode_phore(h_phore, pos_phore, phore_norm, self.ex_col)
         v, x0, bond = eng.forward(h_node_pert.float(), pos_pert.float(), h_edge_pert.float(), time_step)

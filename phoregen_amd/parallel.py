@@ -8,10 +8,28 @@ import torch
 import torch.distributed as dist
 
 
-def partition_graphs(num_atoms, world_size):
-    """Greedy balanced partition by the triplet cost n^3 (the dominant term).  Returns a list of LongTensors of
-    graph ids (ascending inside each rank, so results can be re-assembled deterministically)."""
-    cost = num_atoms.double() ** 3
+# What a graph of n atoms and p pharmacophore nodes costs inside a sampler step, in microseconds, from the kernel tables of the
+# headline batch (profiles/r03_bench_serial_kernel_stats.md, 128 graphs, one stream): the triplet kernel's row tiles (618 440 tiles
+# of 16 rows <-> 6 x 1.95 ms), everything that scales with the bond edges n (n - 1) (their GEMMs and the two bond attention
+# modes: 203 720 edges <-> 6.2 ms), everything that scales with the context nodes n + p (knn attention, node GEMMs, knn search,
+# gate: 18 816 nodes <-> 3.0 ms).  Only the ratios matter for the partition.
+COST_US = dict(tile=11.7e3 / 618440, bond=6.2e3 / 203720, node=3.0e3 / 18816)
+
+
+def graph_cost(num_atoms, n_phore=None):
+    """Per-graph cost model of a sampler step (see COST_US).  Without pharmacophore sizes the node term counts the atoms only."""
+    n = num_atoms.double()
+    tiles = torch.div(num_atoms.clamp(min=1) - 1 + 15, 16, rounding_mode='floor').double()       # 16-row tiles per triplet segment
+    ctx = n + (n_phore.double() if n_phore is not None else 0.0)
+    return COST_US['tile'] * tiles * n * (n - 1) + COST_US['bond'] * n * (n - 1) + COST_US['node'] * ctx
+
+
+def partition_graphs(num_atoms, world_size, n_phore=None):
+    """Greedy (longest-processing-time) balanced partition of independent graphs over the ranks by `graph_cost`: the triplet
+    term ~ n^3 dominates a large graph, but at the 16 graphs a rank gets of the headline batch 45 % of a step scales with n^2 and
+    n + p (p ranges 23 .. 203), so n^3 alone picks the wrong slowest rank.  Returns a list of LongTensors of graph ids
+    (ascending inside each rank, so results can be re-assembled deterministically)."""
+    cost = graph_cost(num_atoms, n_phore)
     order = torch.argsort(cost, descending=True, stable=True)
     load = [0.0] * world_size
     parts = [[] for _ in range(world_size)]
@@ -75,6 +93,12 @@ class SamplingJob:
     def n_graphs(self):
         return int(self.num_atoms.numel())
 
+    @property
+    def n_phore(self):
+        """Pharmacophore nodes of every graph (the node term of the partition's cost model)."""
+        sizes = torch.tensor([int(ph[0].size(0)) for ph in self.phores], dtype=torch.long)
+        return sizes[self.graph_phore]
+
     def batch_inputs(self, gids):
         xs, ps, ns, cs, bp = [], [], [], [], []
         for i, g in enumerate(gids.tolist()):
@@ -112,10 +136,10 @@ def sample_job_shard(model, job, graph_ids, batch_size=128, seed=0, num_steps=No
 
 
 def run_sampling_job(model, job, world=1, rank=0, batch_size=128, seed=0, num_steps=None, pos_guidance_opt=None, group=None):
-    """Config 4 end to end on one rank: n^3-balanced partition of ALL graphs of the job, this rank's shard in batches, then
+    """Config 4 end to end on one rank: cost-balanced partition (graph_cost) of ALL graphs of the job, this rank's shard in batches, then
     the one collective of the path (gather of `pred`).  Returns (pred_global, num_atoms_global) in global graph order when
     torch.distributed is initialised (every rank), else this rank's (pred, num_atoms) in its graph_ids order."""
-    mine = partition_graphs(job.num_atoms, world)[rank]
+    mine = partition_graphs(job.num_atoms, world, job.n_phore)[rank]
     pred = sample_job_shard(model, job, mine, batch_size, seed, num_steps, pos_guidance_opt)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         return gather_predictions(pred, job.num_atoms[mine], mine, group)
@@ -200,6 +224,9 @@ class GradientBuckets:
             raise RuntimeError('GradientBuckets: a parameter received a second gradient before finish() -- call finish() after '
                                'every backward() (gradient accumulation over micro-batches is not supported by the hook path)')
         if self.work[bi] is not None:
+            # earlier buckets have collectives in flight: drain them and start over, so that the state is usable after the error
+            # (on more than one rank the peers must reach the same decision -- the absent set is agreed on in finish())
+            self._abandon()
             raise RuntimeError('GradientBuckets: a parameter that had no gradient in the previous step received one after its '
                                'bucket was launched; call reset_absent() when the set of used parameters changes')
         self.fired[bi].add(id(p))
@@ -208,6 +235,16 @@ class GradientBuckets:
 
     def _complete(self, bi):
         return len(self.fired[bi] | self.absent[bi]) == len(self.buckets[bi])
+
+    def _abandon(self):
+        """Wait for whatever is in flight and forget this backward (error path)."""
+        for bi, w in enumerate(self.work):
+            if w is not None and w is not True:
+                w.wait()
+            self.flat[bi], self.work[bi], self.fired[bi] = None, None, set()
+        self.next_launch = 0
+        self.launch_log = []
+        self.reset_absent()
 
     def reset_absent(self):
         """Forget which parameters were unused in the previous step (every bucket waits for all of its parameters again)."""
@@ -225,9 +262,22 @@ class GradientBuckets:
     def finish(self):
         """Wait for every bucket (launching the ones whose hooks did not all fire) and write the reduced gradients back."""
         world = dist.get_world_size(self.group) if self._active() else 1
+        any_fired = any(self.fired)
         while self.next_launch < len(self.buckets):
             self._launch(self.next_launch)
+        # which parameters produced a gradient, agreed on by ALL ranks (a parameter used on any rank is waited for on every rank
+        # in the next step: per-rank sets would make the ranks launch different bucket sequences)
+        used = torch.tensor([1 if id(p) in self.fired[bi] else 0 for bi, b in enumerate(self.buckets) for p in b], dtype=torch.int32)
+        if world > 1:
+            dev = self.buckets[0][0].device if dist.get_backend(self.group) != 'gloo' else torch.device('cpu')
+            used = used.to(dev)
+            any_t = torch.tensor([1 if any_fired else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(any_t, op=dist.ReduceOp.MAX, group=self.group)
+            any_fired = bool(int(any_t.item()))
+        used = used.cpu().tolist()
         n_elems = 0
+        k = 0
         for bi, b in enumerate(self.buckets):
             if self.work[bi] is not True:
                 self.work[bi].wait()
@@ -247,7 +297,9 @@ class GradientBuckets:
             if dst:
                 torch._foreach_copy_(dst, src)          # one multi-tensor launch per bucket instead of one copy per parameter
             n_elems += off
-            self.absent[bi] = {id(p) for p in b} - self.fired[bi]
+            if any_fired:                   # (a finish() without a backward says nothing about which parameters are used)
+                self.absent[bi] = {id(p) for j, p in enumerate(b) if not used[k + j]}
+            k += len(b)
             self.flat[bi], self.work[bi], self.fired[bi] = None, None, set()
         self.next_launch = 0
         return n_elems

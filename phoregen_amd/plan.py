@@ -142,28 +142,37 @@ class BatchPlan:
         self.topo = t
         self.topo_ref = C.byref(t)
         self.key = (bn.numel(), bp.numel(), ei.size(1), B)
-        self._cpu_sig = (bn, bp, ei_ref)
+        self._cpu_sig = (bn.clone(), bp.clone(), ei_ref.clone())     # (copies: .cpu().long() of a CPU long tensor is the caller's own storage)
         self.ws = None   # engine workspace, attached lazily
 
     @staticmethod
-    def _ident(*tensors):
-        """Identity of the caller's index tensors: same storage, same shape, no in-place write since."""
-        return tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, str(t.device), t.dtype) for t in tensors)
+    def _versions(tensors):
+        """Version counters of the caller's index tensors, or None when one of them does not track versions (tensors created
+        under torch.inference_mode()): then only the contents can tell."""
+        try:
+            return tuple(t._version for t in tensors)
+        except RuntimeError:
+            return None
 
     def matches(self, batch_node, batch_phore, edge_index):
-        """Is this the topology the plan was built for?  The same tensor objects as last time (same storage, unmodified) answer
-        without touching their contents; otherwise the contents are compared on the host -- for device tensors that is a
-        device -> host copy which WAITS for everything enqueued before it (a training loop that calls compute_loss on the same
-        batch object every step would otherwise drain the GPU once per step: 142 ms of a 258 ms step were spent in that wait)."""
-        ident = self._ident(batch_node, batch_phore, edge_index)
-        if ident == getattr(self, '_last_ident', None):
-            return True
+        """Is this the topology the plan was built for?  The same tensor OBJECTS as the last match, unmodified since (version
+        counters), answer without touching their contents; otherwise the contents are compared on the host -- for device tensors
+        that is a device -> host copy which WAITS for everything enqueued before it (a training loop that calls compute_loss on the
+        same batch object every step would otherwise drain the GPU once per step: 142 ms of a 258 ms step were spent in that wait).
+        The plan keeps references to the three tensors that matched: an object that is held alive cannot have its storage
+        recycled for a different batch of the same shapes."""
+        now = (batch_node, batch_phore, edge_index)
+        last = getattr(self, '_last_match', None)
+        if last is not None and all(a is b for a, b in zip(now, last[0])):
+            ver = self._versions(now)
+            if ver is not None and ver == last[1]:
+                return True
         bn, bp, ei = self._cpu_sig
         same = (batch_node.numel() == bn.numel() and batch_phore.numel() == bp.numel() and
                 edge_index.shape == ei.shape and torch.equal(batch_node.cpu(), bn) and
                 torch.equal(batch_phore.cpu(), bp) and torch.equal(edge_index.cpu(), ei))
         if same:
-            self._last_ident = ident
+            self._last_match = (now, self._versions(now))
         return same
 
 

@@ -102,6 +102,32 @@ def conditioning_floor(name, s):
     return _FLOOR['floor'][name][s]
 
 
+# ---- aggregate guard over a fixture's checked steps (round 4): the per-step bound max(5 x TOL, 3 x floor) is loose wherever
+# 3 x floor > 5 x TOL, so a UNIFORM loss of precision in a kernel (say 10 x) would pass every single step.  The median of
+# err / max(floor, 1e-6) over all (step, output) pairs of a fixture must stay below the value frozen here: 4 x the median measured
+# in round 3 (profiles/r03_parity_ratio_table.md: 0.04 .. 0.61), at least 0.3, at most 1.0.  Frozen like the floor table: derived
+# from recorded measurements once, not retuned for a kernel.  tools/degraded_build_check.sh shows a build whose triplet kernel
+# drops 9 mantissa bits of its activations failing this guard while passing most per-step bounds.
+AGG_RATIO_EPS = 1e-6
+AGG_MEDIAN_BOUND = {
+    ('teacher_forced', 'g5_sample_head3'): 0.75, ('teacher_forced', 'g5_sample_tail4'): 0.30,
+    ('teacher_forced', 'g5_sample_full25'): 0.31, ('teacher_forced', 'g5_sample_guid3'): 0.42,
+    ('teacher_forced', 'g5_sample_head3_gamma_signed'): 1.0, ('teacher_forced', 'g5_sample_tail4_gamma_signed'): 0.64,
+    ('teacher_forced', 'g5_sample_head3_trained_like'): 1.0, ('teacher_forced', 'g5_sample_tail4_trained_like'): 1.0,
+    ('closed_loop', 'g5_sample_head3'): 0.91, ('closed_loop', 'g5_sample_head3_gamma_signed'): 0.97,
+    ('closed_loop', 'g5_sample_head3_trained_like'): 1.0,
+}
+
+
+def assert_aggregate_parity(test, name, ratios):
+    """`ratios` = err / max(floor, AGG_RATIO_EPS) of every (step, output) pair checked for fixture `name`."""
+    med = float(np.median(np.asarray(ratios, dtype=np.float64)))
+    bound = AGG_MEDIAN_BOUND[(test, name)]
+    assert med <= bound, f'{test} {name}: median(err / floor) = {med:.3f} over {len(ratios)} (step, output) pairs exceeds the frozen ' \
+                         f'{bound} -- a uniform precision regression (per-step bounds may all still hold)'
+    return med
+
+
 def record_parity_ratio(test, name, s, errs, floors, tol):
     """Evidence trail (gpurun_out/ is scratch; the table judged is copied to profiles/): one JSON line per checked step."""
     import json

@@ -468,10 +468,11 @@ def test_sampler_closed_loop_matches_reference_trajectory(name):
     carried state is re-synchronised to the reference's recorded one, so every later step is still held to the full bounds
     instead of being waved through.  (Every step of every fixture is additionally covered teacher-forced below.)"""
     import torch.nn.functional as F
-    from helpers import conditioning_floor, record_parity_ratio
+    from helpers import AGG_RATIO_EPS, assert_aggregate_parity, conditioning_floor, record_parity_ratio
     g = golden(name)
     model, oracle = _model_for(name), _oracle_for(name)
     tape = _tape(g)
+    ratios = []
     n_rec = sum(1 for k in g.files if k.endswith('_out_v'))
     st = _begin_like_fixture(model, g, 'cpu', tape[:3])          # randn [N,3], rand64 [N,12], rand64 [E,6] (Appendix B 3-4)
     w = st.eng.ws
@@ -495,6 +496,7 @@ def test_sampler_closed_loop_matches_reference_trajectory(name):
                 rel_err(w.out_bond.cpu(), g[f's{s}_out_bond']))
         record_parity_ratio('closed_loop', name, s, errs, conditioning_floor(name, s), tol)
         assert all(e <= b for e, b in zip(errs, tol)), (s, errs, tol)
+        ratios += [e / max(f, AGG_RATIO_EPS) for e, f in zip(errs, conditioning_floor(name, s))]
         tt = torch.full((len(g['n_atoms']),), step)
         log_node = po.q_v_posterior(oracle.tab_node, F.log_softmax(t(g[f's{s}_out_v']), -1), log_node, tt, bn)
         log_edge = po.q_v_posterior(oracle.tab_edge, F.log_softmax(t(g[f's{s}_out_bond']), -1), log_edge, tt, be)
@@ -508,6 +510,7 @@ def test_sampler_closed_loop_matches_reference_trajectory(name):
             st.log_edge[st.cur].copy_(log_edge)
             n_resync += 1
     assert n_resync <= 2, n_resync        # t = 999 (the ligand starts ~36 A away from the pharmacophore), +1 with `trained_like`
+    assert_aggregate_parity('closed_loop', name, ratios)
 
 
 @pytest.mark.parametrize('name', ['g5_sample_head3', 'g5_sample_tail4', 'g5_sample_full25', 'g5_sample_guid3',
@@ -518,10 +521,11 @@ def test_sampler_teacher_forced_every_step(name):
     the reference's recorded draws) and compare with the reference's next state.  Types bit-exact, positions <= 1e-4 RMSD."""
     import torch.nn.functional as F
     from phoregen_amd.data import PhoreGraph
-    from helpers import conditioning_floor, record_parity_ratio
+    from helpers import AGG_RATIO_EPS, assert_aggregate_parity, conditioning_floor, record_parity_ratio
     g = golden(name)
     model, oracle = _model_for(name), _oracle_for(name)
     tape = _tape(g)
+    ratios = []
     n_rec = sum(1 for k in g.files if k.endswith('_out_v'))
     t_total = int(g['t_total'])
     B = len(g['n_atoms'])
@@ -550,6 +554,7 @@ def test_sampler_teacher_forced_every_step(name):
         tol = _step_tolerances(name, s)
         record_parity_ratio('teacher_forced', name, s, errs, conditioning_floor(name, s), tol)
         assert all(e <= b for e, b in zip(errs, tol)), (name, s, errs, tol)
+        ratios += [e / max(f, AGG_RATIO_EPS) for e, f in zip(errs, conditioning_floor(name, s))]
         tt = torch.full((B,), step)
         log_node = po.q_v_posterior(oracle.tab_node, F.log_softmax(t(g[f's{s}_out_v']), -1), log_node, tt, bn)
         log_edge = po.q_v_posterior(oracle.tab_edge, F.log_softmax(t(g[f's{s}_out_bond']), -1), log_edge, tt, be)
@@ -572,6 +577,7 @@ def test_sampler_teacher_forced_every_step(name):
         assert rmsd <= rmsd_tol, (name, s, rmsd, rmsd_tol)
         n_checked += 1
     assert n_checked >= 3
+    assert_aggregate_parity('teacher_forced', name, ratios)      # a uniform precision regression cannot pass (tests/helpers.py)
 
 
 def test_device_rng_sampler_runs_and_is_reproducible(model):
@@ -745,6 +751,9 @@ def test_engine_variants_agree(model):
     # the coordinate-only kernels as three launches on three lanes (pg_apply_dx, pg_bond_smear, pg_lig_normals) instead of pg_layer_geom
     assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never')))
     assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never', streams=False)))
+    # the layer's node chain in front of the triplet kernel (large batches) instead of beside it: same kernels, same bits
+    assert all(torch.equal(a, b) for a, b in zip(base, run(node_first='always')))
+    assert all(torch.equal(a, b) for a, b in zip(base, run(node_first='always', layer_ahead=False)))
     layer_by_layer = run(layer_ahead=False)     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
     assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
     for grid in (0, 96, 200):                   # persistent triplet workgroups (small batches leave CUs to the side lanes):

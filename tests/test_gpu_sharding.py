@@ -47,7 +47,7 @@ def test_sharded_equals_unsharded(model, guidance):
     # 8 ranks, run one after the other on this GPU, each in batches of 2 graphs (different batch composition everywhere);
     # the guidance energies average over the logical batch (G graphs) in both runs
     parts = []
-    shards = partition_graphs(job.num_atoms, 8)
+    shards = partition_graphs(job.num_atoms, 8, job.n_phore)
     assert sorted(torch.cat(shards).tolist()) == list(range(G))
     for mine in shards:
         res = []
@@ -75,7 +75,7 @@ def test_job_driver_matches_manual_shards(model):
     seen = []
     for rank in range(4):
         pred, na = run_sampling_job(model, job, world=4, rank=rank, batch_size=4, seed=3, num_steps=3)
-        mine = partition_graphs(job.num_atoms, 4)[rank]
+        mine = partition_graphs(job.num_atoms, 4, job.n_phore)[rank]
         assert torch.equal(na, job.num_atoms[mine]) and pred[0].size(0) == int(na.sum())
         assert pred[2].size(0) == int((na * (na - 1)).sum())
         seen += mine.tolist()

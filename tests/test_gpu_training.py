@@ -358,3 +358,109 @@ def test_gradient_buckets_over_rccl_one_rank(model):
             gb.remove()
         dist.destroy_process_group()
         model.zero_grad(set_to_none=True)
+
+
+def test_forward_is_differentiable_like_the_reference(model):
+    """diffusion.py:175-246 is an ordinary differentiable nn.Module.forward (compute_loss differentiates it at :267): a caller's own
+    scalar built on PhoreDiff.forward's four outputs must reach the parameters and the perturbed inputs.  Gradients of a random
+    linear functional of (v, x0, bond, counts) against torch autograd through the oracle, same inputs."""
+    from oracle.make_inputs import synthetic_batch
+    inp = synthetic_batch(11, [7, 12, 5], [15, 24, 9], [650, 80, 930])
+    gen = torch.Generator().manual_seed(3)
+    N, E, B = inp['h_node_pert'].size(0), inp['h_edge_pert'].size(0), 3
+    R = [torch.randn(N, 12, generator=gen), torch.randn(N, 3, generator=gen), torch.randn(E, 6, generator=gen),
+         torch.randn(B, 1, generator=gen), torch.randn(B, 1, generator=gen)]
+
+    def functional(out, R):
+        v, x0, bond, (cl, cu) = out
+        return (v * R[0]).sum() + (x0 * R[1]).sum() + (bond * R[2]).sum() + (cl * R[3]).sum() + (cu * R[4]).sum()
+
+    orc = make_oracle(0)
+    probe = ['v_inference.0.weight', 'bond_inference.2.bias', 'node_embedder.weight', 'edge_embedder.weight', 'phore_embedding.weight',
+             'atom_mlp.0.weight', 'phore_encoder.hk_func.net.0.weight', 'denoiser.edge_pred_layer.net.0.weight',
+             'denoiser.base_block.0.node_layer_with_edge.hv_func.net.3.weight', 'denoiser.base_block.2.bond_layer.hk_func.net.0.weight',
+             'denoiser.base_block.3.pos_layer_with_bond.xq_func.net.0.weight', 'denoiser.base_block.5.pos_layer_with_edge.xv_func.net.3.weight',
+             'denoiser.base_block.4.lin_node.weight']
+    for k in probe:
+        orc.sd[k].requires_grad_(True)
+    pos_ref = inp['pos_pert'].clone().requires_grad_(True)
+    functional(orc.forward(**{**inp, 'pos_pert': pos_ref}), R).backward()
+
+    model.train()
+    model.zero_grad(set_to_none=True)
+    dev_inp = {k: v.to('cuda') for k, v in inp.items()}
+    pos = dev_inp['pos_pert'].clone().requires_grad_(True)
+    out = model(**{**dev_inp, 'pos_pert': pos})
+    assert all(o.requires_grad for o in (out[0], out[1], out[2], out[3][0], out[3][1]))
+    with torch.no_grad():                                  # the tape changes no value: same outputs as the launch-list path
+        fast = model(**dev_inp)
+    for a, b in zip((out[0], out[1], out[2], out[3][0], out[3][1]), (fast[0], fast[1], fast[2], fast[3][0], fast[3][1])):
+        assert a.shape == b.shape and rel_err(a.detach().cpu(), b.cpu()) <= 2e-5
+    functional(out, [r.to('cuda') for r in R]).backward()
+    params = dict(model.named_parameters())
+    errs = {k: float((params[k].grad.cpu() - orc.sd[k].grad).norm() / orc.sd[k].grad.norm().clamp(min=1e-30)) for k in probe}
+    errs['pos_pert'] = float((pos.grad.cpu() - pos_ref.grad).norm() / pos_ref.grad.norm())
+    print({k: f'{e:.1e}' for k, e in errs.items()})
+    assert max(errs.values()) <= GRAD_TOL, errs
+    # the denoiser module on its own runs the forward kernels only: under autograd it says so instead of returning constants
+    with pytest.raises(RuntimeError, match='does not record gradients'):
+        z = torch.zeros(4, 128, device='cuda')
+        model.denoiser(z, torch.zeros(4, 3, device='cuda'), None, torch.zeros(2, 0, dtype=torch.long, device='cuda'),
+                       torch.zeros(0, 128, device='cuda'), torch.ones(4, dtype=torch.bool, device='cuda'), None,
+                       torch.zeros(4, dtype=torch.long, device='cuda'))
+    model.eval()
+
+
+def test_config5_full_size_gradient_of_a_graph_inside_the_batch_equals_the_graph_alone(model):
+    """Size-independent property of the gradient path at BASELINE config 5's full size (256 ligand-pharmacophore pairs, n ~ N(25,5)):
+    graphs are independent, so the parameter gradient of a functional of ONE graph's outputs is the same whether that graph is
+    differentiated inside the 256-pair batch or alone (which is also why data-parallel training over graphs is exact).  Through
+    PhoreDiff.forward under autograd = the HIP adjoints at full size (163 k bond edges, 4 M triplets)."""
+    import torch.nn.functional as F
+    from bench import ligphore_workload
+    from phoregen_amd.plan import make_edge_data
+    B = 256
+    w = ligphore_workload(B, seed=4321)
+    g = torch.Generator().manual_seed(99)
+    na = (25 + 5 * torch.randn(B, generator=g)).round().clamp(8, 60).long()
+    nph = w['n_phore']
+    N = int(na.sum())
+    ei, be = make_edge_data(na)
+    inp = dict(h_node_pert=F.one_hot(torch.randint(0, 12, (N,), generator=g), 12).float(), pos_pert=2.0 * torch.randn(N, 3, generator=g),
+               batch_node=torch.repeat_interleave(torch.arange(B), na),
+               h_edge_pert=F.one_hot(torch.randint(0, 6, (ei.size(1),), generator=g), 6).float(), edge_index=ei, batch_edge=be,
+               time_step=torch.randint(0, 1000, (B,), generator=g), h_phore=w['h_phore'], pos_phore=w['pos_phore'],
+               phore_norm=w['phore_norm'], batch_phore=w['batch_phore'])
+    assert ei.size(1) > 150000
+    probe = ['node_embedder.weight', 'phore_embedding.weight', 'denoiser.base_block.0.bond_layer.hk_func.net.0.weight',
+             'denoiser.base_block.2.node_layer_with_edge.hv_func.net.3.weight', 'denoiser.base_block.3.lin_node.weight',
+             'denoiser.base_block.4.pos_layer_with_bond.xk_func.net.0.weight', 'denoiser.base_block.5.bond_layer.hq_func.net.3.weight',
+             'v_inference.0.weight', 'bond_inference.0.weight']
+    params = dict(model.named_parameters())
+    model.train()
+
+    def grads(batch_inp, rows_n, rows_e, R):
+        out = model(**{k: v.to('cuda') for k, v in batch_inp.items()})
+        n0, n, e0, e = rows_n[0], rows_n[1], rows_e[0], rows_e[1]
+        L = (out[0][n0:n0 + n] * R[0]).sum() + (out[1][n0:n0 + n] * R[1]).sum() + (out[2][e0:e0 + e] * R[2]).sum()
+        return [x.detach().clone() for x in torch.autograd.grad(L, [params[k] for k in probe])]
+
+    worst = 0.0
+    for gi in (0, 97, 255):
+        n0, p0 = int(na[:gi].sum()), int(nph[:gi].sum())
+        n, p = int(na[gi]), int(nph[gi])
+        e0, e = int((na[:gi] * (na[:gi] - 1)).sum()), n * (n - 1)
+        R = [torch.randn(n, 12, generator=g).cuda(), torch.randn(n, 3, generator=g).cuda(), torch.randn(e, 6, generator=g).cuda()]
+        one = dict(h_node_pert=inp['h_node_pert'][n0:n0 + n], pos_pert=inp['pos_pert'][n0:n0 + n], batch_node=torch.zeros(n, dtype=torch.long),
+                   h_edge_pert=inp['h_edge_pert'][e0:e0 + e], edge_index=inp['edge_index'][:, e0:e0 + e] - n0,
+                   batch_edge=torch.zeros(e, dtype=torch.long), time_step=inp['time_step'][gi:gi + 1],
+                   h_phore=inp['h_phore'][p0:p0 + p], pos_phore=inp['pos_phore'][p0:p0 + p], phore_norm=inp['phore_norm'][p0:p0 + p],
+                   batch_phore=torch.zeros(p, dtype=torch.long))
+        inside = grads(inp, (n0, n), (e0, e), R)
+        alone = grads(one, (0, n), (0, e), R)
+        for k, a, b in zip(probe, inside, alone):
+            err = float((a - b).norm() / b.norm().clamp(min=1e-30))
+            worst = max(worst, err)
+            assert err <= 2e-4, (gi, k, err)       # same kernels on the same rows; only the order of atomic accumulations differs
+    print('config-5 full size: worst relative gradient difference inside the batch vs alone', worst)
+    model.eval()

@@ -441,3 +441,66 @@ def test_philox_checker_reproduces_random123_known_answers():
         assert tuple(int(v) for v in pr.philox4x32([ctr], [key])[0]) == out
     u = pr.uniform24(np.array([0, 0xffffffff, 0x80000000], dtype=np.uint32))
     assert u[0] == 0.0 and u[1] < 1.0 and u[2] == 0.5
+
+
+def test_plan_matches_is_safe_for_inference_tensors_and_recycled_storage():
+    """BatchPlan.matches: its fast path (same tensor objects, unmodified) must neither crash on tensors that do not track
+    versions (created under torch.inference_mode()) nor accept a different batch of the same shapes whose tensors happen to land
+    on a freed batch's addresses."""
+    import gc
+    from phoregen_amd.plan import BatchPlan, make_edge_data
+
+    def batch(n_atoms, n_phore):
+        na = torch.tensor(n_atoms)
+        bn = torch.repeat_interleave(torch.arange(len(n_atoms)), na)
+        bp = torch.repeat_interleave(torch.arange(len(n_phore)), torch.tensor(n_phore))
+        ei, be = make_edge_data(na)
+        return bn, bp, ei, be
+    bn, bp, ei, be = batch([3, 5], [4, 4])
+    plan = BatchPlan(bn, bp, ei, be, 2, torch.device('cpu'))
+    assert plan.matches(bn, bp, ei) and plan.matches(bn, bp, ei)          # by content, then by identity
+    assert plan.matches(bn.clone(), bp.clone(), ei.clone())                # other objects, same contents
+    bn[0] = 1                                                              # written in place: the identity answer is void
+    assert not plan.matches(bn, bp, ei)
+    bn[0] = 0
+    assert plan.matches(bn, bp, ei)
+    with torch.inference_mode():                                           # no version counters there: contents decide, no crash
+        ibn, ibp, iei, _ = batch([3, 5], [4, 4])
+        assert plan.matches(ibn, ibp, iei) and plan.matches(ibn, ibp, iei)
+        obn, obp, oei, _ = batch([5, 3], [4, 4])
+        assert not plan.matches(obn, obp, oei)
+    # a freed batch's addresses re-used by a batch of the same shapes and other contents ([3,5] atoms -> [5,3])
+    for _ in range(20):
+        a = batch([3, 5], [4, 4])
+        assert plan.matches(*a[:3])
+        ptrs = [x.data_ptr() for x in a[:3]]
+        del a
+        gc.collect()
+        b = batch([5, 3], [4, 4])
+        assert not plan.matches(*b[:3]), ([x.data_ptr() for x in b[:3]], ptrs)
+        del b
+
+
+def test_partition_balances_the_fitted_step_cost():
+    """parallel.partition_graphs: longest-processing-time greedy on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p).  The
+    heaviest rank stays within one graph of the mean (the LPT bound), every graph lands on exactly one rank, and on a batch whose
+    pharmacophore sizes are skewed against the atom counts the fitted cost balances better than n^3 alone does."""
+    from phoregen_amd.parallel import COST_US, graph_cost, partition_graphs
+    g = torch.Generator().manual_seed(5)
+    for B, world in ((128, 8), (128, 3), (37, 4), (5, 8)):
+        na = (40 + 6 * torch.randn(B, generator=g)).round().clamp(20, 60).long()
+        nph = (107 + 30 * torch.randn(B, generator=g)).round().clamp(23, 203).long()
+        cost = graph_cost(na, nph)
+        parts = partition_graphs(na, world, nph)
+        assert sorted(torch.cat(parts).tolist()) == list(range(B)) and all(bool((p[1:] > p[:-1]).all()) for p in parts if p.numel() > 1)
+        loads = torch.stack([cost[p].sum() for p in parts])
+        assert float(loads.max()) <= float(cost.sum()) / world + float(cost.max()) + 1e-9
+    # the model's terms are the ones the kernels scale with: tiles of the triplet kernel, bond edges, context nodes
+    one = graph_cost(torch.tensor([40]), torch.tensor([107]))
+    assert abs(float(one) - (COST_US['tile'] * 3 * 40 * 39 + COST_US['bond'] * 40 * 39 + COST_US['node'] * 147)) < 1e-9
+    # small ligands with huge pharmacophores vs large ligands with small ones: n^3 alone piles the node work on one rank
+    na = torch.tensor([20] * 8 + [30] * 8)
+    nph = torch.tensor([203] * 8 + [23] * 8)
+    cost = graph_cost(na, nph)
+    worst = lambda parts: max(float(cost[p].sum()) for p in parts)
+    assert worst(partition_graphs(na, 4, nph)) <= worst(partition_graphs(na, 4))

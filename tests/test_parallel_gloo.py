@@ -153,6 +153,25 @@ def _bucket_worker(rank, world, port, q):
     out[2] = (local, [p.grad.numpy().copy() if p.grad is not None else None for p in params], n)
     out['launch_order'] = [b for b, _ in gb.launch_log]
     out['from_hook'] = [h for _, h in gb.launch_log]
+    # the set of parameters a bucket does not wait for is agreed on by all ranks (MAX over the ranks' used-bitmaps in finish()):
+    # the first Linear, unused on rank 1 in the step above, is still waited for there -- its gradients arriving now do not find
+    # their bucket launched (per-rank sets made that a RuntimeError on rank 1 and a hang on rank 0)
+    out['absent_after_3'] = sorted(len(a) for a in gb.absent)
+    for p in params:
+        p.grad = None
+    gb.launch_log.clear()
+    net(x).pow(2).sum().backward()
+    gb.finish()
+    out['from_hook_4'] = [h for _, h in gb.launch_log]
+    # a finish() without a backward says nothing about which parameters are used: the next step still launches from hooks
+    gb.launch_log.clear()
+    for p in params:
+        p.grad = None
+    gb.finish()
+    gb.launch_log.clear()
+    net(x).pow(2).sum().backward()
+    gb.finish()
+    out['from_hook_5'] = [h for _, h in gb.launch_log]
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -172,6 +191,9 @@ def test_bucketed_hook_allreduce_world_size_2_gloo():
     assert res[0]['launch_order'] == res[1]['launch_order'] == list(range(n_b)) and n_b >= 2
     assert all(res[0]['from_hook'])     # rank 0: every bucket from a hook (the never-used parameter is known absent after step 1)
     assert not all(res[1]['from_hook'])                                  # rank 1: the first Linear's bucket only in finish()
+    for r in (0, 1):
+        assert sum(res[r]['absent_after_3']) == 1, res[r]['absent_after_3']      # only the parameter no rank uses
+        assert all(res[r]['from_hook_4']) and all(res[r]['from_hook_5']), (res[r]['from_hook_4'], res[r]['from_hook_5'])
     for it in range(3):
         l0, r0, n0 = res[0][it]
         l1, r1, n1 = res[1][it]
