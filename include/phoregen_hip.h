@@ -205,11 +205,6 @@ typedef struct {
    * leaves some CUs to the launches that run beside the triplet kernel on other streams: 16 graphs of the headline shape 3.76 ->
    * 3.57 ms per step with 200 workgroups (the results do not depend on it: the queue hands out the same segments). */
   int tri_grid;
-  /* fused node-target modes (ABI 6): 0 = one persistent 12-wave workgroup per CU with the W2k table in LDS (large batches);
-   * 1 = 4-wave workgroups, a node per wave, W2k streamed through L2 (small batches: a launch of a few hundred nodes spreads over
-   * the whole chip); 2 = persistent 8-wave workgroups with W2k in LDS (256 registers per lane, no spills).  Same arithmetic per
-   * node, bit for bit. */
-  int small_wg;
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 

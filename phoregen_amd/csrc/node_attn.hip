@@ -51,12 +51,8 @@ __device__ __forceinline__ float ln_fold_k(f4 (&hid)[8], const float* bp, int g)
   return rs;
 }
 
-// W2K_LDS (fused form): the lane-fixed W2k table sits in LDS (64 KB: one persistent 12-wave workgroup per CU).  Without it (the
-// small-batch form: 4-wave workgroups, two per CU, one node per wave and launch) the query fold streams W2k through L2 like the
-// value unfold streams W2v: a launch of a few hundred nodes then spreads over the whole chip instead of filling 64 KB of LDS per
-// workgroup for a dozen nodes of work.
-template <bool KNN, bool POS, int MAXT, int THREADS, bool FUSED, bool W2K_LDS>
-__global__ __launch_bounds__(THREADS, FUSED ? (W2K_LDS ? 1 : 2) : 3) void node_attn_kernel(PgTopo t, PgSegAttn p) {
+template <bool KNN, bool POS, int MAXT, int THREADS, bool FUSED>
+__global__ __launch_bounds__(THREADS, FUSED ? 1 : 3) void node_attn_kernel(PgTopo t, PgSegAttn p) {
   constexpr int NSTEP = KNN ? 12 : 0;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const bpk = lds;                   // [128] b' of the key MLP
@@ -66,7 +62,7 @@ __global__ __launch_bounds__(THREADS, FUSED ? (W2K_LDS ? 1 : 2) : 3) void node_a
   float* const w2xv = wf_v + NSTEP * 512;   // POS: [32][64]
   float* const b2xv = w2xv + (POS ? 2048 : 0);
   float* const w2k = b2xv + (POS ? 16 : 0); // FUSED: lane-fixed W2k [64][64][4]
-  float* const b2v_s = w2k + (W2K_LDS ? 16384 : 0);   // FUSED node update: [128]
+  float* const b2v_s = w2k + 16384;         // FUSED node update: [128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, m = lane & 15;
   // Two target lists in one launch (fused knn form, PgSegAttn.seg_ids2): the grid is rows of 8 workgroups (one per XCD under
@@ -93,8 +89,7 @@ __global__ __launch_bounds__(THREADS, FUSED ? (W2K_LDS ? 1 : 2) : 3) void node_a
     for (int i = tid; i < 16; i += THREADS) b2xv[i] = p.b2xv[i];
   }
   if constexpr (FUSED) {
-    if constexpr (W2K_LDS)
-      for (int i = tid; i < 4096; i += THREADS) reinterpret_cast<f4*>(w2k)[i] = reinterpret_cast<const f4*>(p.W2k_l)[i];
+    for (int i = tid; i < 4096; i += THREADS) reinterpret_cast<f4*>(w2k)[i] = reinterpret_cast<const f4*>(p.W2k_l)[i];
     if constexpr (!POS) for (int i = tid; i < 128; i += THREADS) b2v_s[i] = p.b2v[i];
   }
   __syncthreads();
@@ -156,21 +151,19 @@ __global__ __launch_bounds__(THREADS, FUSED ? (W2K_LDS ? 1 : 2) : 3) void node_a
     // ======================= pass A =======================
     {
       f4 U[8];
-      if constexpr (FUSED) {          // U[c][h] = sum_d q[8h+d] W2k[8h+d][c]: the arithmetic of pg_attn_fold_query, from LDS (or L2)
+      if constexpr (FUSED) {          // U[c][h] = sum_d q[8h+d] W2k[8h+d][c]: the arithmetic of pg_attn_fold_query, from LDS
         const float* qp = p.q + (size_t)seg * 128 + 8 * m;
         const f4 qa = *reinterpret_cast<const f4*>(qp), qb = *reinterpret_cast<const f4*>(qp + 4);
-        const float* const w2k_src = W2K_LDS ? w2k : p.W2k_l;
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = tq * 4 + r;
-            const f4 wa = *reinterpret_cast<const f4*>(w2k_src + ((size_t)(2 * i) * 64 + lw) * 4);
-            const f4 wb = *reinterpret_cast<const f4*>(w2k_src + ((size_t)(2 * i + 1) * 64 + lw) * 4);
+            const f4 wa = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i) * 64 + lw) * 4);
+            const f4 wb = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i + 1) * 64 + lw) * 4);
             U[tq][r] = (qa[0] * wa[0] + qa[1] * wa[1]) + (qa[2] * wa[2] + qa[3] * wa[3]) +
                        (qb[0] * wb[0] + qb[1] * wb[1]) + (qb[2] * wb[2] + qb[3] * wb[3]);
-            // at most 8 weight reads in flight from LDS (the 12-wave form needs the registers), 16 from L2 (latency)
-            if (W2K_LDS ? r == 3 : (i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            if (r == 3) __builtin_amdgcn_sched_barrier(0);     // at most 8 weight reads in flight: the registers are needed
           }
       } else {
         const float* up = p.U + (size_t)seg * 2048 + lane;
@@ -480,46 +473,42 @@ __global__ __launch_bounds__(THREADS, FUSED ? (W2K_LDS ? 1 : 2) : 3) void node_a
   }
 }
 
-template <bool KNN, bool POS, int MAXT, int THREADS, bool FUSED, bool W2K_LDS>
+template <bool KNN, bool POS, int MAXT, int THREADS, bool FUSED>
 static int launch_na(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   constexpr int NSTEP = KNN ? 12 : 0;
-  const size_t lds = (256 + 2 * NSTEP * 512 + (POS ? 2048 + 16 : 0) + (FUSED ? (W2K_LDS ? 16384 : 0) + 128 : 0)) * sizeof(float);
-  if (int rc = reserve_lds(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED, W2K_LDS>), lds, "node_attn")) return rc;
+  const size_t lds = (256 + 2 * NSTEP * 512 + (POS ? 2048 + 16 : 0) + (FUSED ? 16384 + 128 : 0)) * sizeof(float);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED>), lds, "node_attn")) return rc;
   const int per = THREADS / 64;
   int blocks = (p->n_seg + per - 1) / per;
   if (FUSED && KNN && p->n_seg2 > 0) {
     blocks += (p->n_seg2 + per - 1) / per;
     if (blocks < 16) blocks = 16;                            // (two lists: at least one row of 8 workgroups each)
   }
-  if (FUSED && W2K_LDS) { if (blocks > kNumCU) blocks = kNumCU; }      // one persistent workgroup per CU (64 KB of W2k each)
-  else if (FUSED) { if (blocks > 4 * kNumCU) blocks = 4 * kNumCU; }    // small form: a node per wave; beyond 4 096 nodes the workgroups loop
+  if (FUSED) { if (blocks > kNumCU) blocks = kNumCU; }      // one persistent workgroup per CU (64 KB of W2k each)
   else if (KNN && blocks > 3 * kNumCU) blocks = 3 * kNumCU; // LDS-heavy: persistent-ish, the weights are loaded per block
-  hipLaunchKernelGGL((node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED, W2K_LDS>), dim3(blocks), dim3(THREADS), lds, st, *t, *p);
+  hipLaunchKernelGGL((node_attn_kernel<KNN, POS, MAXT, THREADS, FUSED>), dim3(blocks), dim3(THREADS), lds, st, *t, *p);
   return check_launch("pg_seg_attn(node)");
 }
 
-// FORM (fused): 0 = 12-wave persistent workgroups, W2k in LDS; 1 = 4-wave workgroups, W2k through L2 (small batches);
-// 2 = 8-wave persistent workgroups, W2k in LDS (256 registers per lane: no spills, two waves per SIMD)
-template <bool FUSED, int FORM>
+template <bool FUSED>
 static int launch_node_attn_t(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
-  constexpr int TH = !FUSED ? 256 : (FORM == 0 ? 768 : (FORM == 1 ? 256 : 512));
-  constexpr bool WL = FUSED && FORM != 1;
+  constexpr int TH = FUSED ? 768 : 256;
   const bool knn = p->mode == PG_SEG_KNN_NODE || p->mode == PG_SEG_KNN_POS;
   const bool pos = p->mode == PG_SEG_KNN_POS || p->mode == PG_SEG_BOND_POS;
   if (knn) {
     if (p->knn_k > 32) return -1;
-    return pos ? launch_na<true, true, 2, TH, FUSED, WL>(t, p, st) : launch_na<true, false, 2, TH, FUSED, WL>(t, p, st);
+    return pos ? launch_na<true, true, 2, TH, FUSED>(t, p, st) : launch_na<true, false, 2, TH, FUSED>(t, p, st);
   }
   const int tiles = (t->max_nlig + 15) / 16;
   if (tiles > 5) return -1;
   if (pos) {
-    if (tiles <= 3) return launch_na<false, true, 3, TH, FUSED, WL>(t, p, st);
-    if (tiles == 4) return launch_na<false, true, 4, TH, FUSED, WL>(t, p, st);
-    return launch_na<false, true, 5, TH, FUSED, WL>(t, p, st);
+    if (tiles <= 3) return launch_na<false, true, 3, TH, FUSED>(t, p, st);
+    if (tiles == 4) return launch_na<false, true, 4, TH, FUSED>(t, p, st);
+    return launch_na<false, true, 5, TH, FUSED>(t, p, st);
   }
-  if (tiles <= 3) return launch_na<false, false, 3, TH, FUSED, WL>(t, p, st);
-  if (tiles == 4) return launch_na<false, false, 4, TH, FUSED, WL>(t, p, st);
-  return launch_na<false, false, 5, TH, FUSED, WL>(t, p, st);
+  if (tiles <= 3) return launch_na<false, false, 3, TH, FUSED>(t, p, st);
+  if (tiles == 4) return launch_na<false, false, 4, TH, FUSED>(t, p, st);
+  return launch_na<false, false, 5, TH, FUSED>(t, p, st);
 }
 
 // returns -1 when the shape is outside what the two-pass kernels hold in registers (caller falls back to seg_attn.hip).
@@ -535,10 +524,7 @@ int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
     set_error("pg_seg_attn: Wf_k / Wf_v / W2xv_l must be 16-byte aligned");
     return PG_ERR_ARG;
   }
-  if (!node_attn_fused_request(p)) return launch_node_attn_t<false, 0>(t, p, st);
-  if (p->small_wg == 1) return launch_node_attn_t<true, 1>(t, p, st);
-  if (p->small_wg == 2) return launch_node_attn_t<true, 2>(t, p, st);
-  return launch_node_attn_t<true, 0>(t, p, st);
+  return node_attn_fused_request(p) ? launch_node_attn_t<true>(t, p, st) : launch_node_attn_t<false>(t, p, st);
 }
 
 }  // namespace pg

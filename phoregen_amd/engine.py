@@ -64,14 +64,10 @@ class Engine:
         # not depend on the new coordinates) run on lane 2 during this layer's position updates
         self.layer_ahead = o['layer_ahead']
         self.small_below = o['small_below']
-        self.node_first, self.node_first_from = o['node_first'], o['node_first_from']
         self.tri_grid = o['tri_grid']                  # persistent triplet workgroups (-1: by batch size)
         # apply_dx + bond smearing + direction vectors as one launch on lane 0: small batches (measured, same box: 16 graphs 3.52 -> 3.40 ms
         # per step, 32 graphs 5.69 -> 5.43; 128 graphs 20.20 -> 20.28: there the three launches hide beside the first-layer GEMM)
         self.fused_geom = o['fused_geom'] == 'always' or (o['fused_geom'] == 'auto' and self.plan.n_bond < o['small_below'])
-        self.small_node = o['small_node']
-        self.node_waves = o['node_waves']
-        self.small_node_below = o['small_node_below']
         # hipGraph replay of the forward launch list.  Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -283,10 +279,6 @@ class Engine:
                                                                                    #  grid below: 16 graphs = 1 920 nodes slower
                                                                                    #  merged, 24 / 32 graphs 3 % faster, 48+ equal)
         lists = [h_dst_lists[0]] if merged else h_dst_lists
-        # small batches: 4-wave workgroups, a node per wave, no 64 KB W2k table per workgroup (PgSegAttn.small_wg).  Below ~3 000
-        # target nodes the 12-wave persistent form does not fill one round of the chip
-        n_targets = sum(n for _, n, _ in h_dst_lists)
-        small = fused and (self.small_node == 'always' or (self.small_node == 'auto' and n_targets < self.small_node_below))
         for seg_ids, n_seg, is_lig in lists:
             if not fused:
                 self._call(prog, self.lib.pg_attn_fold_query, wq.data_ptr(), 128, a.W2k_l.data_ptr(), n_seg,
@@ -307,7 +299,7 @@ class Engine:
             else:
                 kw.update(S=wS, swn=wsw)
             if fused:      # (U / S / swn stay attached as scratch for the one-pass fallback inside pg_seg_attn)
-                kw.update(q=wq, W2k_l=a.W2k_l, small_wg=1 if small else (2 if self.node_waves == 8 else 0))
+                kw.update(q=wq, W2k_l=a.W2k_l)
                 if not pos:
                     assert out.stride(0) == 128
                     kw.update(W2v_l=a.W2v_l, b2v=a.b2v, out=out)
@@ -405,14 +397,11 @@ class Engine:
         # 3.93 -> 3.83 ms, 32 graphs 5.94 -> 5.67, 64 graphs 10.55 -> 10.36, 128 graphs 20.12 -> 20.17 (the triplet kernel then
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
         ahead = self.layer_ahead and self.multi_stream and E < self.small_below
-        node_first = self.multi_stream and (self.node_first == 'always' or (self.node_first == 'auto' and E >= self.node_first_from))
         chain_q = self.multi_stream and E < self.small_below         # small batches: the Q rows on the bond chain's own lane
         # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
         # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 192 workgroups, 24 / 32 graphs 4.9 -> 4.7 / 5.87 -> 5.61 with
         # 224 and the merged knn launch; 48 graphs equal either way, from 64 graphs up the full grid is fastest)
         tri_grid = self.tri_grid if self.tri_grid >= 0 else ((192 if E < 30000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
-        if node_first and self.tri_grid < 0:
-            tri_grid = 0                           # (alone on the chip)
 
         def first_layer_gemm(L, h_in):
             # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
@@ -501,13 +490,7 @@ class Engine:
                     self._fork(prog, (3,))
                     self._lane = 3
                     heads[0](hbn)
-            # Large batches (`node_first`): the persistent triplet kernel owns every CU while it runs, so whatever is launched beside
-            # it is starved and finishes AFTER it, on the critical path (128 graphs: ~500 us of node chain per layer behind a 2 040 us
-            # triplet kernel).  There the whole node chain of the layer -- knn attention, lin_node, Y2, knn position update -- goes
-            # first (beside the P / Q products) and the triplet kernel is launched when it is done; small batches keep the two
-            # chains side by side (the triplet grid leaves them CUs).
-            if not node_first:
-                launch_triplet()
+            launch_triplet()
             # ---- node update over bond edges (:284)                                   [lane 2]
             # (the sub-layer reads no coordinates: from layer 1 on a small batch has launched it during the previous layer's position
             #  updates, see below)
@@ -540,12 +523,7 @@ class Engine:
                 self._gemm(prog, hn, 128, L.W_node2[512:], w.Y2[:, 512:], p.n_lig, 768, bias=L.b_node2[512:], rows=p.lig2ctx)
             else:
                 self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
-            if node_first:
-                self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._sync(prog, 0, (1,))                  # lane 0 continues after the triplet kernel AND Y2 (which implies lane 2)
-            if node_first:
-                launch_triplet()
-                self._lane = 0
             # the bond position update's query MLP runs beside its edge product / the knn position update, not in front of the
             # attention on lane 0: lane 3 is free after the triplet queries (last layer: lane 2, in front of the node head --
             # forked from lane 0, which has just seen h' and Y2: a lane-2-waits-lane-1 edge after lane 1 waited on lane 2 crashes
@@ -575,9 +553,8 @@ class Engine:
                 bond_node_rows(Ln, hbn)
                 self._node_attention(prog, hip.SEG_BOND_NODE, Ln.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=2)
                 bn_done = self._record(prog, 3)
-            if not node_first:
-                self._lane = 1
-                self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
+            self._lane = 1
+            self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
             self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
             self._wait(prog, 0, q_done)

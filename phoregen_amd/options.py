@@ -17,15 +17,10 @@ DEFAULTS = dict(
     knn_merge='auto',     # ligand + pharmacophore targets of a knn sub-layer in one launch: 'auto' by batch size, 'never', 'always'
     layer_ahead=True,     # small batches: the next layer's x-independent products inside this layer's position phase
     small_below=10**9,    # ... 'small' = fewer bond edges than this (round 4: the schedule pays at every size, 128 graphs 20.10 -> 19.81 ms)
-    node_first='auto',    # the layer's node chain in front of the triplet kernel instead of beside it: 'auto' = large batches, 'never', 'always'
-    node_first_from=10**9,  # ... 'auto': from this many bond edges up
     tri_grid=-1,          # persistent workgroups of the staged triplet kernel (-1: by batch size)
     graph=False,          # hipGraph replay of the forward launch list
     fused_geom='auto',    # coordinate update + bond smearing + direction vectors as one launch on the bond chain's lane (pg_layer_geom):
                           # 'auto' = small batches (below ~100 graphs of the headline shape), 'never', 'always'
-    small_node='never',   # node attention in 4-wave workgroups: 'auto' by batch size, 'never', 'always'
-    node_waves=12,        # waves per persistent workgroup of the fused node attention: 12 (168 registers per lane) or 8 (256, no spills)
-    small_node_below=3072,  # ... 'auto': launches with fewer target nodes than this
     dgrad_mm=True,        # training: input gradients through the library GEMM
     rows_sum=True,        # training: pg_bond_rows_sum instead of atomic index_add_
     tri_onepass=True,     # training: one-pass triplet / node adjoints fed by the forward's softmax weights
@@ -38,8 +33,8 @@ _flag = lambda v: v != '0'
 _ENV = {
     'PG_STREAMS': ('streams', _flag), 'PG_ROW_SUBSETS': ('row_subsets', _flag), 'PG_TRI_STAGED': ('tri_staged', _flag),
     'PG_NODE_FUSED': ('node_fused', _flag), 'PG_KNN_GROUP': ('knn_group', _flag), 'PG_KNN_MERGE': ('knn_merge', _tri),
-    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_TRI_GRID': ('tri_grid', int), 'PG_NODE_FIRST': ('node_first', _tri), 'PG_NODE_FIRST_FROM': ('node_first_from', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag),
-    'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_SMALL_NODE': ('small_node', _tri), 'PG_SMALL_NODE_BELOW': ('small_node_below', int), 'PG_NODE_WAVES': ('node_waves', int), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
+    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_TRI_GRID': ('tri_grid', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag),
+    'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
     'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int),
 }
 _overrides = {}

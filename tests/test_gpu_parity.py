@@ -751,9 +751,6 @@ def test_engine_variants_agree(model):
     # the coordinate-only kernels as three launches on three lanes (pg_apply_dx, pg_bond_smear, pg_lig_normals) instead of pg_layer_geom
     assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never')))
     assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never', streams=False)))
-    # the layer's node chain in front of the triplet kernel (large batches) instead of beside it: same kernels, same bits
-    assert all(torch.equal(a, b) for a, b in zip(base, run(node_first='always')))
-    assert all(torch.equal(a, b) for a, b in zip(base, run(node_first='always', layer_ahead=False)))
     layer_by_layer = run(layer_ahead=False)     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
     assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
     for grid in (0, 96, 200):                   # persistent triplet workgroups (small batches leave CUs to the side lanes):
@@ -762,11 +759,6 @@ def test_engine_variants_agree(model):
     one_launch = run(knn_merge='always')           # ... or as one launch with the workgroups split between the lists (the default only
     assert all(torch.equal(a, b) for a, b in zip(base, two_launches))     # from ~60 graphs up): same bits per node either way
     assert all(torch.equal(a, b) for a, b in zip(base, one_launch))
-    # node attention in 4-wave workgroups with W2k streamed through L2 (small batches) or in persistent 12-wave workgroups with W2k
-    # in LDS (large ones): the same arithmetic per node
-    for kw in (dict(small_node='always'), dict(small_node='never'), dict(small_node='always', knn_merge='always'),
-               dict(small_node='never', knn_merge='never')):
-        assert all(torch.equal(a, b) for a, b in zip(base, run(**kw))), kw
     old_dbg = hip.lib().pg_debug_force_generic_seg(1)  # the one-pass fallback takes a two-list call list after list
     try:
         generic_two_lists = run(knn_merge='always')
