@@ -348,7 +348,10 @@ def main():
         i = W
         for r in range(R):
             barrier()
-            if time_triplet:
+            # HIP events around the triplet / knn-node launches (on their lanes) during the LAST timed block only: 24 event records
+            # per step cost a small batch ~2 % (16 graphs: 3.36 vs 3.30 ms per step), so with R = 3 the median block -- the
+            # headline -- is one without them, and the instrumented block stays listed in `repeats_ms_per_step`
+            if time_triplet and r == R - 1:
                 st.eng.timers = {}
             t0 = time.perf_counter()
             for _ in range(K):
@@ -356,7 +359,7 @@ def main():
                 i += 1
             barrier()
             times.append(max_over_ranks(time.perf_counter() - t0))
-            if time_triplet:
+            if time_triplet and r == R - 1:
                 tri += st.eng.kernel_ms('triplet')
                 knn += st.eng.kernel_ms('knn_node')
                 st.eng.timers = None
@@ -423,6 +426,7 @@ def main():
                          'bound': 'mfma', 'achieved': exec_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': (exec_tf / peak_tf) if exec_tf else None, 'traffic': traffic, 'traffic_source': traffic_src,
                          'avg_launch_ms': tri_avg_ms, 'launches_timed': len(tri_ms),
+                         'timed_in': f'block {R} of {R} of the timed region (every launch of its {K} steps; HIP events on the launch stream)',
                          'flops_per_launch': counts['flops_triplet_executed'],
                          'note': 'achieved = fp32 FLOPs the kernel EXECUTES per launch (112 MFMA 16x16x4 per 16-row tile + query fold / '
                                  'value unfold, padding rows included; Q arrives as a GEMM row) / mean launch duration (HIP events on the launch stream). '
@@ -433,7 +437,7 @@ def main():
                          'share_of_step': (6 * tri_avg_ms) / (dt / K * 1e3) if tri_ms else None},
             # the kernel furthest below its roofline (round-2 review): the knn-node attention sub-layer, both launches of a layer
             'roofline_knn_node': (lambda ms, mf: {
-                'kernel': 'knn-node attention (pg_seg_attn PG_SEG_KNN_NODE fused form, node_attn_kernel<true,false,2,768,true,true>), '
+                'kernel': 'knn-node attention (pg_seg_attn PG_SEG_KNN_NODE fused form, node_attn_kernel<true,false,2,768,true>), '
                           + ('ONE launch per layer serving the ligand and the pharmacophore target lists' if run.knn_launches == 1 else
                              '2 launches per layer: ligand targets, pharmacophore targets') + ', rank 0',
                 'bound': 'mfma', 'peak': peak_tf, 'unit': 'TFLOP/s', 'avg_sublayer_ms': ms, 'sublayers_timed': len(run.knn_ms),

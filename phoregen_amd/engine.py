@@ -27,10 +27,23 @@ def side_streams(device_index, stream_set=0):
     """The three side lanes of a device, shared by every Engine of the process: the runtime maps HIP streams onto a handful of
     hardware queues (4 by default), and streams that share a queue serialise -- an Engine that created its own streams made the
     lanes of every later Engine slower (measured: a second model's 16-graph step 3.4 -> 5.4 ms)."""
-    key = (device_index, stream_set)
+    prio = options.get('side_priority')          # (experiment: lanes 2 / 3 -- the work launched one layer ahead -- at another priority)
+    key = (device_index, stream_set, prio)
     if key not in _SIDE_STREAMS:
         with torch.cuda.device(device_index):
-            _SIDE_STREAMS[key] = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+            if prio == 0:
+                _SIDE_STREAMS[key] = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+            else:
+                import ctypes as _C
+                rt = _C.CDLL('libamdhip64.so')
+                out = []
+                for pr in (0, prio, prio):
+                    h = _C.c_void_p()
+                    rc = rt.hipStreamCreateWithPriority(_C.byref(h), 1, pr)        # 1 = hipStreamNonBlocking
+                    if rc != 0:
+                        raise RuntimeError(f'hipStreamCreateWithPriority({pr}) failed: {rc}')
+                    out.append(torch.cuda.ExternalStream(h.value, device=device_index))
+                _SIDE_STREAMS[key] = out
     return _SIDE_STREAMS[key]
 
 
@@ -473,24 +486,22 @@ class Engine:
             if not pre:
                 self._lane = 3                                                          # triplet queries
                 triplet_queries(L, hbc)
-            def launch_triplet():
-                self._lane = 0
-                if not pre:                            # (pre: lane 3 carries the bond-node attention, which lin_node waits for)
-                    self._join(prog, (3,))
-                a = L.TB
-                self._event(prog, 'triplet', True)
-                self.tri_calls.append(len(prog))
-                self._seg(prog, hip.SEG_TRIPLET, E, p.tri_order, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
-                          ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
-                          W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks,
-                          **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter, tri_grid=tri_grid,
-                                  Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
-                self._event(prog, 'triplet', False)
-                if last:                               # lane 3 (the triplet queries) has been joined: the bond head takes it
-                    self._fork(prog, (3,))
-                    self._lane = 3
-                    heads[0](hbn)
-            launch_triplet()
+            self._lane = 0
+            if not pre:                            # (pre: lane 3 carries the bond-node attention, which lin_node waits for)
+                self._join(prog, (3,))
+            a = L.TB
+            self._event(prog, 'triplet', True)
+            self.tri_calls.append(len(prog))
+            self._seg(prog, hip.SEG_TRIPLET, E, p.tri_order, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
+                      ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
+                      W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks,
+                      **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter, tri_grid=tri_grid,
+                              Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
+            self._event(prog, 'triplet', False)
+            if last:                               # lane 3 (the triplet queries) has been joined: the bond head takes it
+                self._fork(prog, (3,))
+                self._lane = 3
+                heads[0](hbn)
             # ---- node update over bond edges (:284)                                   [lane 2]
             # (the sub-layer reads no coordinates: from layer 1 on a small batch has launched it during the previous layer's position
             #  updates, see below)
