@@ -422,9 +422,18 @@ class SegCoreFn(torch.autograd.Function):
                 g.S, g.swn = S_.data_ptr(), sw_.data_ptr()
                 keep += [S_, sw_]
         s = SegCoreFn._struct(cfg, t)
+        if bwd_timers is not None:       # measurement (tools/bench_train.py): HIP events around the adjoint launch, on its stream
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         hip.check(lib.pg_seg_attn_bwd(cfg['topo'], C.byref(s), C.byref(g), _st()), 'pg_seg_attn_bwd')
+        if bwd_timers is not None:
+            ev[1].record()
+            bwd_timers.setdefault(cfg['mode'], []).append(ev)
         # first-layer blocks: the k|v target halves live in Ydst[:, 0:256], the source halves in Ysrc[:, 0:256]
         return (None, gYdst, gYsrc, gU, gx, gnrm, gew, gWf_k, gWf_v, gbk, gbv, gW2, gb2)
+
+
+bwd_timers = None       # dict mode -> [(start, end) events] when a benchmark wants the adjoint launches timed
 
 
 def seg_core(cfg, Ydst, Ysrc, U, x, nrm=None, ew=None, Wf_k=None, Wf_v=None, bk=None, bv=None, W2xv_l=None, b2xv=None):

@@ -719,6 +719,58 @@ def test_knn_group_by_kind_is_a_stable_partition(model):
         assert torch.equal(nbr1[node, d:], nbr0[node, d:]) and torch.equal(ew1[node, d:], ew0[node, d:])
 
 
+def test_layer_geom_equals_the_three_launches_it_replaces():
+    """pg_layer_geom (coordinate update + bond smearing + direction vectors as ONE launch) against pg_apply_dx -> pg_bond_smear +
+    pg_lig_normals, bit for bit, on ragged graphs: 1- and 2-atom ligands (no bonds / fewer than 3 neighbours), a 96-atom ligand,
+    tile-boundary sizes, few and many graphs (1 and 8 parts per graph); the no-update (layer 0) and update-only (last layer) forms;
+    and against plain tensor arithmetic for the meaning (uni_denoiser.py:295-296,128,137; common.py:300-314)."""
+    from phoregen_amd import hip
+    from phoregen_amd.plan import BatchPlan, make_edge_data
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(21)
+    offs = torch.tensor([0., 1., 1.25, 1.5, 1.75, 2., 2.25, 2.5, 2.75, 3., 3.5, 4., 4.5, 5., 5.5, 6., 7., 8., 9., 10.])
+    for na, nph in ((torch.tensor([5, 1, 2, 96, 17, 33]), torch.tensor([7, 3, 40, 11, 1, 64])),
+                    (torch.randint(2, 50, (300,), generator=g), torch.randint(1, 90, (300,), generator=g))):
+        ei, be = make_edge_data(na)
+        B = na.numel()
+        plan = BatchPlan(torch.repeat_interleave(torch.arange(B), na), torch.repeat_interleave(torch.arange(B), nph), ei, be, B, DEV)
+        n, E = plan.n_ctx, plan.n_bond
+        x = (3.0 * torch.randn(n, 3, generator=g)).to(DEV)
+        dx1, dx2 = (0.1 * torch.randn(n, 3, generator=g)).to(DEV), (0.1 * torch.randn(n, 3, generator=g)).to(DEV)
+        pn = torch.randn(plan.n_phore, 3, generator=g).to(DEV)
+        pn_ctx = torch.zeros(n, 3, device=DEV).index_copy_(0, plan.phore2ctx_long, pn)
+        s = hip.stream_ptr()
+        # the three launches
+        x_ref, nrm_ref, G_ref = torch.empty(n, 3, device=DEV), torch.full((n, 3), 7.0, device=DEV), torch.full((E, 20), 7.0, device=DEV)
+        hip.check(lib.pg_apply_dx(plan.topo_ref, x.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), x_ref.data_ptr(), s))
+        hip.check(lib.pg_bond_smear(plan.topo_ref, x_ref.data_ptr(), G_ref.data_ptr(), s))
+        hip.check(lib.pg_lig_normals(plan.topo_ref, x_ref.data_ptr(), pn.data_ptr(), plan.phore2ctx.data_ptr(), nrm_ref.data_ptr(), s))
+        # one launch
+        x_new, nrm, G = torch.empty(n, 3, device=DEV), torch.full((n, 3), -7.0, device=DEV), torch.full((E, 20), -7.0, device=DEV)
+        hip.check(lib.pg_layer_geom(plan.topo_ref, x.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), pn_ctx.data_ptr(), x_new.data_ptr(),
+                                    nrm.data_ptr(), G.data_ptr(), s))
+        torch.cuda.synchronize()
+        assert torch.equal(x_new, x_ref) and torch.equal(G, G_ref) and torch.equal(nrm, nrm_ref)
+        # layer 0: no update, products from x itself; last layer: the update alone (G / nrm untouched)
+        G0, nrm0 = torch.empty(E, 20, device=DEV), torch.empty(n, 3, device=DEV)
+        hip.check(lib.pg_layer_geom(plan.topo_ref, x_ref.data_ptr(), None, None, pn_ctx.data_ptr(), None, nrm0.data_ptr(), G0.data_ptr(), s))
+        x_only = torch.empty(n, 3, device=DEV)
+        hip.check(lib.pg_layer_geom(plan.topo_ref, x.data_ptr(), dx1.data_ptr(), dx2.data_ptr(), None, x_only.data_ptr(), None, None, s))
+        torch.cuda.synchronize()
+        assert torch.equal(G0, G_ref) and torch.equal(nrm0, nrm_ref) and torch.equal(x_only, x_ref)
+        # meaning: x' = x + (dx1 + dx2) on ligand rows only; G = exp(-(|x'_dst - x'_src| - offset)^2 / 2) per bond row
+        is_lig = plan.ctx_is_lig.bool()
+        assert torch.equal(x_new[~is_lig], x[~is_lig])
+        assert torch.allclose(x_new[is_lig], (x + dx1 + dx2)[is_lig], rtol=0, atol=1e-6)
+        if E:
+            d = (x_new[plan.bond_dst.long()] - x_new[plan.bond_src.long()]).norm(dim=-1)
+            assert torch.allclose(G, torch.exp(-0.5 * (d[:, None] - offs.to(DEV)[None, :]) ** 2), rtol=1e-5, atol=1e-6)
+        assert torch.equal(nrm[plan.phore2ctx_long], pn)
+    # contract: dx1 / dx2 / x_new come together
+    assert lib.pg_layer_geom(plan.topo_ref, x.data_ptr(), dx1.data_ptr(), None, pn_ctx.data_ptr(), x_new.data_ptr(), nrm.data_ptr(),
+                             G.data_ptr(), s) != 0
+
+
 def test_engine_variants_agree(model):
     """The measurement switches of the engine must not change results beyond fp32 summation order: one stream vs four lanes
     (bit-identical: same kernels, same order per kernel), node attention with separate fold / unfold launches, the gather triplet

@@ -79,6 +79,32 @@ def main(argv=None):
         info = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    # roofline of the dominant kernel of the step, the triplet adjoint (pg_seg_attn_bwd PG_SEG_TRIPLET, 6 launches per step): HIP
+    # events around its launches during two more steps; executed FLOPs = its MFMA count per launch from the committed PMC pass
+    # (profiles/train_adjoint_mfma.json: SQ_INSTS_MFMA x 2 048, every MFMA of the kernel is a 16x16x4) scaled by the triplet rows
+    from phoregen_amd import training as _tr
+    _tr.bwd_timers = {}
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    tri_ms = [e0.elapsed_time(e1) for e0, e1 in _tr.bwd_timers.get(4, [])]
+    knn_ms = [e0.elapsed_time(e1) for e0, e1 in _tr.bwd_timers.get(0, [])]
+    _tr.bwd_timers = None
+    roof = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'train_adjoint_mfma.json')))
+        e3_now = int((na * (na - 1) * ((na + 15) // 16 * 16)).sum())      # rows the adjoint walks: n (n-1) segments x 16-row tiles of n rows
+        mfma = rec['mfma_per_launch'] * e3_now / rec['padded_rows']
+        avg = sum(tri_ms) / max(len(tri_ms), 1)
+        roof = {'kernel': 'triplet adjoint (pg_seg_attn_bwd PG_SEG_TRIPLET, ' + rec['kernel'] + '), 6 launches per step', 'bound': 'mfma',
+                'achieved': mfma * 2048 / (avg * 1e-3) / 1e12, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': mfma * 2048 / (avg * 1e-3) / 1e12 / 157.3,
+                'avg_launch_ms': avg, 'launches_timed': len(tri_ms), 'flops_per_launch': mfma * 2048, 'traffic': rec.get('hbm_bytes_per_launch'),
+                'share_of_step': 6 * avg / ms, 'knn_node_adjoint_avg_launch_ms': sum(knn_ms) / max(len(knn_ms), 1),
+                'source': {k: rec.get(k) for k in ('commit', 'method', 'workload')},
+                'note': 'achieved = fp32 FLOPs the kernel EXECUTES (16x16x4 MFMAs counted by SQ_INSTS_MFMA in a PMC pass of this benchmark, '
+                        'padding rows included) / mean launch duration (HIP events on the launch stream)'}
+    except Exception as ex:
+        roof = {'error': f'no PMC record of the adjoint ({ex})'}
     if a.buckets and world == 1:      # the same step again with the bucketed all-reduce path on a 1-rank RCCL group
         ms_plain = ms
         torch.cuda.set_device(local)
@@ -108,7 +134,7 @@ def main(argv=None):
                                                       'graphs': a.graphs, 'n_lig': int(na.sum()), 'e_bond': e_bond, 'e3': e3},
                       **({'ms_without_buckets': ms_plain, 'buckets': len(buckets.buckets), 'buckets_launched_from_hooks': hooked,
                           'note': 'value = with GradientBuckets on a 1-rank nccl group'} if ms_plain is not None else {}),
-                      'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30, 'last_loss': info['loss']}))
+                      'roofline': roof, 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30, 'last_loss': info['loss']}))
 
 
 if __name__ == '__main__':
