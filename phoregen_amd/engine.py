@@ -26,24 +26,14 @@ _SIDE_STREAMS = {}
 def side_streams(device_index, stream_set=0):
     """The three side lanes of a device, shared by every Engine of the process: the runtime maps HIP streams onto a handful of
     hardware queues (4 by default), and streams that share a queue serialise -- an Engine that created its own streams made the
-    lanes of every later Engine slower (measured: a second model's 16-graph step 3.4 -> 5.4 ms)."""
-    prio = options.get('side_priority')          # (experiment: lanes 2 / 3 -- the work launched one layer ahead -- at another priority)
-    key = (device_index, stream_set, prio)
+    lanes of every later Engine slower (measured: a second model's 16-graph step 3.4 -> 5.4 ms).  tools/micro/hw_queues.py
+    (profiles/r04_micro_hw_queues.txt): exactly four streams of a process run side by side (the null stream + three); a fifth
+    shares a queue and waits for its partner unless GPU_MAX_HW_QUEUES is raised BEFORE the runtime starts.  Four lanes = lane 0
+    (the caller's stream) + these three is therefore the most this design can use without asking the host program for more."""
+    key = (device_index, stream_set)
     if key not in _SIDE_STREAMS:
         with torch.cuda.device(device_index):
-            if prio == 0:
-                _SIDE_STREAMS[key] = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
-            else:
-                import ctypes as _C
-                rt = _C.CDLL('libamdhip64.so')
-                out = []
-                for pr in (0, prio, prio):
-                    h = _C.c_void_p()
-                    rc = rt.hipStreamCreateWithPriority(_C.byref(h), 1, pr)        # 1 = hipStreamNonBlocking
-                    if rc != 0:
-                        raise RuntimeError(f'hipStreamCreateWithPriority({pr}) failed: {rc}')
-                    out.append(torch.cuda.ExternalStream(h.value, device=device_index))
-                _SIDE_STREAMS[key] = out
+            _SIDE_STREAMS[key] = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
     return _SIDE_STREAMS[key]
 
 
