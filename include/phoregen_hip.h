@@ -205,6 +205,11 @@ typedef struct {
    * leaves some CUs to the launches that run beside the triplet kernel on other streams: 16 graphs of the headline shape 3.76 ->
    * 3.57 ms per step with 200 workgroups (the results do not depend on it: the queue hands out the same segments). */
   int tri_grid;
+  /* Fused position modes (KNN_POS, BOND_POS), optional: 1 = the row tiles of a node over several waves of a workgroup (a small
+   * batch's launch of a few hundred nodes is bound by the dependent chain inside the one wave that owns a node); the sequential
+   * chains are run in the one-wave kernel's order, so the result is bit-identical.  Ignored for shapes it does not hold (ligands
+   * above 64 atoms, k > 32, training outputs): those take the one-wave kernel. */
+  int pos_tiled;
 } PgSegAttn;
 int pg_seg_attn(const PgTopo* t, const PgSegAttn* p, void* stream);
 

@@ -511,6 +511,313 @@ static int launch_node_attn_t(const PgTopo* t, const PgSegAttn* p, hipStream_t s
   return launch_na<false, false, 5, TH, FUSED>(t, p, st);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Position-update modes of a SMALL batch: the row tiles of a node over T waves.
+// A launch of a few hundred target nodes is bound by the dependent chain inside the one wave that owns a node (fold -> T row tiles,
+// each two MLP paths -> softmax -> weighted sum); neither more CUs nor fewer waves per CU change that (tools/experiments).  Here wave
+// (slot, tile) of a persistent 12-wave workgroup computes ONE 16-row tile of node `slot` (the query fold redundantly per wave), the
+// tiles' per-head maxima and then their softmax numerators e[row,h] and products w[row,h] = e * gate * v meet in LDS, and one wave
+// per node runs the two short sequential chains (l += e ; a = fma(w, x_dst - x_src, a)) over them in the order of the one-wave
+// kernel: the result is that kernel's, bit for bit.  T = 2 (knn, k <= 32) / 3 / 4 (ligands up to 48 / 64 atoms).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool KNN, int T>
+__global__ __launch_bounds__(768, 1) void node_attn_pos_tiled_kernel(PgTopo t, PgSegAttn p) {
+  constexpr int NSTEP = KNN ? 12 : 0, THREADS = 768, NPW = 12 / T;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const bpk = lds;
+  float* const bpv = lds + 128;
+  float* const wf_k = lds + 256;            // [NSTEP][8][64]
+  float* const wf_v = wf_k + NSTEP * 512;
+  float* const w2xv = wf_v + NSTEP * 512;   // [32][64]
+  float* const b2xv = w2xv + 2048;
+  float* const w2k = b2xv + 16;             // lane-fixed W2k [64][64][4]
+  float* const xmax = w2k + 16384;          // [12 waves][64]      lane-local maxima of a wave's tile
+  float* const xew = xmax + 12 * 64;        // [12 waves][64][8]   e[4] | w[4] of a wave's tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = wave / T, tile0 = wave - slot * T;
+  for (int i = tid; i < 128; i += THREADS) { bpk[i] = p.ln_bk[i]; bpv[i] = p.ln_bv[i]; }
+  for (int i = tid; i < NSTEP * 128; i += THREADS) {
+    reinterpret_cast<f4*>(wf_k)[i] = reinterpret_cast<const f4*>(p.Wf_k)[i];
+    reinterpret_cast<f4*>(wf_v)[i] = reinterpret_cast<const f4*>(p.Wf_v)[i];
+  }
+  for (int i = tid; i < 512; i += THREADS) reinterpret_cast<f4*>(w2xv)[i] = reinterpret_cast<const f4*>(p.W2xv_l)[i];
+  for (int i = tid; i < 16; i += THREADS) b2xv[i] = p.b2xv[i];
+  for (int i = tid; i < 4096; i += THREADS) reinterpret_cast<f4*>(w2k)[i] = reinterpret_cast<const f4*>(p.W2k_l)[i];
+  __syncthreads();
+
+  // XCD-affine hand-out of chunks of NPW nodes (as in node_attn_kernel)
+  const int n_chunks = (p.n_seg + NPW - 1) / NPW;
+  const int n_wg = (int)gridDim.x, n_x = n_wg < 8 ? n_wg : 8;
+  const int xcd = (int)blockIdx.x % n_x, jx = (int)blockIdx.x / n_x, n_jx = (n_wg - xcd + n_x - 1) / n_x;
+  const int c_lo = (int)((long long)n_chunks * xcd / n_x), c_hi = (int)((long long)n_chunks * (xcd + 1) / n_x);
+  const int n_it = (c_hi - c_lo + n_jx - 1) / n_jx;          // (uniform per workgroup: every wave runs every barrier)
+  for (int it = 0; it < n_it; ++it) {
+    const int ch = c_lo + jx + it * n_jx;
+    const int si = ch * NPW + slot;
+    const bool active = ch < c_hi && si < p.n_seg;
+    // opaque copies of the lane id and of the wave's tile index: everything addressed through them (the LDS weight tables, the row
+    // gathers, the per-channel offsets) is then not loop-invariant, and the compiler cannot hoist ~100 address registers out of
+    // the node loop and spill them (the tile index is a compile-time constant in the one-wave kernel, a per-wave constant here)
+    int lw = lane, tile = __builtin_amdgcn_readfirstlane(tile0);
+    asm volatile("" : "+v"(lw));
+    asm volatile("" : "+s"(tile));
+    const int g = lw >> 4, m = lw & 15;
+    int seg = 0, n_rows = 0, lig0 = 0, n = 0, li = 0, n_tiles = 0;
+    const int* eid_g = nullptr;
+    float xd[3] = {0.f, 0.f, 0.f}, nd[3] = {0.f, 0.f, 0.f};
+    f4 lg = {NA_NEG, NA_NEG, NA_NEG, NA_NEG}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      seg = p.seg_ids ? p.seg_ids[si] : si;
+      if constexpr (KNN) {
+        n_rows = p.deg[seg];
+      } else {
+        const int gi = t.ctx_graph[seg];
+        n = t.g_nlig[gi];
+        lig0 = t.g_ctx_off[gi] + t.g_nph[gi];
+        li = seg - lig0;
+        eid_g = t.eid + t.g_eid_off[gi];
+        n_rows = n;
+      }
+      n_tiles = (n_rows + 15) >> 4;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xd[c] = p.x[seg * 3 + c];
+      if constexpr (KNN) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nd[c] = p.nrm[seg * 3 + c];
+      }
+    }
+    {   // (unconditional: a wave without a node or beyond the node's last tile computes masked rows of node `seg` = 0 / of the
+        //  node itself; nothing of it is used -- one straight-line body keeps the register allocation that of the one-wave kernel)
+      const float* ckp = p.Cdst_k + (size_t)seg * p.ld_cdst;
+      const float* cvp = p.Cdst_v + (size_t)seg * p.ld_cdst;
+      f4 U[8];
+      {
+        const float* qp = p.q + (size_t)seg * 128 + 8 * m;
+        const f4 qa = *reinterpret_cast<const f4*>(qp), qb = *reinterpret_cast<const f4*>(qp + 4);
+        // the table reads are addressed through a lane id that "depends" on the query: the scheduler otherwise issues all 64 of them
+        // while the query is still in flight and spills every one (ds_read -> scratch_store pairs, 770 B of scratch per lane)
+        int lq = lw;
+        asm volatile("" : "+v"(lq) : "v"(qa[0]), "v"(qb[0]));
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = tq * 4 + r;
+            const f4 wa = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i) * 64 + lq) * 4);
+            const f4 wb = *reinterpret_cast<const f4*>(w2k + ((size_t)(2 * i + 1) * 64 + lq) * 4);
+            U[tq][r] = (qa[0] * wa[0] + qa[1] * wa[1]) + (qa[2] * wa[2] + qa[3] * wa[3]) +
+                       (qb[0] * wb[0] + qb[1] * wb[1]) + (qb[2] * wb[2] + qb[3] * wb[3]);
+            if (r == 3) {
+              // the four values are pinned here (an empty asm that "rewrites" them): otherwise the vectoriser gathers all 64 table
+              // reads of the fold in front of its arithmetic and every one of them is spilled (770 B of scratch per lane)
+              asm volatile("" : "+v"(U[tq][0]), "+v"(U[tq][1]), "+v"(U[tq][2]), "+v"(U[tq][3]) : : "memory");
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      }
+      const int k = tile * 16 + m;
+      bool valid = k < n_rows;
+      int src = 0, crow = 0;
+      if constexpr (KNN) {
+        if (valid) { src = p.nbr[(size_t)seg * p.knn_k + k]; crow = src; }
+      } else {
+        valid = valid && k != li;
+        if (valid) { src = lig0 + k; crow = eid_g[k * n + li]; }
+      }
+      float feat[NSTEP > 0 ? NSTEP : 1];
+      bool has_lig = false, has_ph = false;
+      if constexpr (KNN) {
+        float d = 0.f, dots[3] = {0.f, 0.f, 0.f};
+        bool src_lig = false;
+        if (valid) {
+          float xs[3], ns[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { xs[c] = p.x[src * 3 + c]; ns[c] = p.nrm[src * 3 + c]; }
+          const float r0 = xd[0] - xs[0], r1 = xd[1] - xs[1], r2 = xd[2] - xs[2];
+          d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+          dots[0] = ns[0] * nd[0] + ns[1] * nd[1] + ns[2] * nd[2];
+          dots[1] = -(ns[0] * r0 + ns[1] * r1 + ns[2] * r2);
+          dots[2] = -(nd[0] * r0 + nd[1] * r1 + nd[2] * r2);
+          src_lig = t.ctx_is_lig[src] != 0;
+        }
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+          const float sv = valid ? smear(d, 4 * st + g) : 0.f;
+          feat[st] = src_lig ? sv : 0.f;
+          feat[5 + st] = src_lig ? 0.f : sv;
+        }
+        has_lig = __ballot(valid && src_lig) != 0ull;
+        has_ph = __ballot(valid && !src_lig) != 0ull;
+        feat[10] = g == 0 ? dots[0] : (g == 1 ? dots[1] : (g == 2 ? dots[2] : ((valid && src_lig) ? 1.f : 0.f)));
+        feat[11] = g == 0 ? ((valid && !src_lig) ? 1.f : 0.f) : (g == 3 ? 1.f : 0.f);
+      }
+      // ---- key MLP -> logits of the tile's rows ----
+      f4 hid[8];
+      {
+        const float* pk = p.Csrc_k + (size_t)crow * p.ld_csrc + 4 * g;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) {
+          f4 c = {0.f, 0.f, 0.f, 0.f};
+          if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+          if constexpr (!KNN) c += *reinterpret_cast<const f4*>(ckp + 16 * tq + 4 * g);
+          hid[tq] = c;
+        }
+      }
+#pragma unroll
+      for (int blk3 = 0; blk3 < (NSTEP ? 3 : 0); ++blk3) {
+        if ((blk3 == 0 && !has_lig) || (blk3 == 1 && !has_ph)) continue;
+#pragma unroll
+        for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) {
+            float w = wf_k[(st * 8 + tq) * 64 + lw];
+            if (st == 11) w = g == 3 ? ckp[16 * tq + m] : w;
+            hid[tq] = mfma16(w, feat[st], hid[tq]);
+          }
+      }
+      const float rs = ln_fold_k(hid, bpk, g);
+      f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          acc = mfma16(hid[tq][r], U[tq][r], acc);
+          acc2 = mfma16(hid[tq][r + 1], U[tq][r + 1], acc2);
+        }
+      acc += acc2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kr = tile * 16 + 4 * g + r;
+        const bool vr = kr < n_rows && (KNN || kr != li);
+        const float sc_ = acc[r] * __shfl(rs, 4 * g + r);
+        lg[r] = vr ? sc_ : NA_NEG;
+      }
+      // ---- value MLP of the position update: v[row,h] ----
+      f4 hx[8];
+      {
+        const float* pk = p.Csrc_v + (size_t)crow * p.ld_csrc + 4 * g;
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq) {
+          f4 c = {0.f, 0.f, 0.f, 0.f};
+          if (valid) c = *reinterpret_cast<const f4*>(pk + 16 * tq);
+          if constexpr (!KNN) c += *reinterpret_cast<const f4*>(cvp + 16 * tq + 4 * g);
+          hx[tq] = c;
+        }
+      }
+#pragma unroll
+      for (int blk3 = 0; blk3 < (NSTEP ? 3 : 0); ++blk3) {
+        if ((blk3 == 0 && !has_lig) || (blk3 == 1 && !has_ph)) continue;
+#pragma unroll
+        for (int st = 5 * blk3; st < (blk3 == 2 ? 12 : 5 * blk3 + 5); ++st)
+#pragma unroll
+          for (int tq = 0; tq < 8; ++tq) {
+            float w = wf_v[(st * 8 + tq) * 64 + lw];
+            if (st == 11) w = g == 3 ? cvp[16 * tq + m] : w;
+            hx[tq] = mfma16(w, feat[st], hx[tq]);
+          }
+      }
+      const float rsx = ln_fold_k(hx, bpv, g);
+      f4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tq = 0; tq < 8; ++tq)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          a1 = mfma16(hx[tq][r], w2xv[(tq * 4 + r) * 64 + lw], a1);
+          a2 = mfma16(hx[tq][r + 1], w2xv[(tq * 4 + r + 1) * 64 + lw], a2);
+        }
+      a1 += a2;
+      const float bx = b2xv[m];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[r] = a1[r] * __shfl(rsx, 4 * g + r) + bx;
+    }
+
+    // ---- the tiles of a node meet: per-head maximum (exact in any order) ----
+    xmax[wave * 64 + lane] = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+    __syncthreads();
+    float mx = NA_NEG;
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) mx = fmaxf(mx, xmax[(slot * T + tt) * 64 + lane]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    {
+      f4 gate = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (KNN) {
+        if (active && tile < n_tiles) gate = *reinterpret_cast<const f4*>(p.ew + (size_t)seg * p.knn_k + tile * 16 + 4 * g);
+      }
+      f4 e4, w4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = lg[r] > 0.5f * NA_NEG ? __builtin_amdgcn_exp2f(lg[r] - mx) : 0.f;
+        e4[r] = e;
+        w4[r] = (e * gate[r]) * vv[r];
+      }
+      *reinterpret_cast<f4*>(xew + ((size_t)wave * 64 + lane) * 8) = e4;
+      *reinterpret_cast<f4*>(xew + ((size_t)wave * 64 + lane) * 8 + 4) = w4;
+    }
+    __syncthreads();
+    // ---- one wave per node: the sequential chains in the one-wave kernel's order (tile-major, row inner) ----
+    if (active && tile == 0) {
+      float l = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+        const f4 e4 = *reinterpret_cast<const f4*>(xew + ((size_t)(slot * T + tt) * 64 + lane) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) l += e4[r];
+      }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt)
+        if (tt < n_tiles) {
+          const f4 w4 = *reinterpret_cast<const f4*>(xew + ((size_t)(slot * T + tt) * 64 + lane) * 8 + 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kr = tt * 16 + 4 * g + r;
+            const bool vr = kr < n_rows && (KNN || kr != li);
+            if (vr) {
+              const int src = KNN ? p.nbr[(size_t)seg * p.knn_k + kr] : lig0 + kr;
+              const float w = w4[r];
+              a0 = fmaf(w, xd[0] - p.x[src * 3], a0);
+              a1 = fmaf(w, xd[1] - p.x[src * 3 + 1], a1);
+              a2 = fmaf(w, xd[2] - p.x[src * 3 + 2], a2);
+            }
+          }
+        }
+      a0 = wave_sum(a0 * inv) * (1.f / 16.f);
+      a1 = wave_sum(a1 * inv) * (1.f / 16.f);
+      a2 = wave_sum(a2 * inv) * (1.f / 16.f);
+      if (lane == 0) {
+        if (p.accumulate_dx) { p.dx[seg * 3] += a0; p.dx[seg * 3 + 1] += a1; p.dx[seg * 3 + 2] += a2; }
+        else { p.dx[seg * 3] = a0; p.dx[seg * 3 + 1] = a1; p.dx[seg * 3 + 2] = a2; }
+      }
+    }
+  }
+}
+
+template <bool KNN, int T>
+static int launch_pos_tiled(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  constexpr int NSTEP = KNN ? 12 : 0, NPW = 12 / T;
+  const size_t lds = (256 + 2 * NSTEP * 512 + 2048 + 16 + 16384 + 12 * 64 + 12 * 64 * 8) * sizeof(float);
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(node_attn_pos_tiled_kernel<KNN, T>), lds, "node_attn(pos, tiled)")) return rc;
+  int blocks = (p->n_seg + NPW - 1) / NPW;
+  if (blocks > kNumCU) blocks = kNumCU;
+  hipLaunchKernelGGL((node_attn_pos_tiled_kernel<KNN, T>), dim3(blocks), dim3(768), lds, st, *t, *p);
+  return check_launch("pg_seg_attn(node pos, tiled)");
+}
+
+// the tiled form serves the fused sampler calls of the position modes (no second target list, no training outputs); -1 otherwise
+static int launch_pos_tiled_any(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
+  if (p->alpha || p->n_seg2 > 0) return -1;
+  if (p->mode == PG_SEG_KNN_POS) return p->knn_k <= 32 ? launch_pos_tiled<true, 2>(t, p, st) : -1;
+  const int tiles = (t->max_nlig + 15) / 16;
+  if (tiles <= 2) return launch_pos_tiled<false, 2>(t, p, st);
+  if (tiles == 3) return launch_pos_tiled<false, 3>(t, p, st);
+  if (tiles == 4) return launch_pos_tiled<false, 4>(t, p, st);
+  return -1;
+}
+
 // returns -1 when the shape is outside what the two-pass kernels hold in registers (caller falls back to seg_attn.hip).
 // Fused form: q and W2k_l given (and, for the node-update modes, W2v_l, b2v, out) -- see node_attn_fused_request()
 bool node_attn_fused_request(const PgSegAttn* p) {
@@ -524,7 +831,12 @@ int launch_node_attn(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
     set_error("pg_seg_attn: Wf_k / Wf_v / W2xv_l must be 16-byte aligned");
     return PG_ERR_ARG;
   }
-  return node_attn_fused_request(p) ? launch_node_attn_t<true>(t, p, st) : launch_node_attn_t<false>(t, p, st);
+  if (!node_attn_fused_request(p)) return launch_node_attn_t<false>(t, p, st);
+  if (p->pos_tiled && (p->mode == PG_SEG_KNN_POS || p->mode == PG_SEG_BOND_POS)) {
+    const int rc = launch_pos_tiled_any(t, p, st);
+    if (rc != -1) return rc;
+  }
+  return launch_node_attn_t<true>(t, p, st);
 }
 
 }  // namespace pg

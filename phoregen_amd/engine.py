@@ -67,6 +67,10 @@ class Engine:
         # not depend on the new coordinates) run on lane 2 during this layer's position updates
         self.layer_ahead = o['layer_ahead']
         self.small_below = o['small_below']
+        # (hipGraph capture of the v2 launch list segfaults inside the runtime -- lanes 2 / 3 wait on lane 1 there while lane 1 waits on
+        #  lane 3; the replay variant, off by default and measured slower, keeps the previous list)
+        self.ahead_v2 = (o['ahead_v2'] == 'always' or (o['ahead_v2'] == 'auto' and self.plan.n_bond < o['ahead_v2_below'])) and not o['graph']
+        self.pos_tiled, self.pos_tiled_below = o['pos_tiled'], o['pos_tiled_below']
         self.tri_grid = o['tri_grid']                  # persistent triplet workgroups (-1: by batch size)
         # apply_dx + bond smearing + direction vectors as one launch on lane 0: small batches (measured, same box: 16 graphs 3.52 -> 3.40 ms
         # per step, 32 graphs 5.69 -> 5.43; 128 graphs 20.20 -> 20.28: there the three launches hide beside the first-layer GEMM)
@@ -299,6 +303,11 @@ class Engine:
                 kw.update(Csrc_k=csrc[:, 0:128], Csrc_v=csrc[:, 128:256], ld_csrc=csrc.stride(0))
             if pos:
                 kw.update(W2xv_l=a.W2xv_l, b2xv=a.b2xv, dx=dx, accumulate_dx=0)
+                # small batches: a node's row tiles over several waves (csrc/node_attn.hip, bit-identical): the launch is bound by the
+                # dependent chain inside the wave that owns a node, not by the chip
+                tiled = self.pos_tiled == 'always' or (self.pos_tiled == 'auto' and n_seg <= self.pos_tiled_below)
+                if fused and tiled:
+                    kw.update(pos_tiled=1)
             else:
                 kw.update(S=wS, swn=wsw)
             if fused:      # (U / S / swn stay attached as scratch for the one-pass fallback inside pg_seg_attn)
@@ -400,6 +409,7 @@ class Engine:
         # 3.93 -> 3.83 ms, 32 graphs 5.94 -> 5.67, 64 graphs 10.55 -> 10.36, 128 graphs 20.12 -> 20.17 (the triplet kernel then
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
         ahead = self.layer_ahead and self.multi_stream and E < self.small_below
+        v2 = self.ahead_v2 and ahead        # Y1 of the next layer on lane 1 behind Y2, bond-node of layer 0 on lane 3, finer waits (round 4)
         chain_q = self.multi_stream and E < self.small_below         # small batches: the Q rows on the bond chain's own lane
         # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
         # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 192 workgroups, 24 / 32 graphs 4.9 -> 4.7 / 5.87 -> 5.61 with
@@ -442,7 +452,9 @@ class Engine:
                 self._lane = 3
                 self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
                 self._lane = 0
-            if pre:
+            if pre and v2:
+                self._wait(prog, 0, y1_done)           # P / Q read this layer's first-layer blocks (lane 1 wrote them behind the previous Y2)
+            elif pre:
                 self._sync(prog, 0, (2,))              # lane 2 carried them through the previous layer's position updates
             else:
                 first_layer_gemm(L, hc)
@@ -476,9 +488,16 @@ class Engine:
             if not pre:
                 self._lane = 3                                                          # triplet queries
                 triplet_queries(L, hbc)
+                q3_done = self._record(prog, 3)
             self._lane = 0
             if not pre:                            # (pre: lane 3 carries the bond-node attention, which lin_node waits for)
-                self._join(prog, (3,))
+                if v2:
+                    self._wait(prog, 0, q3_done)   # (lane 3 goes on with the bond-node attention: not joined)
+                else:
+                    self._join(prog, (3,))
+            elif v2:
+                self._sync(prog, 0, (2,))          # this layer's triplet queries (lane 2, launched one layer ahead)
+            before_tri = self._record(prog, 0)     # every reader of this layer's Y1 on lanes 0 / 2 / 3 (but the bond-node attention) is in front of this
             a = L.TB
             self._event(prog, 'triplet', True)
             self.tri_calls.append(len(prog))
@@ -495,20 +514,24 @@ class Engine:
             # ---- node update over bond edges (:284)                                   [lane 2]
             # (the sub-layer reads no coordinates: from layer 1 on a small batch has launched it during the previous layer's position
             #  updates, see below)
-            self._lane = 2
-            if not pre:
+            self._lane = 3 if v2 else 2            # (v2: lane 1 then never waits on lane 2, so lane 2 may wait on lane 1 -- the other
+            if not pre:                            #  order of the two edges breaks hipGraph capture)
                 bond_node_rows(L, hbc)
                 self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=1)
+                if v2:
+                    bn_done = self._record(prog, 3)
             # ---- node update over knn edges (:281), then h' = h + lin_node(aggE + aggB) (:288)   [lane 1]
             self._lane = 1
             if not pre:
                 self._query_gemm(prog, L.NE, w.Y1, 0, both, 0)
+            if pre and v2:
+                self._wait(prog, 1, ne_done)           # this layer's knn-node query (lane 3, launched one layer ahead)
             self._event(prog, 'knn_node', True)       # (the launches of the sub-layer: ligand targets, pharmacophore targets)
             self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0, query_done=True,
                                  qbuf=3 if pre else None)
             self._event(prog, 'knn_node', False)
-            if pre:
-                self._wait(prog, 1, bn_done)           # aggB: the bond-node attention launched one layer ahead (lane 3)
+            if pre or v2:
+                self._wait(prog, 1, bn_done)           # aggB: the bond-node attention on lane 3 (launched one layer ahead from layer 1 on)
             else:
                 self._sync(prog, 1, (2,))              # aggB
             # two K = 128 launches of the streaming kernel instead of one K = 256 launch of the tiled one (56 -> 2 x ~17 us)
@@ -525,6 +548,15 @@ class Engine:
             else:
                 self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
             self._sync(prog, 0, (1,))                  # lane 0 continues after the triplet kernel AND Y2 (which implies lane 2)
+            more_ahead = ahead and li + 1 < n_layers and not last
+            if v2 and more_ahead:
+                # h' is final and Y2 is out: the next layer's first-layer blocks follow on lane 1 (beside the triplet kernel / the bond
+                # position update), so that the position phase's side lanes start with the triplet queries right away and the next P
+                # waits for these blocks only.  Readers of this layer's Y1 on the other lanes are all in front of `before_tri`.
+                self._lane = 1
+                self._wait(prog, 1, before_tri)
+                first_layer_gemm(pk.layers[li + 1], hn)
+                y1_done = self._record(prog, 1)
             # the bond position update's query MLP runs beside its edge product / the knn position update, not in front of the
             # attention on lane 0: lane 3 is free after the triplet queries (last layer: lane 2, in front of the node head --
             # forked from lane 0, which has just seen h' and Y2: a lane-2-waits-lane-1 edge after lane 1 waited on lane 2 crashes
@@ -545,12 +577,19 @@ class Engine:
                 #      bond position update's query; lin_node of the next layer is what waits for it, not its triplet kernel).
                 Ln = pk.layers[li + 1]
                 self._lane = 2
-                first_layer_gemm(Ln, hn)
-                y1_done = self._record(prog, 2)
+                if v2:
+                    self._wait(prog, 2, y1_done)
+                else:
+                    first_layer_gemm(Ln, hn)
+                    y1_done = self._record(prog, 2)
                 triplet_queries(Ln, hbn)
-                self._query_gemm(prog, Ln.NE, w.Y1, 0, both, 3)
+                if not v2:
+                    self._query_gemm(prog, Ln.NE, w.Y1, 0, both, 3)
                 self._lane = 3
                 self._wait(prog, 3, y1_done)
+                if v2:
+                    self._query_gemm(prog, Ln.NE, w.Y1, 0, both, 3)
+                    ne_done = self._record(prog, 3)
                 bond_node_rows(Ln, hbn)
                 self._node_attention(prog, hip.SEG_BOND_NODE, Ln.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=2)
                 bn_done = self._record(prog, 3)

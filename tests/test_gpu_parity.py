@@ -803,6 +803,11 @@ def test_engine_variants_agree(model):
     # the coordinate-only kernels as three launches on three lanes (pg_apply_dx, pg_bond_smear, pg_lig_normals) instead of pg_layer_geom
     assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never')))
     assert all(torch.equal(a, b) for a, b in zip(base, run(fused_geom='never', streams=False)))
+    # position-update attention with a node's row tiles over several waves (small batches) or one wave per node: same bits
+    assert all(torch.equal(a, b) for a, b in zip(base, run(pos_tiled='never')))
+    assert all(torch.equal(a, b) for a, b in zip(base, run(pos_tiled='always')))
+    assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='never')))     # the placement of the work launched one layer ahead used for large batches
+    assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='always')))
     layer_by_layer = run(layer_ahead=False)     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
     assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
     for grid in (0, 96, 200):                   # persistent triplet workgroups (small batches leave CUs to the side lanes):
