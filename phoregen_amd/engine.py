@@ -452,10 +452,10 @@ class Engine:
                 self._lane = 3
                 self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
                 self._lane = 0
-            if pre and v2:
-                self._wait(prog, 0, y1_done)           # P / Q read this layer's first-layer blocks (lane 1 wrote them behind the previous Y2)
-            elif pre:
-                self._sync(prog, 0, (2,))              # lane 2 carried them through the previous layer's position updates
+            if pre:
+                # lane 2 carried this layer's triplet queries through the previous layer's position updates (v2: behind a wait for its
+                # first-layer blocks, which lane 1 wrote: one wait on lane 2 covers both)
+                self._sync(prog, 0, (2,))
             else:
                 first_layer_gemm(L, hc)
             if li == 0 and pre_join:
@@ -495,9 +495,8 @@ class Engine:
                     self._wait(prog, 0, q3_done)   # (lane 3 goes on with the bond-node attention: not joined)
                 else:
                     self._join(prog, (3,))
-            elif v2:
-                self._sync(prog, 0, (2,))          # this layer's triplet queries (lane 2, launched one layer ahead)
-            before_tri = self._record(prog, 0)     # every reader of this layer's Y1 on lanes 0 / 2 / 3 (but the bond-node attention) is in front of this
+            if v2:
+                before_tri = self._record(prog, 0) # every reader of this layer's Y1 on lanes 0 / 2 / 3 (but the bond-node attention) is in front of this
             a = L.TB
             self._event(prog, 'triplet', True)
             self.tri_calls.append(len(prog))
@@ -547,6 +546,10 @@ class Engine:
                 self._gemm(prog, hn, 128, L.W_node2[512:], w.Y2[:, 512:], p.n_lig, 768, bias=L.b_node2[512:], rows=p.lig2ctx)
             else:
                 self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
+            if v2:
+                # the bond position update's query right behind Y2 on the node chain's lane (Y2 is out well before the triplet kernel ends):
+                # the one event lane 0 waits for below then covers it, instead of a second cross-lane hop in front of the attention
+                self._query_gemm(prog, L.PB, w.Y2, 5 * 128, lig, 1)
             self._sync(prog, 0, (1,))                  # lane 0 continues after the triplet kernel AND Y2 (which implies lane 2)
             more_ahead = ahead and li + 1 < n_layers and not last
             if v2 and more_ahead:
@@ -564,8 +567,9 @@ class Engine:
             qlane = 2 if last else 3
             self._fork(prog, (2, 3) if (ahead and li + 1 < n_layers) else (qlane,))
             self._lane = qlane
-            self._query_gemm(prog, L.PB, w.Y2, 5 * 128, lig, 1)
-            q_done = self._record(prog, qlane)         # (this point of the lane: the node head below is not waited for)
+            if not v2:
+                self._query_gemm(prog, L.PB, w.Y2, 5 * 128, lig, 1)
+                q_done = self._record(prog, qlane)     # (this point of the lane: the node head below is not waited for)
             if last:
                 heads[1](hn)                           # lane 2 has nothing else left in this step: the node head takes it
             elif ahead and li + 1 < n_layers:
@@ -597,7 +601,8 @@ class Engine:
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
             self._lane = 0
             self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
-            self._wait(prog, 0, q_done)
+            if not v2:
+                self._wait(prog, 0, q_done)
             self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1, query_done=True)
             self._join(prog, (1,))
             if self.fused_geom:      # x' = x + dx, and from x' the next layer's smearing + direction vectors (last layer: the update alone)
