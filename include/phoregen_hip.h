@@ -306,6 +306,11 @@ typedef struct {
   const float* S; const float* swn;        /* ... with the forward's S / swn: one pass instead of two                */
   float* rowbuf; int rowbuf_rows; int grid;/* scratch: grid * pg_seg_attn_bwd_waves(mode) * rowbuf_rows * 48 floats,
                                               rowbuf_rows >= rows of the largest segment; grid = workgroups to launch */
+  const int* atom_order;                   /* PG_SEG_TRIPLET, optional: [n_lig] ligand atoms (0 .. n_lig-1) in the order the persistent
+                                              workgroups take them (workgroup b: entries b, b + grid, ...).  The kernel works off one SOURCE
+                                              ATOM per workgroup round and an atom costs ~ (n-1) x ceil(n/16): in index order the slowest of
+                                              256 workgroups carries 16 % more than the average on the config-5 batch; sorted by cost and
+                                              dealt out in a snake it is 1 %.  NULL = index order.  Results do not depend on it. */
 } PgSegAttnGrad;
 int pg_seg_attn_bwd_waves(int mode);
 int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* g, void* stream);

@@ -863,7 +863,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   if constexpr (T::TRI) {
     // one workgroup per source atom j: its n-1 segments (j -> i) all scatter into the rows P[k -> j], which no other
     // source touches: accumulate them in LDS and store each row once
-    for (int a = blockIdx.x; a < t.n_lig; a += gridDim.x) {
+    for (int ai = blockIdx.x; ai < t.n_lig; ai += gridDim.x) {
+      const int a = gr.atom_order ? gr.atom_order[ai] : ai;      // cost-sorted hand-out (PgSegAttnGrad.atom_order): levels the workgroups
       const int cj = t.lig2ctx[a];
       const int gi = t.ctx_graph[cj];
       const int n = t.g_nlig[gi], lig0 = t.g_ctx_off[gi] + t.g_nph[gi], lj = cj - lig0;

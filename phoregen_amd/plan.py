@@ -145,6 +145,22 @@ class BatchPlan:
         self._cpu_sig = (bn.clone(), bp.clone(), ei_ref.clone())     # (copies: .cpu().long() of a CPU long tensor is the caller's own storage)
         self.ws = None   # engine workspace, attached lazily
 
+    def bwd_atom_order(self, grid):
+        """Ligand atoms in the order the `grid` persistent workgroups of the triplet adjoint take them (PgSegAttnGrad.atom_order):
+        sorted by cost (n - 1 segments x (ceil(n / 16) tiles + 1)) descending and dealt out in a snake, so that every workgroup gets
+        the same mix (config-5 batch: heaviest workgroup 1.16 x the mean in index order, 1.01 x this way)."""
+        cache = self.__dict__.setdefault('_bwd_atom_order', {})
+        if grid not in cache:
+            n = torch.repeat_interleave(self.num_atoms, self.num_atoms).double()
+            cost = (n - 1) * (torch.ceil(n / 16) + 1)
+            srt = torch.argsort(cost, descending=True, stable=True)
+            idx = torch.arange(srt.numel())
+            rnd, pos = idx // grid, idx % grid
+            full = (rnd + 1) * grid <= srt.numel()                       # (a partial last round keeps its order)
+            j = torch.where((rnd % 2 == 1) & full, grid - 1 - pos, pos)
+            cache[grid] = srt[rnd * grid + j].to(torch.int32).to(self.device)
+        return cache[grid]
+
     @staticmethod
     def _versions(tensors):
         """Version counters of the caller's index tensors, or None when one of them does not track versions (tensors created

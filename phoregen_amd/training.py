@@ -413,6 +413,10 @@ class SegCoreFn(torch.autograd.Function):
         rows = (cfg['max_rows'] + 15) // 16 * 16
         rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
         g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
+        if cfg['mode'] == hip.SEG_TRIPLET and cfg.get('plan') is not None and options.get('bwd_atom_sort'):
+            ao = cfg['plan'].bwd_atom_order(grid)          # cost-sorted source atoms, dealt out in a snake (levels the persistent workgroups)
+            g.atom_order = ao.data_ptr()
+            keep.append(ao)
         if getattr(ctx, 'has_alpha', False):
             a_ = ctx.saved_tensors[0]
             g.alpha, g.alpha_rows = a_.data_ptr(), ctx.alpha_rows
@@ -602,7 +606,7 @@ class TrainForward:
             qhid = linear_gather_add(hb, a.W_q_hb, Y1(14 * 128, 15 * 128), p.bond_dst, topo=p.topo_ref, kinds=('dst',))
             qT = linear(LnReluFn.apply(qhid, a.q_ln_g, a.q_ln_b), a.W2q, a.b2q) * HEAD_SCALE
             U = FoldFn.apply(qT, a.W2k_l, None, E)
-            cfg = dict(mode=hip.SEG_TRIPLET, n_seg=E, seg_ids=None, k=self.k, topo=p.topo_ref, n_out_rows=E,
+            cfg = dict(mode=hip.SEG_TRIPLET, n_seg=E, seg_ids=None, k=self.k, topo=p.topo_ref, plan=p, n_out_rows=E,
                        max_rows=max_lig, need_gx=True,
                        tri_fwd=dict(q=qT.detach(), W2k_l=a.W2k_l.detach(), W2v_l=a.W2v_l.detach(), b2v=a.b2v.detach(),
                                     Wg2_k=a.Wg2_k.detach(), Wg2_v=a.Wg2_v.detach(), G=G.detach().contiguous(),

@@ -504,3 +504,24 @@ def test_partition_balances_the_fitted_step_cost():
     cost = graph_cost(na, nph)
     worst = lambda parts: max(float(cost[p].sum()) for p in parts)
     assert worst(partition_graphs(na, 4, nph)) <= worst(partition_graphs(na, 4))
+
+
+def test_triplet_adjoint_atom_order_is_a_balanced_permutation():
+    """BatchPlan.bwd_atom_order (PgSegAttnGrad.atom_order): every ligand atom exactly once, and the persistent workgroups of the triplet
+    adjoint -- workgroup b works off entries b, b + grid, ... -- carry nearly equal cost, unlike in index order."""
+    from phoregen_amd.plan import BatchPlan, make_edge_data
+    g = torch.Generator().manual_seed(11)
+    na = (25 + 5 * torch.randn(256, generator=g)).round().clamp(8, 60).long()
+    B = na.numel()
+    ei, be = make_edge_data(na)
+    plan = BatchPlan(torch.repeat_interleave(torch.arange(B), na), torch.zeros(0, dtype=torch.long), ei, be, B, 'cpu')
+    n = torch.repeat_interleave(na, na).double()
+    cost = (n - 1) * (torch.ceil(n / 16) + 1)
+    for grid in (256, 64, 7):
+        order = plan.bwd_atom_order(grid).long()
+        assert sorted(order.tolist()) == list(range(int(na.sum())))
+        load = lambda seq: torch.stack([cost[seq[b::grid]].sum() for b in range(grid)])
+        sorted_load, index_load = load(order), load(torch.arange(order.numel()))
+        assert float(sorted_load.max() / sorted_load.mean()) <= 1.03, grid
+        assert float(sorted_load.max()) <= float(index_load.max())
+    assert float(load(torch.arange(order.numel())).max() / cost.sum() * 7) > 0      # (index order at 256 workgroups: 1.16 x the mean)
