@@ -335,6 +335,29 @@ def test_forward_against_oracle_larger_graphs(profile):
         assert max(errs32.values()) <= TOL, errs32
 
 
+def test_tiled_position_kernels_are_bit_identical_on_ragged_graphs(model):
+    """node_attn_pos_tiled_kernel (a node's row tiles over several waves, small batches) against the one-wave kernels on shapes that
+    hit every instantiation and edge: ligands of 1 and 2 atoms (no / one row), 15..17, 31..33, 47..49, 64 atoms (T = 2, 3, 4 bond tiles;
+    one batch per tile count, the kernel is chosen by the largest ligand), knn degrees below 16 and below 32 (one / two knn tiles), a
+    ligand above 64 atoms in the batch (bond form falls back to the one-wave kernel, knn form stays tiled).  Same bits required."""
+    from oracle.make_inputs import synthetic_batch
+    from phoregen_amd import options
+    batches = [([1, 2, 15, 16, 17, 31, 32], [3, 1, 9, 20, 40, 5, 70]),
+               ([33, 47, 48, 2, 5], [12, 30, 1, 8, 25]),
+               ([49, 64, 20, 3], [60, 10, 2, 33]),
+               ([70, 12, 40], [15, 4, 90])]
+    for bi, (na, nph) in enumerate(batches):
+        inp = {k: v.to(DEV) for k, v in synthetic_batch(40 + bi, na, nph, [(137 * (i + 1)) % 1000 for i in range(len(na))]).items()}
+        outs = {}
+        for mode in ('never', 'always'):
+            model._engine = None
+            with options.override(pos_tiled=mode), torch.no_grad():
+                outs[mode] = [o.clone() for o in model(**inp)[:3]]
+        model._engine = None
+        for a, b in zip(outs['never'], outs['always']):
+            assert torch.isfinite(a).all() and torch.equal(a, b), (bi, na)
+
+
 def test_forward_row_tile_boundaries(model, oracle):
     """Ligand sizes on both sides of every 16-row tile boundary of the segment kernels (15..17, 31..33, 47..49, 64, 65) and
     pharmacophores around the knn degree (k = 32: graphs of 32, 33, 34 nodes in total)."""
