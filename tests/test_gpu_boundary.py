@@ -204,3 +204,37 @@ def test_cpu_rng_mode_consumes_the_generator_exactly_like_the_reference(model):
         assert torch.equal(res['traj'][2][s].cpu().argmax(-1), ref['traj'][2][s].argmax(-1)), s
         rmsd = float(((res['traj'][1][s].cpu() - ref['traj'][1][s]) ** 2).sum(-1).mean().sqrt())
         assert rmsd <= 1e-4, (s, rmsd)
+
+
+def test_config2_full_size_sample_call(model):
+    """BASELINE.json configs[1] at its real size through the reference's entry point: `model.sample(data, 100, device)` on ONE pharmacophore
+    (the 44-node P03211 shape recorded in g8_phore_parse), all 1000 reverse steps, guidance on as in sample.sh.  Contract of the result
+    (diffusion.py:505-525): shapes, finite coordinates, one-hot discrete trajectories, atom counts honoured; same seed -> same sample;
+    the first graphs equal the same graphs sampled in a smaller call (noise is keyed by graph id, not by the batch)."""
+    from phoregen_amd.data import PhoreGraph
+    g = golden('g8_phore_parse')
+    data = PhoreGraph(t(g['x']), t(g['pos']), t(g['norm']), t(g['center'])).to(DEV)
+    gen = torch.Generator().manual_seed(2032)
+    na = torch.randint(20, 45, (100,), generator=gen)
+    guid = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}]
+    res = model.sample(data, 100, DEV, pos_guidance_opt=guid, num_atoms=na, seed=77, return_traj=True)
+    N, E = int(na.sum()), int((na * (na - 1)).sum())
+    tn, tp, te = res['traj']
+    assert tn.shape == (1001, N, 12) and tp.shape == (1001, N, 3) and te.shape == (1001, E, 6)
+    assert torch.isfinite(tp).all() and all(torch.isfinite(x).all() for x in res['pred'])
+    assert tn.sum(-1).eq(1).all() and te.sum(-1).eq(1).all()
+    assert torch.equal(res['lig_info'][0].cpu(), na)
+    again = model.sample(data, 100, DEV, pos_guidance_opt=guid, num_atoms=na, seed=77, return_traj=False)
+    assert torch.equal(again['pred'][0], res['pred'][0]) and torch.equal(again['pred'][1], res['pred'][1])
+    # the first 10 graphs in a 10-graph call: same types, coordinates to 1e-6 of the coordinate scale (guidance energies are means over
+    # the call's graphs, so the smaller call passes the full batch size on)
+    n10, e10 = int(na[:10].sum()), int((na[:10] * (na[:10] - 1)).sum())
+    p = g['x'].shape[0]
+    small = model.sample_batch(t(g['x']).repeat(10, 1), t(g['pos']).repeat(10, 1), t(g['norm']).repeat(10, 1),
+                               torch.repeat_interleave(torch.arange(10), p), na[:10], t(g['center']).unsqueeze(0).expand(10, 3),
+                               pos_guidance_opt=guid, rng='device', seed=77, return_traj=False, guidance_batch=100,
+                               guidance_center=t(g['pos'])[t(g['x'])[:, 12] != 1].mean(0))
+    assert torch.equal(small['pred'][0].argmax(-1), res['pred'][0][:n10].argmax(-1))
+    assert torch.equal(small['pred'][2].argmax(-1), res['pred'][2][:e10].argmax(-1))
+    scale = max(1.0, float(res['pred'][1].abs().max()))
+    assert float((small['pred'][1] - res['pred'][1][:n10]).abs().max()) <= 1e-6 * scale
