@@ -4,7 +4,7 @@ conditioning floor of that state (tests/golden/conditioning_floor.json) and thei
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1])]
 commit = sys.argv[2] if len(sys.argv) > 2 else '?'
-print(f'# r03 (commit {commit}): HIP error / conditioning floor for every checked sampler step\n')
+print(f'# (commit {commit}): HIP error / conditioning floor for every checked sampler step\n')
 print('`python -m pytest tests -m gpu` on 1x MI355X.  err = max-abs error of the HIP output against the REFERENCE\'s recorded fp32 output, relative to '
       'max|reference|; floor = largest distance of a 12-member fp32 ensemble of the reference\'s own dataflow (rows permuted, coordinates '
       '+-1 ulp) from its float64 evaluation on the same state (`oracle/make_conditioning_floor.py`, frozen in '
