@@ -24,7 +24,7 @@ def graph_cost(num_atoms, n_phore=None):
     return COST_US['tile'] * tiles * n * (n - 1) + COST_US['bond'] * n * (n - 1) + COST_US['node'] * ctx
 
 
-def partition_graphs(num_atoms, world_size, n_phore=None):
+def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.0, big_discount=None):
     """Greedy (longest-processing-time) balanced partition of independent graphs over the ranks by `graph_cost`: the triplet
     term ~ n^3 dominates a large graph, but at the 16 graphs a rank gets of the headline batch 45 % of a step scales with n^2 and
     n + p (p ranges 23 .. 203), so n^3 alone picks the wrong slowest rank.  Returns a list of LongTensors of graph ids
@@ -33,10 +33,69 @@ def partition_graphs(num_atoms, world_size, n_phore=None):
     order = torch.argsort(cost, descending=True, stable=True)
     load = [0.0] * world_size
     parts = [[] for _ in range(world_size)]
+    if by_size and world_size > 1:
+        # first-fit decreasing into bins of the mean load: the largest ligands end up TOGETHER on the first ranks.  The attention kernels
+        # are instantiated for the row tiles of the largest ligand of a batch (n >= 50 atoms: 4 tiles of 16 rows, n <= 49: 3): spread by
+        # LPT, the nine 50+-atom graphs of the headline batch put all eight ranks on the 4-tile kernels (+ 5 % per step)
+        # ... and a rank on the 4-tile kernels gets `big_discount` less than its share (measured on the headline batch: equal cost, + 5 % time)
+        cap_mean = float(cost.sum()) / world_size
+        if big_discount is None:
+            # measured on shares of the headline batch (tools/predict_scaling.py): per unit of cost a rank on the 4-tile kernels is 5.0 / 5.7 %
+            # slower at 16 / 32 graphs per rank, 0.7 % at 64 (the kernels are throughput-bound there)
+            big_discount = 0.05 * min(1.0, max(0.15, (12000.0 - cap_mean) / 6000.0))
+        big = (num_atoms >= 50).tolist()
+        n_big_cost = float(cost[num_atoms >= 50].sum())
+        cap0 = float(cost.sum()) / world_size
+        n_big_bins = max(1, -(-int(n_big_cost * 1000) // int(cap0 * (1.0 - big_discount) * 1000))) if n_big_cost > 0 else 0
+        # the other ranks share what the big-ligand ranks leave
+        cap_small = (float(cost.sum()) - n_big_bins * cap0 * (1.0 - big_discount)) / max(world_size - n_big_bins, 1) if n_big_bins < world_size else cap0
+        caps = [cap0 * (1.0 - big_discount) if i < n_big_bins else cap_small for i in range(world_size)]
+        rest = []
+        for g in order.tolist():
+            r = next((i for i in range(world_size) if load[i] + float(cost[g]) <= caps[i] * (1.0 + slack) and (not big[g] or i < max(n_big_bins, 1))), None)
+            if r is None:
+                rest.append(g)
+                continue
+            parts[r].append(g)
+            load[r] += float(cost[g])
+        order = torch.tensor(rest, dtype=torch.long)
+        load = [l / c * cap0 for l, c in zip(load, caps)]          # (the leftovers level the ranks relative to their capacities)
     for g in order.tolist():
         r = min(range(world_size), key=lambda i: (load[i], i))
         parts[r].append(g)
         load[r] += float(cost[g])
+    if by_size and world_size > 1 and len(num_atoms) <= 2048:      # (a large job is level to a fraction of a per cent already)
+        # level what first-fit left: move one graph at a time from the fullest rank (relative to its capacity) to the emptiest while that
+        # lowers the maximum; a 50+-atom ligand never moves to a rank that has none
+        cl = cost.tolist()
+        tot = [sum(cl[g] for g in parts[i]) for i in range(world_size)]
+        rel = lambda i: tot[i] / caps[i]
+        for _ in range(64):
+            hi = max(range(world_size), key=rel)
+            lo = min(range(world_size), key=rel)
+            gap = rel(hi) - rel(lo)
+            best = None
+            ok = lambda g, dst: not (big[g] and dst >= max(n_big_bins, 1))
+            for g in parts[hi]:                            # a move (h = None) or a swap g <-> h
+                for h in [None] + parts[lo]:
+                    if not ok(g, lo) or (h is not None and not ok(h, hi)):
+                        continue
+                    c = cl[g] - (cl[h] if h is not None else 0.0)
+                    a, b = rel(hi) - c / caps[hi], rel(lo) + c / caps[lo]
+                    new_gap = abs(a - b)
+                    if c > 0 and new_gap < gap - 1e-12 and (best is None or new_gap < best[0]):
+                        best = (new_gap, g, h)
+            if best is None:
+                break
+            parts[hi].remove(best[1])
+            parts[lo].append(best[1])
+            tot[hi] -= cl[best[1]]
+            tot[lo] += cl[best[1]]
+            if best[2] is not None:
+                parts[lo].remove(best[2])
+                parts[hi].append(best[2])
+                tot[lo] -= cl[best[2]]
+                tot[hi] += cl[best[2]]
     return [torch.tensor(sorted(p), dtype=torch.long) for p in parts]
 
 

@@ -482,19 +482,31 @@ def test_plan_matches_is_safe_for_inference_tensors_and_recycled_storage():
 
 
 def test_partition_balances_the_fitted_step_cost():
-    """parallel.partition_graphs: longest-processing-time greedy on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p).  The
-    heaviest rank stays within one graph of the mean (the LPT bound), every graph lands on exactly one rank, and on a batch whose
+    """parallel.partition_graphs on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p).  Every graph lands on exactly one rank; plain LPT
+    (by_size=False) keeps the heaviest rank within one graph of the mean; the default groups the largest ligands on the first ranks (the
+    attention kernels are instantiated for the row tiles of a batch's largest ligand: ligands of 50+ atoms then do not put EVERY rank on the
+    4-tile kernels) and gives the ranks that hold them up to 5 % less than their share, the others correspondingly more; on a batch whose
     pharmacophore sizes are skewed against the atom counts the fitted cost balances better than n^3 alone does."""
     from phoregen_amd.parallel import COST_US, graph_cost, partition_graphs
     g = torch.Generator().manual_seed(5)
-    for B, world in ((128, 8), (128, 3), (37, 4), (5, 8)):
+    for B, world in ((128, 8), (128, 3), (37, 4), (5, 8), (128, 1)):
         na = (40 + 6 * torch.randn(B, generator=g)).round().clamp(20, 60).long()
         nph = (107 + 30 * torch.randn(B, generator=g)).round().clamp(23, 203).long()
         cost = graph_cost(na, nph)
-        parts = partition_graphs(na, world, nph)
-        assert sorted(torch.cat(parts).tolist()) == list(range(B)) and all(bool((p[1:] > p[:-1]).all()) for p in parts if p.numel() > 1)
-        loads = torch.stack([cost[p].sum() for p in parts])
-        assert float(loads.max()) <= float(cost.sum()) / world + float(cost.max()) + 1e-9
+        mean = float(cost.sum()) / world
+        for by_size in (False, True):
+            parts = partition_graphs(na, world, nph, by_size=by_size)
+            assert sorted(torch.cat(parts).tolist()) == list(range(B)) and all(bool((p[1:] > p[:-1]).all()) for p in parts if p.numel() > 1)
+            loads = torch.stack([cost[p].sum() if p.numel() else cost.new_zeros(()) for p in parts])
+            assert float(loads.max()) <= mean * (1.06 if by_size else 1.0) + float(cost.max()) + 1e-9
+        if B == 128 and world == 8:
+            parts = partition_graphs(na, world, nph)                       # default: by size
+            with_big = [r for r, p in enumerate(parts) if int(na[p].max()) >= 50]
+            assert with_big and with_big == list(range(len(with_big))) and len(with_big) <= 3       # the 50+-atom ligands sit together on the first ranks
+            lpt_big = [r for r, p in enumerate(partition_graphs(na, world, nph, by_size=False)) if int(na[p].max()) >= 50]
+            assert len(lpt_big) > len(with_big)
+            loads = torch.stack([cost[p].sum() for p in parts])
+            assert float(loads[with_big].max()) <= mean * 0.96 and float(loads.max()) <= mean * 1.05
     # the model's terms are the ones the kernels scale with: tiles of the triplet kernel, bond edges, context nodes
     one = graph_cost(torch.tensor([40]), torch.tensor([107]))
     assert abs(float(one) - (COST_US['tile'] * 3 * 40 * 39 + COST_US['bond'] * 40 * 39 + COST_US['node'] * 147)) < 1e-9
@@ -503,7 +515,7 @@ def test_partition_balances_the_fitted_step_cost():
     nph = torch.tensor([203] * 8 + [23] * 8)
     cost = graph_cost(na, nph)
     worst = lambda parts: max(float(cost[p].sum()) for p in parts)
-    assert worst(partition_graphs(na, 4, nph)) <= worst(partition_graphs(na, 4))
+    assert worst(partition_graphs(na, 4, nph, by_size=False)) <= worst(partition_graphs(na, 4, by_size=False))
 
 
 def test_triplet_adjoint_atom_order_is_a_balanced_permutation():

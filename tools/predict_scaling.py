@@ -1,0 +1,50 @@
+"""Strong-scaling prediction from ONE GPU: the headline batch is partitioned exactly as `bench.py --gpus N` does (parallel.partition_graphs
+on the fitted step cost), every rank's share is run here one after the other, and the slowest share sets the N-GPU step time (the ranks
+do not communicate inside the loop).  Prints per N: graphs / cost / ms per step of every share, predicted speed-up = T(128 graphs) / max."""
+import json, sys, time, torch
+sys.path.insert(0, '/root/repo')
+from bench import ligphore_workload, subset_workload
+from phoregen_amd.config import default_model_config
+from phoregen_amd.models.diffusion import PhoreDiff
+from phoregen_amd.parallel import graph_cost, partition_graphs
+from phoregen_amd.weights import init_deterministic_
+
+model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to('cuda')
+full = ligphore_workload(128, seed=1234)
+W, K = 6, 30
+
+
+def ms_per_step(work, gids):
+    G = int(work['num_atoms'].numel())
+    st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm'], work['batch_phore'], work['num_atoms'],
+                              torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + 3 * K, graph_ids=gids)
+    for i in range(W):
+        model.reverse_step(st, i, 999 - i)
+    ts = []
+    for r in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(W + r * K, W + (r + 1) * K):
+            model.reverse_step(st, i, 999 - i)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / K * 1e3)
+    return sorted(ts)[1]
+
+
+t_full = ms_per_step(full, torch.arange(128))
+cost = graph_cost(full['num_atoms'], full['n_phore'])
+out = {'ms_128_graphs': t_full, 'by_world': {}}
+print(f'128 graphs on one GPU: {t_full:.3f} ms/step')
+modes = [m == 'by_size' for m in (sys.argv[1:] or ['lpt', 'by_size'])]
+for by_size, world in [(b, w) for b in modes for w in (2, 4, 8)]:
+    parts = partition_graphs(full['num_atoms'], world, full['n_phore'], by_size=by_size)
+    rows = []
+    for r, ids in enumerate(parts):
+        ms = ms_per_step(subset_workload(full, ids), ids)
+        rows.append(dict(rank=r, graphs=int(ids.numel()), cost=float(cost[ids].sum()), ms=ms))
+    worst = max(x['ms'] for x in rows)
+    out['by_world'][f"{'by_size' if by_size else 'lpt'}_{world}"] = dict(shares=rows, slowest_ms=worst, predicted_speedup=t_full / worst,
+                                  cost_max_over_mean=max(x['cost'] for x in rows) / (sum(x['cost'] for x in rows) / world))
+    print(f"{'by_size' if by_size else 'lpt':8s} N = {world}: shares " + ', '.join(f"{x['graphs']}g {x['ms']:.3f}" for x in rows) +
+          f' -> slowest {worst:.3f} ms, predicted {t_full / worst:.2f} x (cost max/mean {max(x["cost"] for x in rows) / (sum(x["cost"] for x in rows) / world):.3f})')
+print(json.dumps(out))
