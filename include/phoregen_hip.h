@@ -28,6 +28,15 @@ extern "C" {
 const char* pg_last_error(void);
 int pg_abi_version(void);
 
+/* ---- order points between the HIP streams one denoiser step is spread over (phoregen_amd/engine.py; the reference has no
+ * counterpart: it runs on one torch stream).  An event without timestamp and without the system-scope fence of a default HIP
+ * event: it orders kernels of ONE device against each other (each kernel ends with its own device-scope release), it does not
+ * make results visible to the host -- callers synchronise the stream itself for that. */
+int pg_order_point_create(void** ev);
+int pg_order_point_destroy(void* ev);
+int pg_order_point_record(void* ev, void* stream);
+int pg_order_point_wait(void* ev, void* stream);          /* `stream` continues after the last record of `ev` */
+
 /* ---- MFMA lane-map self test (device writes 0 on success) -------------------------------- */
 int pg_selftest_mfma(int* d_result, void* stream);
 /* ---- raw words of the device generator (Philox4x32-10, Salmon et al. SC'11) for known-answer tests:

@@ -41,6 +41,20 @@ def _f(*shape, device, zero=False):
     return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=device)
 
 
+class _TorchPoint:
+    """torch.cuda.Event behind the two calls of hip.OrderPoint."""
+    __slots__ = ('ev',)
+
+    def __init__(self):
+        self.ev = torch.cuda.Event()
+
+    def record(self, stream):
+        self.ev.record(stream)
+
+    def wait(self, stream):
+        stream.wait_event(self.ev)
+
+
 class Engine:
     def __init__(self, pack: ModelPack, plan, knn_k=32, full=True, phore_only=False):
         self.lib = hip.lib()
@@ -66,6 +80,9 @@ class Engine:
         # the next layer's first-layer blocks, triplet queries and bond-node rows (everything in front of its triplet kernel that does
         # not depend on the new coordinates) run on lane 2 during this layer's position updates
         self.layer_ahead = o['layer_ahead']
+        # cross-lane order points without the host-visibility fence of a default event (hip.OrderPoint; tools/micro/stream_packets.py)
+        self.order_points = o['order_points'] and not o['graph']
+        self.geom_split = o['geom_split'] == 'always' or (o['geom_split'] == 'auto' and self.plan.n_bond < o['geom_split_below'])
         self.small_below = o['small_below']
         # (hipGraph capture of the v2 launch list segfaults inside the runtime -- lanes 2 / 3 wait on lane 1 there while lane 1 waits on
         #  lane 3; the replay variant, off by default and measured slower, keeps the previous list)
@@ -114,6 +131,7 @@ class Engine:
         w.deg = torch.zeros(n, dtype=torch.int32, device=d)
         w.ew, w.nrm, w.G = _f(n, k, device=d), _f(n, 3, device=d), _f(E, 20, device=d)
         w.Y1, w.Y2 = _f(n, 1920, device=d), _f(n, 1280, device=d)
+        w.Y1b = None                      # second first-layer buffer of the `ahead_v2` schedule (allocated by the program builder)
         # per concurrent chain: 0 knn, 1 bond, 2 the bond-node sub-layer launched one layer ahead, 3 (q only) the knn-node query ahead
         w.q = [_f(n, 128, device=d) for _ in range(4)]
         w.U, w.S = [_f(n, 2048, device=d) for _ in range(3)], [_f(n, 2048, device=d) for _ in range(3)]
@@ -134,6 +152,12 @@ class Engine:
         assert len(args) + 1 == len(fn.argtypes), (fn.__name__, len(args) + 1, len(fn.argtypes))
         prog.append((fn, args, self._lane if self.multi_stream else 0))
 
+    def _point(self):
+        """A new cross-lane order point: the library's fence-free event, or a torch event (option `order_points` off; hipGraph capture)."""
+        if self.order_points:
+            return hip.OrderPoint()
+        return _TorchPoint()
+
     def _fork(self, prog, lanes):
         """Side lanes start after everything enqueued so far on lane 0."""
         if not self.multi_stream:
@@ -142,10 +166,10 @@ class Engine:
                                                     # wait refers to the record that precedes it, so re-use across steps is safe)
         def tap(streams):
             if not evs:
-                evs.append(torch.cuda.Event())
+                evs.append(self._point())
             evs[0].record(streams[0])
             for l in lanes:
-                streams[l].wait_event(evs[0])
+                evs[0].wait(streams[l])
             return 0
         tap.__name__ = 'fork'
         prog.append((tap, None, -1))
@@ -157,10 +181,10 @@ class Engine:
         evs = []
         def tap(streams):
             if not evs:
-                evs.extend(torch.cuda.Event() for _ in lanes)
+                evs.extend(self._point() for _ in lanes)
             for ev, l in zip(evs, lanes):
                 ev.record(streams[l])
-                streams[0].wait_event(ev)
+                ev.wait(streams[0])
             return 0
         tap.__name__ = 'join'
         prog.append((tap, None, -1))
@@ -172,10 +196,10 @@ class Engine:
         evs = []
         def tap(streams):
             if not evs:
-                evs.extend(torch.cuda.Event() for _ in on)
+                evs.extend(self._point() for _ in on)
             for ev, l in zip(evs, on):
                 ev.record(streams[l])
-                streams[waiter].wait_event(ev)
+                ev.wait(streams[waiter])
             return 0
         tap.__name__ = 'sync'
         prog.append((tap, None, -1))
@@ -186,7 +210,7 @@ class Engine:
         if self.multi_stream:
             def tap(streams):
                 if not evs:
-                    evs.append(torch.cuda.Event())
+                    evs.append(self._point())
                 evs[0].record(streams[lane])
                 return 0
             tap.__name__ = 'record'
@@ -197,7 +221,7 @@ class Engine:
         if not self.multi_stream:
             return
         def tap(streams):
-            streams[waiter].wait_event(evs[0])
+            evs[0].wait(streams[waiter])
             return 0
         tap.__name__ = 'wait'
         prog.append((tap, None, -1))
@@ -416,25 +440,41 @@ class Engine:
         # 224 and the merged knn launch; 48 graphs equal either way, from 64 graphs up the full grid is fastest)
         tri_grid = self.tri_grid if self.tri_grid >= 0 else ((192 if E < 30000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
 
-        def first_layer_gemm(L, h_in):
+        if v2 and w.Y1b is None:
+            w.Y1b = torch.empty_like(w.Y1)
+        # v2: the layer's closing launch (x' = x + dx, and the next layer's geometry from x') once per chain -- on lane 0 for the bond
+        # chain (x', bond smearing), on lane 1 for the node chain (its own copy of x', direction vectors) -- so that neither chain waits
+        # for a launch on the other's lane: each waits for the other's position update only.  The two copies of x' are the same
+        # expression of the same operands.
+        split = v2 and self.fused_geom and self.geom_split
+        if split and getattr(w, 'x_node', None) is None:
+            w.x_node = [torch.empty_like(x[0]), torch.empty_like(x[0])]
+            w.dxe2 = torch.zeros_like(w.dxe)
+
+        def first_layer_gemm(L, h_in, Y1):
             # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
             # (ligand atoms: targets and sources of bond edges)
             if self.row_subsets:
-                self._gemm(prog, h_in, 128, L.W_node1[:640], w.Y1[:, :640], n, 640, bias=L.b_node1[:640])
-                self._gemm(prog, h_in, 128, L.W_node1[640:], w.Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
+                self._gemm(prog, h_in, 128, L.W_node1[:640], Y1[:, :640], n, 640, bias=L.b_node1[:640])
+                self._gemm(prog, h_in, 128, L.W_node1[640:], Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
             else:
-                self._gemm(prog, h_in, 128, L.W_node1, w.Y1, n, 1920, bias=L.b_node1)
+                self._gemm(prog, h_in, 128, L.W_node1, Y1, n, 1920, bias=L.b_node1)
 
-        def triplet_queries(L, hb_in):
-            self._gemm(prog, hb_in, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=w.Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
+        def triplet_queries(L, hb_in, Y1):
+            self._gemm(prog, hb_in, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
             self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b), scale=HEAD_SCALE)
 
-        def bond_node_rows(L, hb_in):
-            self._gemm(prog, hb_in, 128, L.NB.W_hb, w.CsB2, E, 256, add1=w.Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
+        def bond_node_rows(L, hb_in, Y1):
+            self._gemm(prog, hb_in, 128, L.NB.W_hb, w.CsB2, E, 256, add1=Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
 
         for li, L in enumerate(pk.layers):
             nxt = 1 - cur
             hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
+            # v2 writes the next layer's first-layer blocks while this layer's are still being read: two buffers, alternating (the
+            # other schedules overwrite in place, behind the last reader)
+            Y1c, Y1n = (w.Y1, w.Y1) if not v2 else ((w.Y1, w.Y1b) if li % 2 == 0 else (w.Y1b, w.Y1))
+            xc1 = w.x_node[cur] if (split and li > 0) else xc      # the node chain's coordinates
+            dxe = w.dxe2 if (split and li % 2) else w.dxe           # (alternating: lane 1 writes the next while lane 0's closing launch may read this one)
             pre = ahead and li > 0            # Y1, the triplet queries and the bond-node rows of this layer were launched by the previous one
             if self.fused_geom:
                 # direction vectors and bond-length smearing of this layer came with the previous layer's coordinate update (ONE
@@ -452,15 +492,18 @@ class Engine:
                 self._lane = 3
                 self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
                 self._lane = 0
-            if pre:
-                # lane 2 carried this layer's triplet queries through the previous layer's position updates (v2: behind a wait for its
-                # first-layer blocks, which lane 1 wrote: one wait on lane 2 covers both)
+            if pre and not v2:
+                # lane 2 carried this layer's first-layer blocks and triplet queries through the previous layer's position updates
                 self._sync(prog, 0, (2,))
-            else:
-                first_layer_gemm(L, hc)
+            elif not pre:
+                first_layer_gemm(L, hc, Y1c)
             if li == 0 and pre_join:
                 self._join(prog, pre_join)
-            self._fork(prog, (1, 2, 3))
+            # (v2 from layer 1 on: lanes 2 / 3 have nothing in the first half of the layer, only the node chain's lane is released here)
+            if not (pre and split):                # (split: lane 1 went on behind its own closing launch)
+                self._fork(prog, (1,) if (pre and v2) else (1, 2, 3))
+            # (v2: this layer's first-layer blocks came from lane 1 behind the previous layer's Y2, which lane 0 has joined since; the
+            #  triplet queries on lane 2 are waited for in front of the triplet kernel, not in front of P)
             if not self.fused_geom:
                 self._sync(prog, 0, (3,))              # the smearing (alone on lane 3 so far) is read by P on lane 0
                 self._sync(prog, 2, (3,))              # ... and by the Q rows on lane 2; the queries on lane 3 do not wait for it
@@ -475,19 +518,19 @@ class Engine:
             # per product; the gather kernel builds Q in-kernel and keeps it on P)
             self._lane = 0
             self._gemm(prog, hbc, 128, L.TB.W_hbg, w.P, E, 256, X2=w.G, K2=20,
-                       add1=w.Y1[:, 10 * 128:12 * 128], idx1=p.bond_src,
-                       **({} if staged else dict(add2=w.Y1[:, 12 * 128:14 * 128], idx2=p.bond_dst)))
+                       add1=Y1c[:, 10 * 128:12 * 128], idx1=p.bond_src,
+                       **({} if staged else dict(add2=Y1c[:, 12 * 128:14 * 128], idx2=p.bond_dst)))
             # the per-segment constant of the triplet MLPs as rows: Wg2 . smear(d_ji) + (target half)[j].  Small batches: behind P on
             # lane 0 (a 25 us product costs less there than the two cross-lane hops around it on a side lane)
             q_lane = 0 if (chain_q and self.fused_geom) else 2
             self._lane = q_lane
             if staged:
-                self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=w.Y1[:, 12 * 128:14 * 128], idx1=p.bond_src)
+                self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=Y1c[:, 12 * 128:14 * 128], idx1=p.bond_src)
                 if q_lane != 0:
                     self._sync(prog, 0, (2,))          # lane 0 (the triplet kernel) waits for the Q rows, not for all of lane 2
             if not pre:
                 self._lane = 3                                                          # triplet queries
-                triplet_queries(L, hbc)
+                triplet_queries(L, hbc, Y1c)
                 q3_done = self._record(prog, 3)
             self._lane = 0
             if not pre:                            # (pre: lane 3 carries the bond-node attention, which lin_node waits for)
@@ -495,8 +538,8 @@ class Engine:
                     self._wait(prog, 0, q3_done)   # (lane 3 goes on with the bond-node attention: not joined)
                 else:
                     self._join(prog, (3,))
-            if v2:
-                before_tri = self._record(prog, 0) # every reader of this layer's Y1 on lanes 0 / 2 / 3 (but the bond-node attention) is in front of this
+            if pre and v2:
+                self._sync(prog, 0, (2,))          # this layer's triplet queries (lane 2, launched one layer ahead)
             a = L.TB
             self._event(prog, 'triplet', True)
             self.tri_calls.append(len(prog))
@@ -515,18 +558,18 @@ class Engine:
             #  updates, see below)
             self._lane = 3 if v2 else 2            # (v2: lane 1 then never waits on lane 2, so lane 2 may wait on lane 1 -- the other
             if not pre:                            #  order of the two edges breaks hipGraph capture)
-                bond_node_rows(L, hbc)
-                self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=1)
+                bond_node_rows(L, hbc, Y1c)
+                self._node_attention(prog, hip.SEG_BOND_NODE, L.NB, Y1c, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=1)
                 if v2:
                     bn_done = self._record(prog, 3)
             # ---- node update over knn edges (:281), then h' = h + lin_node(aggE + aggB) (:288)   [lane 1]
             self._lane = 1
             if not pre:
-                self._query_gemm(prog, L.NE, w.Y1, 0, both, 0)
+                self._query_gemm(prog, L.NE, Y1c, 0, both, 0)
             if pre and v2:
                 self._wait(prog, 1, ne_done)           # this layer's knn-node query (lane 3, launched one layer ahead)
             self._event(prog, 'knn_node', True)       # (the launches of the sub-layer: ligand targets, pharmacophore targets)
-            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, w.Y1, 0, xc, both, out=w.aggE, buf=0, query_done=True,
+            self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, Y1c, 0, xc1, both, out=w.aggE, buf=0, query_done=True,
                                  qbuf=3 if pre else None)
             self._event(prog, 'knn_node', False)
             if pre or v2:
@@ -555,10 +598,10 @@ class Engine:
             if v2 and more_ahead:
                 # h' is final and Y2 is out: the next layer's first-layer blocks follow on lane 1 (beside the triplet kernel / the bond
                 # position update), so that the position phase's side lanes start with the triplet queries right away and the next P
-                # waits for these blocks only.  Readers of this layer's Y1 on the other lanes are all in front of `before_tri`.
+                # waits for these blocks only.  They go to the OTHER first-layer buffer: its last readers belong to the previous layer,
+                # and lane 1 has waited for every one of them since (layer-start fork, ne_done, bn_done)
                 self._lane = 1
-                self._wait(prog, 1, before_tri)
-                first_layer_gemm(pk.layers[li + 1], hn)
+                first_layer_gemm(pk.layers[li + 1], hn, Y1n)
                 y1_done = self._record(prog, 1)
             # the bond position update's query MLP runs beside its edge product / the knn position update, not in front of the
             # attention on lane 0: lane 3 is free after the triplet queries (last layer: lane 2, in front of the node head --
@@ -584,34 +627,42 @@ class Engine:
                 if v2:
                     self._wait(prog, 2, y1_done)
                 else:
-                    first_layer_gemm(Ln, hn)
+                    first_layer_gemm(Ln, hn, Y1n)
                     y1_done = self._record(prog, 2)
-                triplet_queries(Ln, hbn)
+                triplet_queries(Ln, hbn, Y1n)
                 if not v2:
-                    self._query_gemm(prog, Ln.NE, w.Y1, 0, both, 3)
+                    self._query_gemm(prog, Ln.NE, Y1n, 0, both, 3)
                 self._lane = 3
                 self._wait(prog, 3, y1_done)
                 if v2:
-                    self._query_gemm(prog, Ln.NE, w.Y1, 0, both, 3)
+                    self._query_gemm(prog, Ln.NE, Y1n, 0, both, 3)
                     ne_done = self._record(prog, 3)
-                bond_node_rows(Ln, hbn)
-                self._node_attention(prog, hip.SEG_BOND_NODE, Ln.NB, w.Y1, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=2)
+                bond_node_rows(Ln, hbn, Y1n)
+                self._node_attention(prog, hip.SEG_BOND_NODE, Ln.NB, Y1n, 5 * 128, xc, lig, out=w.aggB, csrc=w.CsB2, buf=2)
                 bn_done = self._record(prog, 3)
             self._lane = 1
-            self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc, lig, dx=w.dxe, buf=0)
+            self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc1, lig, dx=dxe, buf=0)
             self._lane = 0
             self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
             if not v2:
                 self._wait(prog, 0, q_done)
             self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1, query_done=True)
+            more = li + 1 < n_layers
+            if split and more:
+                bp_done = self._record(prog, 0)
             self._join(prog, (1,))
             if self.fused_geom:      # x' = x + dx, and from x' the next layer's smearing + direction vectors (last layer: the update alone)
-                more = li + 1 < n_layers
-                self._call(prog, lib.pg_layer_geom, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), w.nrm_phore_ctx.data_ptr(),
-                           xn.data_ptr(), w.nrm.data_ptr() if more else None, w.G.data_ptr() if more else None)
+                self._call(prog, lib.pg_layer_geom, t, xc.data_ptr(), dxe.data_ptr(), w.dxb.data_ptr(), w.nrm_phore_ctx.data_ptr(),
+                           xn.data_ptr(), w.nrm.data_ptr() if (more and not split) else None, w.G.data_ptr() if more else None)
+                if split and more:
+                    self._lane = 1
+                    self._wait(prog, 1, bp_done)
+                    self._call(prog, lib.pg_layer_geom, t, xc1.data_ptr(), dxe.data_ptr(), w.dxb.data_ptr(), w.nrm_phore_ctx.data_ptr(),
+                               w.x_node[nxt].data_ptr(), w.nrm.data_ptr(), None)
+                    self._lane = 0
             else:
-                self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), w.dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
-            self._mark(prog, f'L{li}', hn, hbn, xn, w.dxe, w.dxb, hbc)
+                self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
+            self._mark(prog, f'L{li}', hn, hbn, xn, dxe, w.dxb, hbc)
             cur = nxt
         if heads is not None:
             self._join(prog, (2, 3))

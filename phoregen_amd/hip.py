@@ -67,6 +67,10 @@ _lib = None
 _PROTOS = {
     'pg_last_error': (C.c_char_p, []),
     'pg_abi_version': (C.c_int, []),
+    'pg_order_point_create': (C.c_int, [C.POINTER(C.c_void_p)]),
+    'pg_order_point_destroy': (C.c_int, [C.c_void_p]),
+    'pg_order_point_record': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pg_order_point_wait': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pg_selftest_mfma': (C.c_int, [c_ip, C.c_void_p]),
     'pg_selftest_philox': (C.c_int, [c_ip, C.c_int, c_ip, C.c_void_p]),
     'pg_debug_force_generic_seg': (C.c_int, [C.c_int]),
@@ -142,6 +146,30 @@ def lib():
         raise RuntimeError('phoregen_amd: no MI355X / ROCm device visible; the HIP path has no CPU fallback.')
     _gpu_checked = True
     return l
+
+
+class OrderPoint:
+    """A point of one stream that other streams of the same device can wait for (pg_order_point_*: a HIP event without timestamp
+    and without the host-visibility fence).  Same two calls as torch.cuda.Event, so the engine can take either."""
+    __slots__ = ('h', '_lib')
+
+    def __init__(self):
+        self._lib = lib()
+        self.h = C.c_void_p()
+        check(self._lib.pg_order_point_create(C.byref(self.h)), 'pg_order_point_create')
+
+    def record(self, stream):
+        if self._lib.pg_order_point_record(self.h, stream.cuda_stream):
+            check(1, 'pg_order_point_record')
+
+    def wait(self, stream):
+        if self._lib.pg_order_point_wait(self.h, stream.cuda_stream):
+            check(1, 'pg_order_point_wait')
+
+    def __del__(self):
+        if self.h:
+            self._lib.pg_order_point_destroy(self.h)
+            self.h = None
 
 
 def check(rc, what=''):

@@ -831,6 +831,11 @@ def test_engine_variants_agree(model):
     assert all(torch.equal(a, b) for a, b in zip(base, run(pos_tiled='always')))
     assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='never')))     # the placement of the work launched one layer ahead used for large batches
     assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='always')))
+    # the layer's closing launch once per chain (tiny batches) or once on the bond chain's lane: x' is the same expression either way
+    assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='always', geom_split='always')))
+    assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='always', geom_split='never')))
+    # cross-lane order points as torch events (with the host-visibility fence) instead of the library's fence-free ones
+    assert all(torch.equal(a, b) for a, b in zip(base, run(order_points=False)))
     layer_by_layer = run(layer_ahead=False)     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
     assert all(torch.equal(a, b) for a, b in zip(base, layer_by_layer))
     for grid in (0, 96, 200):                   # persistent triplet workgroups (small batches leave CUs to the side lanes):
