@@ -156,9 +156,28 @@ struct BwdLds {
 
 }  // namespace
 
-template <int MODE, int NW, bool OP = false>   // OP: one pass, alpha / S of the forward given (triplet training form)
+// SPLIT (one-pass forms of the feature modes only): the key path and the value path of a segment as two launches, so that a wave
+// holds ONE path's operands, accumulators and tiles -- half the registers and, for the triplet rows, half the LDS: 8 waves per
+// workgroup = two per SIMD instead of one, and the dependent chain of a wave (~170 MFMA + ~1 500 VALU / LDS instructions per tile
+// and path) overlaps with another wave's.  SPLIT = 1, the value pass, runs first: it needs nothing of the key path and leaves
+// d logit [segment][row][16] (PgSegAttnGrad.dlogit) and its d feat rows (PgSegAttnGrad.gfeat_v) for SPLIT = 2, the key pass,
+// which adds the two d feat parts and runs the geometry adjoint once.  SPLIT = 0: both paths in one wave (every other form).
+template <int MODE, int NW, bool OP = false, int SPLIT = 0>   // OP: one pass, alpha / S of the forward given (triplet training form)
 __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAttn p, PgSegAttnGrad gr PG_ABL_PARAM) {
   using T = ModeTraits<MODE>;
+  // An opaque kernel-uniform zero.  The d feat and d Wf products of a tile sit behind `if (live)` tests of it: always taken, but
+  // the instruction scheduler cannot move their MFMA chains across the test and interleave them with the LayerNorm adjoint in
+  // front and the scatter behind (which it does otherwise, at the price of longer live ranges everywhere).  Measured, same box,
+  // same sources: knn-node adjoint 2.25 -> 1.91 ms per launch, its key pass 1.22 -> 1.04, the triplet key pass 5.09 -> 4.13
+  // (profiles/r04_adjoint_codegen_fences.txt).
+  // The one-wave triplet form is the exception (7.19 -> 7.34 ms with the tests): it keeps plain code.
+  constexpr bool FENCED = T::KNN || SPLIT != 0;
+  int opq_zero = 0;
+  asm volatile("" : "+s"(opq_zero));
+  const bool live = FENCED ? opq_zero == 0 : true;
+  static_assert(SPLIT == 0 || (OP && !T::POS), "the split form exists for the one-pass feature modes");
+  constexpr bool DO_K = SPLIT != 1, DO_V = SPLIT != 2;
+  constexpr int NPATH = SPLIT ? 1 : 2, ACCW = SPLIT ? 128 : 256;
   constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
   constexpr int FS = 16 * NF + 1;
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;       // per-wave floats
@@ -169,14 +188,14 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   BwdLds L;
   {
     float* q = lds_raw;
-    L.wf_k = q; q += NSTEP * 512;
-    L.wf_v = q; q += NSTEP * 512;
+    L.wf_k = q; if (DO_K) q += NSTEP * 512;
+    L.wf_v = q; if (DO_V) q += NSTEP * 512;
     L.bk = q; q += 128;
     L.bv = q; q += 128;
-    L.accP = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * 256;   // triplet: d P[k -> j] of the workgroup's source atom
+    L.accP = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * ACCW;  // triplet: d P[k -> j] of the workgroup's source atom
     L.accX = q; if (T::TRI) q += (size_t)((t.max_nlig + 15) & ~15) * 3;     // triplet: d x_k of the workgroup's graph rows
-    L.wfp_k = q; if (NFT == 1) q += 128 * 17;                  // Wf[c][f] (stride 17) for d feat = Wf^T . d hidden
-    L.wfp_v = q; if (NFT == 1) q += 128 * 17;
+    L.wfp_k = q; if (NFT == 1 && DO_K) q += 128 * 17;          // Wf[c][f] (stride 17) for d feat = Wf^T . d hidden
+    L.wfp_v = q; if (NFT == 1 && DO_V) q += 128 * 17;
     q += wave * PW;
     L.sT = q; q += 128 * 17;
     L.sF = q; q += 16 * FS;
@@ -186,15 +205,16 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     L.sC = q;
   }
   for (int i = tid; i < NSTEP * 512; i += blockDim.x) {
-    L.wf_k[i] = p.Wf_k[i]; L.wf_v[i] = p.Wf_v[i];
+    if (DO_K) L.wf_k[i] = p.Wf_k[i];
+    if (DO_V) L.wf_v[i] = p.Wf_v[i];
   }
   for (int i = tid; i < 128; i += blockDim.x) { L.bk[i] = p.ln_bk[i]; L.bv[i] = p.ln_bv[i]; }
   if constexpr (NFT == 1) {
     for (int i = tid; i < 128 * 16; i += blockDim.x) {
       const int c = i >> 4, f = i & 15;
       const int src = ((f >> 2) * 8 + (c >> 4)) * 64 + (f & 3) * 16 + (c & 15);
-      L.wfp_k[c * 17 + f] = f < F ? p.Wf_k[src] : 0.f;
-      L.wfp_v[c * 17 + f] = f < F ? p.Wf_v[src] : 0.f;
+      if (DO_K) L.wfp_k[c * 17 + f] = f < F ? p.Wf_k[src] : 0.f;
+      if (DO_V) L.wfp_v[c * 17 + f] = f < F ? p.Wf_v[src] : 0.f;
     }
   }
   for (int i = lane; i < 16 * FS; i += 64) { L.sF[i] = 0.f; L.sGF[i] = 0.f; }
@@ -209,9 +229,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
 #pragma unroll
   for (int tq = 0; tq < 8; ++tq) gw2_acc[tq] = (f4){0.f, 0.f, 0.f, 0.f};
   float gbk0 = 0.f, gbk1 = 0.f, gbv0 = 0.f, gbv1 = 0.f;        // d b'[lane], d b'[lane + 64] of the two paths
-  f4 gwf_acc[2][NF][8];                                        // d Wf: [path][f tile][tau] -> (c = 16 tau + 4g + r, f = 16 ft + m)
+  f4 gwf_acc[NPATH][NF][8];                                    // d Wf: [path][f tile][tau] -> (c = 16 tau + 4g + r, f = 16 ft + m)
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NPATH; ++a)
 #pragma unroll
     for (int ft = 0; ft < NF; ++ft)
 #pragma unroll
@@ -226,14 +246,14 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     constexpr int CPW = 128 / NW, GROUPS = 64 / CPW, RPL = 16 / GROUPS;   // channels per wave, lane groups, rows per lane
     __syncthreads();
     const int cc = CPW * wave + (lane % CPW), grp = lane / CPW;
-    float* ap = L.accP + (size_t)(tile * 16 + RPL * grp) * 256 + (kp ? 0 : 128) + cc;
+    float* ap = L.accP + (size_t)(tile * 16 + RPL * grp) * ACCW + ((SPLIT || kp) ? 0 : 128) + cc;
     const float* st0 = L.sT - wave * PW + cc * 17 + RPL * grp;      // wave 0's tile, this lane's channel / row block
 #pragma unroll
     for (int rr = 0; rr < RPL; ++rr) {
       float v = 0.f;
 #pragma unroll
       for (int w2 = 0; w2 < NW; ++w2) v += st0[w2 * PW + rr];
-      ap[rr * 256] += v;
+      ap[rr * ACCW] += v;
     }
     __syncthreads();
   };
@@ -256,7 +276,10 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { Ur[tq][r] = Uk[(tq * 4 + r) * 64]; Mr[tq][r] = Mv[(tq * 4 + r) * 64]; }
+        for (int r = 0; r < 4; ++r) {
+          Ur[tq][r] = DO_K ? Uk[(tq * 4 + r) * 64] : 0.f;
+          Mr[tq][r] = DO_V ? Mv[(tq * 4 + r) * 64] : 0.f;
+        }
     }
     wave_lds_sync();
     const float* const cdk = L.sC + 4 * g;
@@ -402,7 +425,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     // one-pass form: D[h] = sum_r alpha * dalpha = <S[:,h], dS[:,h]> + swn[h] * dswn[h] (S, swn of the forward), alpha read back
     float Dm = 0.f;
     const float* arow = nullptr;
-    if constexpr (OP) {
+    if constexpr (OP && DO_V) {
       const float* Sp = gr.S + (size_t)s.seg * 2048 + lane;
 #pragma unroll
       for (int tq = 0; tq < 8; ++tq)
@@ -411,8 +434,11 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       Dm += __shfl_xor(Dm, 16);
       Dm += __shfl_xor(Dm, 32);
       Dm = fmaf(gr.swn[(size_t)s.seg * 16 + m], gswn_m, Dm);
-      arow = gr.alpha + (size_t)s.seg * gr.alpha_rows * 16;
     }
+    if constexpr (OP) arow = gr.alpha + (size_t)s.seg * gr.alpha_rows * 16;
+    // split form: d logit and the value pass's d feat rows of this segment (same row indexing as alpha)
+    float* const dl_row = SPLIT ? gr.dlogit + (size_t)s.seg * gr.alpha_rows * 16 : nullptr;
+    float* const gfv_row = SPLIT ? gr.gfeat_v + (size_t)s.seg * gr.alpha_rows * (16 * NF) : nullptr;
     // =============================== pass 2: gradients ===============================
     f4 gU[8];
 #pragma unroll
@@ -426,24 +452,38 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       // every global load of the tile is requested up front (the feature arithmetic runs while they are in flight)
       f4 aD_raw = {0.f, 0.f, 0.f, 0.f}, aK_raw = {0.f, 0.f, 0.f, 0.f};
       if constexpr (OP) {
+        // (key pass: d logit of the value pass instead of the softmax weights, same two layouts)
+        const float* const ar = SPLIT == 2 ? dl_row : arow;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = tile * 16 + 4 * g + r;
-          if (row < n_rows) aD_raw[r] = arow[row * 16 + m];
+          if (row < n_rows) aD_raw[r] = ar[row * 16 + m];
         }
-        if (row_m < n_rows) aK_raw = *reinterpret_cast<const f4*>(arow + row_m * 16 + 4 * g);
+        if (row_m < n_rows) aK_raw = *reinterpret_cast<const f4*>(ar + row_m * 16 + 4 * g);
+      }
+      f4 gfv_raw[NF];
+#pragma unroll
+      for (int ft = 0; ft < NF; ++ft) gfv_raw[ft] = (f4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (SPLIT == 2 && NSTEP > 0) {
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tile * 16 + 4 * g + r;
+            if (row < n_rows) gfv_raw[ft][r] = gfv_row[(size_t)row * (16 * NF) + 16 * ft + m];
+          }
       }
       // the Csrc rows of BOTH paths are requested here: with one wave per SIMD each dependent round trip is exposed (the knn
       // forms are out of registers either way -- they spill ~430 / ~570 with or without these 64 -- and are 4 % faster with them)
       constexpr bool PRE = true;
-      f4 pre[2][PRE ? 8 : 1];
+      f4 pre[NPATH][PRE ? 8 : 1];                 // [0] key path, [1] value path; split form: [0] = the pass's own path
       if constexpr (PRE) {
         const float* pk = p.Csrc_k + (size_t)rk.csrc * p.ld_csrc + 4 * g;
         const float* pv = p.Csrc_v + (size_t)rk.csrc * p.ld_csrc + 4 * g;
 #pragma unroll
         for (int tq = 0; tq < 8; ++tq) {
-          pre[0][tq] = rk.valid ? *reinterpret_cast<const f4*>(pk + 16 * tq) : (f4){0.f, 0.f, 0.f, 0.f};
-          pre[1][tq] = rk.valid ? *reinterpret_cast<const f4*>(pv + 16 * tq) : (f4){0.f, 0.f, 0.f, 0.f};
+          if constexpr (DO_K) pre[0][tq] = rk.valid ? *reinterpret_cast<const f4*>(pk + 16 * tq) : (f4){0.f, 0.f, 0.f, 0.f};
+          if constexpr (DO_V) pre[SPLIT ? 0 : 1][tq] = rk.valid ? *reinterpret_cast<const f4*>(pv + 16 * tq) : (f4){0.f, 0.f, 0.f, 0.f};
         }
       }
       float feat[NS];
@@ -468,7 +508,12 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       for (int ft = 0; ft < NF; ++ft) gfeat[ft] = (f4){0.f, 0.f, 0.f, 0.f};
       // row-buffer values of this tile in one batch of loads: rows 4g + r at head m, and row m at heads 4g .. 4g+3
       f4 aD = {0.f, 0.f, 0.f, 0.f}, glD = {0.f, 0.f, 0.f, 0.f}, aK = {0.f, 0.f, 0.f, 0.f}, glK = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (OP) {
+      if constexpr (SPLIT == 2) {
+        glD = aD_raw;
+        glK = aK_raw;
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft) gfeat[ft] = gfv_raw[ft];
+      } else if constexpr (OP) {
         aD = aD_raw;
         aK = aK_raw;
         if constexpr (T::KNN) {            // the knn forward stores alpha x gate
@@ -492,7 +537,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       }
 
 #pragma unroll
-      for (int path = 0; path < (PG_ABL(8) ? 1 : 2); ++path) {
+      for (int path = (SPLIT == 2 ? 1 : 0); path < ((PG_ABL(8) || SPLIT == 1) ? 1 : 2); ++path) {
         const bool kp = OP ? path == 1 : path == 0;
         const float* bp = kp ? L.bk : L.bv;
         const float* wf = kp ? L.wf_k : L.wf_v;
@@ -503,7 +548,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         } else {
           const float* cd = kp ? cdk : cdv;
 #pragma unroll
-          for (int tq = 0; tq < 8; ++tq) hid[tq] = pre[kp ? 0 : 1][tq] + *reinterpret_cast<const f4*>(cd + 16 * tq);
+          for (int tq = 0; tq < 8; ++tq) hid[tq] = pre[SPLIT ? 0 : (kp ? 0 : 1)][tq] + *reinterpret_cast<const f4*>(cd + 16 * tq);
 #pragma unroll
           for (int st = 0; st < NSTEP; ++st)
 #pragma unroll
@@ -520,11 +565,18 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
             for (int r = 0; r < 4; ++r) {
               const float ga = L.sR[32 + 4 * g + r] * fmaf(y[r], __shfl(rs, 4 * g + r), gswn_m);
               glD[r] = LN2 * aD[r] * (ga - Dm);
-              L.sGF[(4 * g + r) * FS + m] = glD[r];
+              if constexpr (SPLIT == 1) {
+                const int row = tile * 16 + 4 * g + r;
+                if (row < n_rows) dl_row[row * 16 + m] = glD[r];       // for the key pass
+              } else {
+                L.sGF[(4 * g + r) * FS + m] = glD[r];
+              }
             }
-            wave_lds_sync();
+            if constexpr (SPLIT != 1) {
+              wave_lds_sync();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) glK[ks] = L.sGF[m * FS + 4 * g + ks];
+              for (int ks = 0; ks < 4; ++ks) glK[ks] = L.sGF[m * FS + 4 * g + ks];
+            }
           }
         }
         // coefficient of y in the loss, rows 4g+r: k path dlogit ; v path cw * alpha
@@ -665,7 +717,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         PROF(8);   // LN adjoint, db', dhidden tile
         if (NSTEP > 0 && !PG_ABL(4)) {
           // d feat[row, f] += sum_c dhidden[c,row] * Wf[c,f]
-          if (!T::PH && !PG_ABL(256)) {
+          if (!T::PH && !PG_ABL(256) && live) {
             f4 gfp[NF][4];                         // independent chains per r, folded below
 #pragma unroll
             for (int ft = 0; ft < NF; ++ft)
@@ -684,7 +736,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           }
           // d Wf[c,f] += sum_row dhidden[c,row] * feat[row,f]
           // registers for the whole kernel (LDS ds_add_f32 accumulation measured ~700 cycles per instruction)
-          if (!PG_ABL(512))
+          if (!PG_ABL(512) && live)
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {           // k-step outermost: consecutive MFMAs hit different accumulators
             float bf[NF];
@@ -694,7 +746,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
             for (int tq = 0; tq < 8; ++tq) {
               const float a = L.sT[(16 * tq + m) * 17 + 4 * g + ks];
 #pragma unroll
-              for (int ft = 0; ft < NF; ++ft) gwf_acc[kp ? 0 : 1][ft][tq] = mfma16(a, bf[ft], gwf_acc[kp ? 0 : 1][ft][tq]);
+              for (int ft = 0; ft < NF; ++ft)
+                gwf_acc[SPLIT ? 0 : (kp ? 0 : 1)][ft][tq] = mfma16(a, bf[ft], gwf_acc[SPLIT ? 0 : (kp ? 0 : 1)][ft][tq]);
             }
           }
         }
@@ -732,7 +785,17 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
         PROF(10);  // scatter
       }  // paths
 
+      if constexpr (SPLIT == 1 && NSTEP > 0) {     // value pass: its d feat rows go to the key pass, which runs the geometry adjoint
+#pragma unroll
+        for (int ft = 0; ft < NF; ++ft)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tile * 16 + 4 * g + r;
+            if (row < n_rows) gfv_row[(size_t)row * (16 * NF) + 16 * ft + m] = gfeat[ft][r];
+          }
+      }
       // ---------------- geometry: d feat -> positions / direction vectors; pos modes: d rel_x ----------------
+      if constexpr (SPLIT != 1) {
       if constexpr ((T::KNN || T::TRI) && NSTEP > 0) {
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft)
@@ -822,12 +885,15 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           }
         }
       }
+      }  // SPLIT != 1
       wave_lds_sync();
       PROF(11);  // geometry
     }  // tiles
 
     // ---------------- per-segment outputs ----------------
-    if constexpr (T::TRI) {
+    if constexpr (SPLIT == 1) {
+      // (value pass: no geometry outputs)
+    } else if constexpr (T::TRI) {
       if (gr.gx) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -847,14 +913,16 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
     }
     {
       float* up = gr.gU + (size_t)s.seg * 2048 + lane;
+      if constexpr (DO_K) {
 #pragma unroll
-      for (int tq = 0; tq < 8; ++tq)
+        for (int tq = 0; tq < 8; ++tq)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) up[(tq * 4 + r) * 64] = gU[tq][r];
+          for (int r = 0; r < 4; ++r) up[(tq * 4 + r) * 64] = gU[tq][r];
+      }
       float* ck = gr.gCdst_k + (size_t)s.seg * gr.ld_gcdst;
       float* cv = gr.gCdst_v + (size_t)s.seg * gr.ld_gcdst;
-      ck[lane] = gcd_k0; ck[64 + lane] = gcd_k1;
-      cv[lane] = gcd_v0; cv[64 + lane] = gcd_v1;
+      if constexpr (DO_K) { ck[lane] = gcd_k0; ck[64 + lane] = gcd_k1; }
+      if constexpr (DO_V) { cv[lane] = gcd_v0; cv[64 + lane] = gcd_v1; }
     }
     __builtin_amdgcn_wave_barrier();
     PROF(12);  // segment outputs
@@ -869,7 +937,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       const int gi = t.ctx_graph[cj];
       const int n = t.g_nlig[gi], lig0 = t.g_ctx_off[gi] + t.g_nph[gi], lj = cj - lig0;
       const int* eid_g = t.eid + t.g_eid_off[gi];
-      for (int i = tid; i < ((n + 15) & ~15) * 256; i += blockDim.x) L.accP[i] = 0.f;
+      for (int i = tid; i < ((n + 15) & ~15) * ACCW; i += blockDim.x) L.accP[i] = 0.f;
       for (int i = tid; i < ((n + 15) & ~15) * 3; i += blockDim.x) L.accX[i] = 0.f;
       __syncthreads();
       const int n_tiles_j = (n + 15) >> 4;
@@ -888,21 +956,21 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           process(s);
         } else if (!PG_ABL(2)) {       // idle wave of this round: same barrier sequence, zero contribution
           for (int tile = 0; tile < (PG_ABL(64) ? 0 : n_tiles_j); ++tile)
-            for (int path = 0; path < (PG_ABL(8) ? 1 : 2); ++path) {
+            for (int path = (SPLIT == 2 ? 1 : 0); path < ((PG_ABL(8) || SPLIT == 1) ? 1 : 2); ++path) {
               for (int i = lane; i < 128 * 17; i += 64) L.sT[i] = 0.f;
               tri_merge(tile, OP ? path == 1 : path == 0);
             }
         }
       }
       __syncthreads();
-      for (int i = tid; i < n * 256; i += blockDim.x) {
-        const int k = i >> 8, c = i & 255;
+      for (int i = tid; i < n * ACCW; i += blockDim.x) {
+        const int k = i / ACCW, c = i % ACCW;
         if (k == lj) continue;
         const int e = eid_g[k * n + lj];
-        float* dst = (c < 128 ? gr.gCsrc_k : gr.gCsrc_v) + (size_t)e * gr.ld_gcsrc + (c & 127);
+        float* dst = ((SPLIT ? SPLIT == 2 : c < 128) ? gr.gCsrc_k : gr.gCsrc_v) + (size_t)e * gr.ld_gcsrc + (c & 127);
         *dst = L.accP[i];
       }
-      if (gr.gx)
+      if (gr.gx && DO_K)
         for (int i = tid; i < n * 3; i += blockDim.x) atomicAdd(gr.gx + (lig0 + i / 3) * 3 + (i % 3), L.accX[i]);
       __syncthreads();
     }
@@ -917,7 +985,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   // NW: the flush of all workgroups goes to the same 2 x F x 128 addresses, and with one atomic per wave it was still 5 ms of a
   // 168 ms training step).  Chunk = one float4 per lane: (path a, feature tile ft, channel tile tq); 8 chunks per barrier pair.
   if constexpr (NSTEP > 0) {
-    constexpr int NCH = 2 * NF * 8, BATCH = 8;
+    constexpr int NCH = NPATH * NF * 8, BATCH = 8;
     float* const red = lds_raw;                                   // the kernel's LDS is free now
 #pragma unroll
     for (int c0 = 0; c0 < NCH; c0 += BATCH) {
@@ -928,7 +996,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       }
       __syncthreads();
       for (int j = wave; j < BATCH; j += NW) {                    // wave w sums and flushes chunks w, w + NW, ... of the batch
-        const int ch = c0 + j, a = ch / (NF * 8), ft = (ch / 8) % NF, tq = ch % 8;
+        const int ch = c0 + j, a = SPLIT ? (SPLIT == 2 ? 0 : 1) : ch / (NF * 8), ft = (ch / 8) % NF, tq = ch % 8;
         f4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w2 = 0; w2 < NW; ++w2) v += *reinterpret_cast<const f4*>(red + ((size_t)(j * NW + w2) * 64 + lane) * 4);
@@ -942,8 +1010,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       __syncthreads();
     }
   }
-  atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1);
-  atomicAdd(gr.gbv + lane, gbv0); atomicAdd(gr.gbv + 64 + lane, gbv1);
+  if constexpr (DO_K) { atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1); }
+  if constexpr (DO_V) { atomicAdd(gr.gbv + lane, gbv0); atomicAdd(gr.gbv + 64 + lane, gbv1); }
   if constexpr (T::POS) {                                           // d W2xv: the same way, one batch of 8 chunks
     float* const red = lds_raw;
 #pragma unroll
@@ -964,20 +1032,28 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   }
 }
 
-template <int MODE, int NW, bool OP = false>
+template <int MODE, int NW, bool OP = false, int SPLIT = 0>
 static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st) {
   using T = ModeTraits<MODE>;
   constexpr int NSTEP = T::NSTEP, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1, FS = 16 * NF + 1;
   constexpr int PW = 128 * 17 + 2 * 16 * FS + 64 + 32 + 256;
-  const size_t lds = ((size_t)2 * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * 259 : 0) + (NFT == 1 ? 2 * 128 * 17 : 0) +
-                      (size_t)NW * PW) * sizeof(float);
+  constexpr int NPATH = SPLIT ? 1 : 2, ACCW = SPLIT ? 128 : 256;
+  const size_t lds = ((size_t)NPATH * NSTEP * 512 + 256 + (T::TRI ? (size_t)((t->max_nlig + 15) & ~15) * (ACCW + 3) : 0) +
+                      (NFT == 1 ? NPATH * 128 * 17 : 0) + (size_t)NW * PW) * sizeof(float);
   if (lds > 160 * 1024) { set_error("pg_seg_attn_bwd: %zu B of LDS needed (ligand of %d atoms is too large)", lds, t->max_nlig); return PG_ERR_ARG; }
-  if (int rc = reserve_lds(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW, OP>), lds, "pg_seg_attn_bwd")) return rc;
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(seg_attn_bwd_kernel<MODE, NW, OP, SPLIT>), lds, "pg_seg_attn_bwd")) return rc;
   int blocks = T::TRI ? t->n_lig : (p->n_seg + NW - 1) / NW;
   if (blocks > gr->grid) blocks = gr->grid;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW, OP>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr PG_ABL_ARG("PG_BWD_ABLATE"));
+  hipLaunchKernelGGL((seg_attn_bwd_kernel<MODE, NW, OP, SPLIT>), dim3(blocks), dim3(64 * NW), lds, st, *t, *p, *gr PG_ABL_ARG("PG_BWD_ABLATE"));
   return check_launch("pg_seg_attn_bwd");
+}
+
+// the one-pass adjoint as a value pass and a key pass of 8-wave workgroups (two waves per SIMD)
+template <int MODE>
+static int launch_bwd_split(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st) {
+  if (int rc = launch_bwd<MODE, 8, true, 1>(t, p, gr, st)) return rc;
+  return launch_bwd<MODE, 8, true, 2>(t, p, gr, st);
 }
 
 }  // namespace pg
@@ -1004,6 +1080,7 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
   hipStream_t st = (hipStream_t)stream;
   switch (p->mode) {
     case PG_SEG_KNN_NODE:
+      if (gr->alpha && gr->S && gr->swn && gr->dlogit && gr->gfeat_v) return launch_bwd_split<PG_SEG_KNN_NODE>(t, p, gr, st);
       return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_KNN_NODE, 4, true>(t, p, gr, st)
                                              : launch_bwd<PG_SEG_KNN_NODE, 4>(t, p, gr, st);
     case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
@@ -1015,6 +1092,7 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
       // the per-source-atom rows (max_nlig x 259 floats) share the LDS with the per-wave tiles: 4 waves up to 64 atoms,
       // 2 waves up to the reference's maximum of 78 (and beyond, to 96)
       const bool op = gr->alpha && gr->S && gr->swn;
+      if (op && gr->dlogit && gr->gfeat_v && t->max_nlig <= 64) return launch_bwd_split<PG_SEG_TRIPLET>(t, p, gr, st);
       if (t->max_nlig <= 64) return op ? launch_bwd<PG_SEG_TRIPLET, 4, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
       return op ? launch_bwd<PG_SEG_TRIPLET, 2, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 2>(t, p, gr, st);
     }

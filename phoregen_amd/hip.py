@@ -56,7 +56,8 @@ class PgSegAttnGrad(C.Structure):
                 ('gWf_k', c_fp), ('gWf_v', c_fp), ('gbk', c_fp), ('gbv', c_fp),
                 ('gW2xv_l', c_fp), ('gb2xv', c_fp), ('gx', c_fp), ('gnrm', c_fp), ('gew', c_fp),
                 ('alpha', c_fp), ('alpha_rows', C.c_int), ('S', c_fp), ('swn', c_fp),
-                ('rowbuf', c_fp), ('rowbuf_rows', C.c_int), ('grid', C.c_int), ('atom_order', c_ip)]
+                ('rowbuf', c_fp), ('rowbuf_rows', C.c_int), ('grid', C.c_int), ('atom_order', c_ip),
+                ('dlogit', c_fp), ('gfeat_v', c_fp)]
 
 
 SEG_KNN_NODE, SEG_KNN_POS, SEG_BOND_NODE, SEG_BOND_POS, SEG_TRIPLET, SEG_PHORE = range(6)

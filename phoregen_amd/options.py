@@ -35,6 +35,8 @@ DEFAULTS = dict(
     tri_onepass=True,     # training: one-pass triplet / node adjoints fed by the forward's softmax weights
     wide_gemm=True,       # training: one wide first-layer GEMM per layer (ColumnBlocksFn)
     bwd_atom_sort=True,   # training: the triplet adjoint takes its source atoms cost-sorted (PgSegAttnGrad.atom_order)
+    bwd_split='all',      # training: the triplet and knn-node adjoints as a value pass + a key pass of 8-wave workgroups (PgSegAttnGrad.dlogit):
+                          # 'all', 'knn' = the knn-node adjoint only, 'none' = both MLP paths in one wave (round 3)
     bwd_grid=256,         # training: persistent workgroups of pg_seg_attn_bwd (one per CU)
 )
 
@@ -45,7 +47,7 @@ _ENV = {
     'PG_NODE_FUSED': ('node_fused', _flag), 'PG_KNN_GROUP': ('knn_group', _flag), 'PG_KNN_MERGE': ('knn_merge', _tri),
     'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
     'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
-    'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int), 'PG_BWD_ATOM_SORT': ('bwd_atom_sort', _flag),
+    'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int), 'PG_BWD_SPLIT': ('bwd_split', lambda v: {'0': 'none', '1': 'knn', '2': 'all'}[v]), 'PG_BWD_ATOM_SORT': ('bwd_atom_sort', _flag),
 }
 _overrides = {}
 

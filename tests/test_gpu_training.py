@@ -263,6 +263,37 @@ def test_gradients_on_small_and_ragged_graphs(model):
         assert err < GRAD_TOL, (k, err)
 
 
+def test_two_pass_adjoints_equal_the_one_wave_form(model):
+    """The triplet / knn-node adjoints as a value pass + a key pass (8-wave workgroups, PgSegAttnGrad.dlogit / gfeat_v) against the
+    form with both MLP paths in one wave: the same sums in the same order per segment -- only the weight-gradient atomics and the
+    scatter-adds of the knn rows arrive in another order.  Ragged batch: 2- / 3-atom ligands, 3 row tiles, 64 atoms (the largest
+    the two-pass triplet form takes)."""
+    from oracle.make_inputs import synthetic_train_batch
+    from phoregen_amd import options
+    from phoregen_amd.data import TrainBatch
+    b = synthetic_train_batch(78, [2, 33, 3, 17, 64, 9], [5, 41, 4, 23, 12, 30])
+    gen = torch.Generator().manual_seed(6)
+    N, E = b['ligand_x'].numel(), b['f_edge_attr'].numel()
+    draws = dict(time_draw=torch.tensor([620, 870, 415, 77, 940, 233]), pos_noise=torch.randn(N, 3, generator=gen),
+                 u_node=torch.rand(N, 12, generator=gen), u_edge=torch.rand(E, 6, generator=gen))
+    keys = ('ligand_x', 'ligand_pos', 'ligand_batch', 'ligand_ptr', 'f_edge_index', 'f_edge_attr', 'f_edge_batch',
+            'phore_x', 'phore_pos', 'phore_norm', 'phore_batch')
+    grads = {}
+    for split in (False, True):
+        with options.override(bwd_split='all' if split else 'none'):
+            model.zero_grad()
+            loss, _ = model.compute_loss(TrainBatch(*[b[k] for k in keys]), draws=draws)
+            loss.backward()
+        grads[split] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert grads[True].keys() == grads[False].keys()
+    gmax = max(float(v.norm()) for v in grads[False].values())
+    for k, r in grads[False].items():
+        if float(r.norm()) < 1e-6 * gmax:
+            continue
+        err = float((grads[True][k].double() - r.double()).norm() / r.double().norm())
+        assert err < 2e-5, (k, err)
+
+
 def test_gradients_with_a_maximum_size_ligand(model):
     """A 78-atom ligand (the reference's max_atom; 5 row tiles, the 2-wave triplet adjoint) next to a 5-atom one."""
     from oracle import phoregen_oracle as po
