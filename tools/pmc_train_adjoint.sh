@@ -15,16 +15,22 @@ python3 - $out $tag <<'PY'
 import csv, glob, json, subprocess, sys, collections
 root, tag = sys.argv[1], sys.argv[2]
 pat = 'seg_attn_bwd_kernel<4'
-acc, dur, name = collections.defaultdict(list), [], None
+# the adjoint is one launch of the C ABI and one (both MLP paths in a wave) or two (value pass + key pass) kernels: per kernel name the
+# mean over its dispatches, then the sum over the names = per adjoint launch
+acc, dur = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(list)
+short = lambda n: n.split('(')[0].replace('void ', '')
 for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if pat in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value'])); name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+            acc[r['Counter_Name']][short(r['Kernel_Name'])].append(float(r['Counter_Value']))
 for f in glob.glob(root + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if pat in r['Kernel_Name']:
-            dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-avg = {k: sum(v) / len(v) for k, v in acc.items()}
+            dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+avg = {k: sum(sum(v) / len(v) for v in by.values()) for k, by in acc.items()}
+name = ' + '.join(sorted(dur))
+per_kernel_us = {k: sum(v) / len(v) for k, v in dur.items()}
+dur = [sum(per_kernel_us.values())] * max(len(v) for v in dur.values())
 sys.path.insert(0, 'tools'); sys.path.insert(0, '.')
 from bench_train import train_workload
 _, na = train_workload(256, seed=4321)
@@ -32,7 +38,7 @@ rec = {'kernel': name, 'mfma_per_launch': avg.get('SQ_INSTS_MFMA'), 'valu_per_la
        'padded_rows': int((na * (na - 1) * ((na + 15) // 16 * 16)).sum()),
        'hbm_bytes_per_launch': avg.get('FETCH_SIZE', 0) * 1024 * 2 + avg.get('WRITE_SIZE', 0) * 1024,
        'fetch_bytes_x2': avg.get('FETCH_SIZE', 0) * 1024 * 2, 'write_bytes': avg.get('WRITE_SIZE', 0) * 1024,
-       'avg_launch_us_under_pmc': sum(dur) / max(len(dur), 1), 'dispatches': len(dur),
+       'avg_launch_us_under_pmc': sum(dur) / max(len(dur), 1), 'dispatches': len(dur), 'avg_us_by_kernel_under_pmc': per_kernel_us,
        'commit': subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip() or None,
        'workload': 'BASELINE configs[4] shape: 256 synthetic ligand-phore pairs (tools/bench_train.py, seed 4321)',
        'method': 'rocprofv3 --kernel-trace --pmc in separate passes (SQ_INSTS_MFMA ... / FETCH_SIZE / WRITE_SIZE); FETCH_SIZE KiB x 2 '
