@@ -157,9 +157,9 @@ struct BwdLds {
 }  // namespace
 
 // SPLIT (one-pass forms of the feature modes only): the key path and the value path of a segment as two launches, so that a wave
-// holds ONE path's operands, accumulators and tiles -- half the registers and, for the triplet rows, half the LDS: 8 waves per
-// workgroup = two per SIMD instead of one, and the dependent chain of a wave (~170 MFMA + ~1 500 VALU / LDS instructions per tile
-// and path) overlaps with another wave's.  SPLIT = 1, the value pass, runs first: it needs nothing of the key path and leaves
+// holds ONE path's operands, accumulators and tiles -- half the registers and, for the triplet rows, half the LDS.  That allows 8 waves
+// per workgroup = two per SIMD at 256 registers each, or 4 waves that no longer spill at 512 (launch_bwd_split picks per mode and
+// pass).  SPLIT = 1, the value pass, runs first: it needs nothing of the key path and leaves
 // d logit [segment][row][16] (PgSegAttnGrad.dlogit) and its d feat rows (PgSegAttnGrad.gfeat_v) for SPLIT = 2, the key pass,
 // which adds the two d feat parts and runs the geometry adjoint once.  SPLIT = 0: both paths in one wave (every other form).
 template <int MODE, int NW, bool OP = false, int SPLIT = 0>   // OP: one pass, alpha / S of the forward given (triplet training form)
@@ -1049,11 +1049,15 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
   return check_launch("pg_seg_attn_bwd");
 }
 
-// the one-pass adjoint as a value pass and a key pass of 8-wave workgroups (two waves per SIMD)
+// The one-pass adjoint as a value pass and a key pass.  Workgroup size per pass, measured (profiles/r04_adjoint_codegen_fences.txt):
+// a wave that holds ONE path fits 512 registers without spilling (336 ... 446; both paths in a wave: 22 / 431 spilled), and that is
+// worth more than a second wave per SIMD at 256 registers (45 ... 307 spilled) -- except for the triplet value pass, the lightest of
+// the four, which runs best as 8 waves.
 template <int MODE>
 static int launch_bwd_split(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st) {
-  if (int rc = launch_bwd<MODE, 8, true, 1>(t, p, gr, st)) return rc;
-  return launch_bwd<MODE, 8, true, 2>(t, p, gr, st);
+  constexpr int NW_V = MODE == PG_SEG_TRIPLET ? 8 : 4;
+  if (int rc = launch_bwd<MODE, NW_V, true, 1>(t, p, gr, st)) return rc;
+  return launch_bwd<MODE, 4, true, 2>(t, p, gr, st);
 }
 
 }  // namespace pg
