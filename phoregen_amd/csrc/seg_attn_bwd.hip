@@ -170,12 +170,17 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   // front and the scatter behind (which it does otherwise, at the price of longer live ranges everywhere).  Measured, same box,
   // same sources: knn-node adjoint 2.25 -> 1.91 ms per launch, its key pass 1.22 -> 1.04, the triplet key pass 5.09 -> 4.13
   // (profiles/r04_adjoint_codegen_fences.txt).
-  // The one-wave triplet form is the exception (7.19 -> 7.34 ms with the tests): it keeps plain code.
-  constexpr bool FENCED = T::KNN || SPLIT != 0;
+  // The triplet forms at 512 registers are the exception (one wave with both paths 7.19 -> 7.34 ms with the tests, the 4-wave key pass
+  // 6.73 -> 6.84 per adjoint): they keep plain code.
+  constexpr bool FENCED = T::KNN || (SPLIT != 0 && NW == 8);
   int opq_zero = 0;
   asm volatile("" : "+s"(opq_zero));
   const bool live = FENCED ? opq_zero == 0 : true;
-  static_assert(SPLIT == 0 || (OP && !T::POS), "the split form exists for the one-pass feature modes");
+  static_assert(SPLIT == 0 || (OP && !T::POS) || (!OP && T::POS && T::KNN),
+                "the split form exists for the one-pass feature modes and for the knn position update");
+  // path order inside a tile: one-pass forms value first (its projection yields d logit), the others key first
+  constexpr int P_V = OP ? 0 : 1, P_K = OP ? 1 : 0;
+  constexpr int P_BEGIN = SPLIT == 1 ? P_V : (SPLIT == 2 ? P_K : 0), P_END = SPLIT == 1 ? P_V + 1 : (SPLIT == 2 ? P_K + 1 : 2);
   constexpr bool DO_K = SPLIT != 1, DO_V = SPLIT != 2;
   constexpr int NPATH = SPLIT ? 1 : 2, ACCW = SPLIT ? 128 : 256;
   constexpr int NSTEP = T::NSTEP, NS = NSTEP > 0 ? NSTEP : 1, F = 4 * NSTEP, NFT = (F + 15) / 16, NF = NFT > 0 ? NFT : 1;
@@ -509,10 +514,19 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       // row-buffer values of this tile in one batch of loads: rows 4g + r at head m, and row m at heads 4g .. 4g+3
       f4 aD = {0.f, 0.f, 0.f, 0.f}, glD = {0.f, 0.f, 0.f, 0.f}, aK = {0.f, 0.f, 0.f, 0.f}, glK = {0.f, 0.f, 0.f, 0.f};
       if constexpr (SPLIT == 2) {
-        glD = aD_raw;
-        glK = aK_raw;
 #pragma unroll
         for (int ft = 0; ft < NF; ++ft) gfeat[ft] = gfv_raw[ft];
+      }
+      if constexpr (SPLIT == 2 && T::POS) {
+        // A[row] = (1/16) gate sum_h alpha vx of the value pass (d rel_x = A * ddx, below)
+        if (m < 4) {
+          const int row = tile * 16 + 4 * g + m;
+          L.sR[48 + 4 * g + m] = row < n_rows ? dl_row[row * 16] : 0.f;
+        }
+      }
+      if constexpr (SPLIT == 2 && OP) {
+        glD = aD_raw;
+        glK = aK_raw;
       } else if constexpr (OP) {
         aD = aD_raw;
         aK = aK_raw;
@@ -537,8 +551,8 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       }
 
 #pragma unroll
-      for (int path = (SPLIT == 2 ? 1 : 0); path < ((PG_ABL(8) || SPLIT == 1) ? 1 : 2); ++path) {
-        const bool kp = OP ? path == 1 : path == 0;
+      for (int path = P_BEGIN; path < (PG_ABL(8) ? P_BEGIN + 1 : P_END); ++path) {
+        const bool kp = path == P_K;
         const float* bp = kp ? L.bk : L.bv;
         const float* wf = kp ? L.wf_k : L.wf_v;
         f4 hid[8];
@@ -622,6 +636,10 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
             if (m < 4) {
               const float a4 = m == 0 ? av[0] : (m == 1 ? av[1] : (m == 2 ? av[2] : av[3]));
               L.sR[48 + 4 * g + m] = a4;
+              if constexpr (SPLIT == 1) {          // for the key pass, which runs the geometry adjoint
+                const int row = tile * 16 + 4 * g + m;
+                if (row < n_rows) dl_row[row * 16] = a4;
+              }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) gbx_acc += coefD[r];
@@ -956,9 +974,9 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
           process(s);
         } else if (!PG_ABL(2)) {       // idle wave of this round: same barrier sequence, zero contribution
           for (int tile = 0; tile < (PG_ABL(64) ? 0 : n_tiles_j); ++tile)
-            for (int path = (SPLIT == 2 ? 1 : 0); path < ((PG_ABL(8) || SPLIT == 1) ? 1 : 2); ++path) {
+            for (int path = P_BEGIN; path < (PG_ABL(8) ? P_BEGIN + 1 : P_END); ++path) {
               for (int i = lane; i < 128 * 17; i += 64) L.sT[i] = 0.f;
-              tri_merge(tile, OP ? path == 1 : path == 0);
+              tri_merge(tile, path == P_K);
             }
         }
       }
@@ -1012,7 +1030,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
   }
   if constexpr (DO_K) { atomicAdd(gr.gbk + lane, gbk0); atomicAdd(gr.gbk + 64 + lane, gbk1); }
   if constexpr (DO_V) { atomicAdd(gr.gbv + lane, gbv0); atomicAdd(gr.gbv + 64 + lane, gbv1); }
-  if constexpr (T::POS) {                                           // d W2xv: the same way, one batch of 8 chunks
+  if constexpr (T::POS && DO_V) {                                   // d W2xv: the same way, one batch of 8 chunks
     float* const red = lds_raw;
 #pragma unroll
     for (int tq = 0; tq < 8; ++tq) *reinterpret_cast<f4*>(red + ((size_t)(tq * NW + wave) * 64 + lane) * 4) = gw2_acc[tq];
@@ -1025,7 +1043,7 @@ __global__ __launch_bounds__(64 * NW) void seg_attn_bwd_kernel(PgTopo t, PgSegAt
       for (int r = 0; r < 4; ++r) atomicAdd(gr.gW2xv_l + (tq * 4 + r) * 64 + lane, v[r]);
     }
   }
-  if constexpr (T::POS) {
+  if constexpr (T::POS && DO_V) {
     gbx_acc += __shfl_xor(gbx_acc, 16);
     gbx_acc += __shfl_xor(gbx_acc, 32);
     if (g == 0) atomicAdd(gr.gb2xv + m, gbx_acc);
@@ -1053,11 +1071,11 @@ static int launch_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* 
 // a wave that holds ONE path fits 512 registers without spilling (336 ... 446; both paths in a wave: 22 / 431 spilled), and that is
 // worth more than a second wave per SIMD at 256 registers (45 ... 307 spilled) -- except for the triplet value pass, the lightest of
 // the four, which runs best as 8 waves.
-template <int MODE>
+template <int MODE, bool OP = true>
 static int launch_bwd_split(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st) {
   constexpr int NW_V = MODE == PG_SEG_TRIPLET ? 8 : 4;
-  if (int rc = launch_bwd<MODE, NW_V, true, 1>(t, p, gr, st)) return rc;
-  return launch_bwd<MODE, 4, true, 2>(t, p, gr, st);
+  if (int rc = launch_bwd<MODE, NW_V, OP, 1>(t, p, gr, st)) return rc;
+  return launch_bwd<MODE, 4, OP, 2>(t, p, gr, st);
 }
 
 }  // namespace pg
@@ -1087,7 +1105,10 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
       if (gr->alpha && gr->S && gr->swn && gr->dlogit && gr->gfeat_v) return launch_bwd_split<PG_SEG_KNN_NODE>(t, p, gr, st);
       return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_KNN_NODE, 4, true>(t, p, gr, st)
                                              : launch_bwd<PG_SEG_KNN_NODE, 4>(t, p, gr, st);
-    case PG_SEG_KNN_POS: return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
+    case PG_SEG_KNN_POS:
+      // (two passes need the forward's logits / value scalars: each pass redoes the softmax adjoint from them)
+      if (gr->alpha && gr->dlogit && gr->gfeat_v) return launch_bwd_split<PG_SEG_KNN_POS, false>(t, p, gr, st);
+      return launch_bwd<PG_SEG_KNN_POS, 4>(t, p, gr, st);
     case PG_SEG_BOND_NODE:
       return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_BOND_NODE, 4, true>(t, p, gr, st)
                                              : launch_bwd<PG_SEG_BOND_NODE, 4>(t, p, gr, st);

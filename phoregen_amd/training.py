@@ -425,12 +425,15 @@ class SegCoreFn(torch.autograd.Function):
                 S_, sw_ = ctx.saved_tensors[1:3]
                 g.S, g.swn = S_.data_ptr(), sw_.data_ptr()
                 keep += [S_, sw_]
-                if cfg['mode'] in {'knn': (hip.SEG_KNN_NODE,), 'all': (hip.SEG_TRIPLET, hip.SEG_KNN_NODE)}.get(options.get('bwd_split'), ()):
-                    # scratch of the two-pass form (value pass, then key pass; 8-wave workgroups): d logit and the value pass's d feat rows
-                    dl_ = torch.empty_like(a_)
-                    gf_ = torch.empty(a_.numel() // 16 * (16 if cfg['mode'] == hip.SEG_TRIPLET else 48), dtype=torch.float32, device=dev)
-                    g.dlogit, g.gfeat_v = dl_.data_ptr(), gf_.data_ptr()
-                    keep += [dl_, gf_]
+            split_modes = {'knn': (hip.SEG_KNN_NODE, hip.SEG_KNN_POS), 'all': (hip.SEG_TRIPLET, hip.SEG_KNN_NODE, hip.SEG_KNN_POS)}
+            if cfg['mode'] in split_modes.get(options.get('bwd_split'), ()):
+                # scratch of the two-pass form (value pass, then key pass): d logit (position update: one value per row) and the value
+                # pass's d feat rows, indexed like the forward's per-row record
+                n_rows_rec = a_.numel() // (32 if pos else 16)
+                dl_ = torch.empty(n_rows_rec * 16, dtype=torch.float32, device=dev)
+                gf_ = torch.empty(n_rows_rec * (16 if cfg['mode'] == hip.SEG_TRIPLET else 48), dtype=torch.float32, device=dev)
+                g.dlogit, g.gfeat_v = dl_.data_ptr(), gf_.data_ptr()
+                keep += [dl_, gf_]
         s = SegCoreFn._struct(cfg, t)
         if bwd_timers is not None:       # measurement (tools/bench_train.py): HIP events around the adjoint launch, on its stream
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
