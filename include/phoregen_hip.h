@@ -320,11 +320,12 @@ typedef struct {
                                               ATOM per workgroup round and an atom costs ~ (n-1) x ceil(n/16): in index order the slowest of
                                               256 workgroups carries 16 % more than the average on the config-5 batch; sorted by cost and
                                               dealt out in a snake it is 1 %.  NULL = index order.  Results do not depend on it. */
-  float* dlogit; float* gfeat_v;           /* optional scratch, PG_SEG_TRIPLET (ligands up to 64 atoms) and PG_SEG_KNN_NODE with alpha / S / swn given:
-                                              [segments][alpha_rows][16] and [segments][alpha_rows][16 * ceil(F / 16)] floats (F = 12 / 48).
-                                              With both, the adjoint runs as a value pass and a key pass of 8-wave workgroups (a wave holds one
-                                              MLP path: two waves per SIMD instead of one); the value pass leaves d logit and its d feat rows
-                                              there for the key pass.  Same gradients up to the order of the weight-gradient atomics. */
+  float* dlogit; float* gfeat_v;           /* optional scratch, PG_SEG_TRIPLET (ligands up to 64 atoms), PG_SEG_KNN_NODE, PG_SEG_KNN_POS with the forward's
+                                              per-row record (alpha) given: [segments][alpha_rows][16] and [segments][alpha_rows][16 * ceil(F / 16)]
+                                              floats (F = 12 / 48 / 48).  With both, the adjoint runs as a value pass and a key pass (a wave holds ONE
+                                              MLP path and fits 512 registers without spilling); the value pass leaves d logit (position update: one
+                                              scalar per row) and its d feat rows there for the key pass.  Same gradients up to the order of the
+                                              weight-gradient atomics. */
 } PgSegAttnGrad;
 int pg_seg_attn_bwd_waves(int mode);
 int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* g, void* stream);

@@ -35,8 +35,8 @@ DEFAULTS = dict(
     tri_onepass=True,     # training: one-pass triplet / node adjoints fed by the forward's softmax weights
     wide_gemm=True,       # training: one wide first-layer GEMM per layer (ColumnBlocksFn)
     bwd_atom_sort=True,   # training: the triplet adjoint takes its source atoms cost-sorted (PgSegAttnGrad.atom_order)
-    bwd_split='all',      # training: the triplet and knn-node adjoints as a value pass + a key pass of 8-wave workgroups (PgSegAttnGrad.dlogit):
-                          # 'all', 'knn' = the knn-node adjoint only, 'none' = both MLP paths in one wave (round 3)
+    bwd_split='all',      # training: the triplet, knn-node and knn-position adjoints as a value pass + a key pass (one MLP path per wave:
+                          # no spills at 512 registers; PgSegAttnGrad.dlogit): 'all', 'knn' = the knn adjoints only, 'none' = both paths in one wave
     bwd_grid=256,         # training: persistent workgroups of pg_seg_attn_bwd (one per CU)
 )
 
