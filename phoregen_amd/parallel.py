@@ -12,8 +12,10 @@ import torch.distributed as dist
 # headline batch (profiles/r03_bench_serial_kernel_stats.md, 128 graphs, one stream): the triplet kernel's row tiles (618 440 tiles
 # of 16 rows <-> 6 x 1.95 ms), everything that scales with the bond edges n (n - 1) (their GEMMs and the two bond attention
 # modes: 203 720 edges <-> 6.2 ms), everything that scales with the context nodes n + p (knn attention, node GEMMs, knn search,
-# gate: 18 816 nodes <-> 3.0 ms).  Only the ratios matter for the partition.
-COST_US = dict(tile=11.7e3 / 618440, bond=6.2e3 / 203720, node=3.0e3 / 18816)
+# gate: 18 816 nodes <-> 3.0 ms), and a constant per graph (workgroups that are instantiated per graph, tails of its row tiles: fitted on the
+# measured rank shares of the headline batch, tools/predict_scaling.py: 5.6 us per graph at 1.16 us per unit of the other three terms).  Only
+# the ratios matter for the partition.
+COST_US = dict(tile=11.7e3 / 618440, bond=6.2e3 / 203720, node=3.0e3 / 18816, graph=4.8)
 
 
 def graph_cost(num_atoms, n_phore=None):
@@ -21,7 +23,7 @@ def graph_cost(num_atoms, n_phore=None):
     n = num_atoms.double()
     tiles = torch.div(num_atoms.clamp(min=1) - 1 + 15, 16, rounding_mode='floor').double()       # 16-row tiles per triplet segment
     ctx = n + (n_phore.double() if n_phore is not None else 0.0)
-    return COST_US['tile'] * tiles * n * (n - 1) + COST_US['bond'] * n * (n - 1) + COST_US['node'] * ctx
+    return COST_US['tile'] * tiles * n * (n - 1) + COST_US['bond'] * n * (n - 1) + COST_US['node'] * ctx + COST_US['graph']
 
 
 def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.0, big_discount=None):

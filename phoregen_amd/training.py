@@ -343,7 +343,7 @@ class SegCoreFn(torch.autograd.Function):
                 ctx.alpha_rows = arows
         ctx.has_alpha = alpha is not None
         if alpha is not None:
-            ctx.save_for_backward(alpha, *out)
+            ctx.save_for_backward(alpha, *(() if pos else out))      # (the adjoint reads S / swn of the node modes; dx of a position mode is not needed)
         hip.check(lib.pg_seg_attn(cfg['topo'], C.byref(s), _st()), 'pg_seg_attn')
         ctx.cfg, ctx.tensors, ctx.pos = cfg, tensors, pos
         return out if not pos else out[0]

@@ -482,7 +482,7 @@ def test_plan_matches_is_safe_for_inference_tensors_and_recycled_storage():
 
 
 def test_partition_balances_the_fitted_step_cost():
-    """parallel.partition_graphs on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p).  Every graph lands on exactly one rank; plain LPT
+    """parallel.partition_graphs on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p) + d.  Every graph lands on exactly one rank; plain LPT
     (by_size=False) keeps the heaviest rank within one graph of the mean; the default groups the largest ligands on the first ranks (the
     attention kernels are instantiated for the row tiles of a batch's largest ligand: ligands of 50+ atoms then do not put EVERY rank on the
     4-tile kernels) and gives the ranks that hold them up to 5 % less than their share, the others correspondingly more; on a batch whose
@@ -509,7 +509,7 @@ def test_partition_balances_the_fitted_step_cost():
             assert float(loads[with_big].max()) <= mean * 0.96 and float(loads.max()) <= mean * 1.05
     # the model's terms are the ones the kernels scale with: tiles of the triplet kernel, bond edges, context nodes
     one = graph_cost(torch.tensor([40]), torch.tensor([107]))
-    assert abs(float(one) - (COST_US['tile'] * 3 * 40 * 39 + COST_US['bond'] * 40 * 39 + COST_US['node'] * 147)) < 1e-9
+    assert abs(float(one) - (COST_US['tile'] * 3 * 40 * 39 + COST_US['bond'] * 40 * 39 + COST_US['node'] * 147 + COST_US['graph'])) < 1e-9
     # small ligands with huge pharmacophores vs large ligands with small ones: n^3 alone piles the node work on one rank
     na = torch.tensor([20] * 8 + [30] * 8)
     nph = torch.tensor([203] * 8 + [23] * 8)
