@@ -3,6 +3,7 @@
 There is NO fallback: if the library is missing or no GPU is visible the product path raises.
 """
 import ctypes as C
+import sys
 import os
 
 import torch
@@ -168,8 +169,12 @@ class OrderPoint:
             check(1, 'pg_order_point_wait')
 
     def __del__(self):
-        if self.h:
-            self._lib.pg_order_point_destroy(self.h)
+        # (at interpreter shutdown the runtime may already be gone: the process's events go with it)
+        if self.h and not sys.is_finalizing():
+            try:
+                self._lib.pg_order_point_destroy(self.h)
+            except Exception:
+                pass
             self.h = None
 
 
