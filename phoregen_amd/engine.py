@@ -82,6 +82,8 @@ class Engine:
         self.layer_ahead = o['layer_ahead']
         # cross-lane order points without the host-visibility fence of a default event (hip.OrderPoint; tools/micro/stream_packets.py)
         self.order_points = o['order_points'] and not o['graph']
+        self.tune_grid = o['tune_grid']
+        self.tuned_tri_grid = None
         self.geom_split = o['geom_split'] == 'always' or (o['geom_split'] == 'auto' and self.plan.n_bond < o['geom_split_below'])
         self.small_below = o['small_below']
         # (hipGraph capture of the v2 launch list segfaults inside the runtime -- lanes 2 / 3 wait on lane 1 there while lane 1 waits on
@@ -438,7 +440,15 @@ class Engine:
         # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
         # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 192 workgroups, 24 / 32 graphs 4.9 -> 4.7 / 5.87 -> 5.61 with
         # 224 and the merged knn launch; 48 graphs equal either way, from 64 graphs up the full grid is fastest)
-        tri_grid = self.tri_grid if self.tri_grid >= 0 else ((192 if E < 30000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
+        tri_grid = self.tri_grid if self.tri_grid >= 0 else ((160 if E < 15000 else 192 if E < 26000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
+        # ... and which multiple of 32 is best flips from batch to batch of the SAME size (whole 12-segment rounds per workgroup against
+        # the CUs left to the node chain: rank shares of the headline batch with 25.7 k bond edges each: 3.48 / 3.31 ms with 192 / 224
+        # workgroups for one, 3.27 / 3.48 for the next; profiles/r04_share_tri_grid.txt), so small batches TIME the neighbours of this
+        # default during their first steps and keep the fastest (`_tune_*`; the result does not depend on the grid: the queue hands out the
+        # same segments)
+        self._tune = None
+        if (self.tune_grid and self.tri_grid < 0 and self.multi_stream and staged and 0 < tri_grid <= 224 and not self.graph_mode == '1'):
+            self._tune = dict(cands=[g for g in (tri_grid, tri_grid + 32, tri_grid - 32) if 128 <= g <= 256], marks=[], skip=3)
 
         if v2 and w.Y1b is None:
             w.Y1b = torch.empty_like(w.Y1)
@@ -722,8 +732,43 @@ class Engine:
             self._run(self.prog_fwd)
         self._graph = g
 
+    TUNE_REPS = 6          # steps per candidate grid: the first settles, five are timed
+
+    def _set_tri_grid(self, grid):
+        for i in self.tri_calls:
+            self.prog_fwd[i][1][-1]._obj.tri_grid = grid
+
+    def _tune_begin(self):
+        """One timing event at the START of every forward of the tuning phase: the period between two of them is a whole sampler step
+        (denoiser, posterior kernels, whatever overlaps), which is what the choice is about."""
+        t = self._tune
+        if t['skip'] > 0:                            # the first forwards of an engine pay one-time costs (kernel attributes, allocator)
+            t['skip'] -= 1
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        t['marks'].append(ev)
+        k = len(t['marks']) - 1                      # this forward's index within the phase
+        if k == self.TUNE_REPS * len(t['cands']):    # one past the last candidate's steps: decide
+            ev.synchronize()                         # the one host wait of the tuning phase
+            ms = {}
+            for ci, g in enumerate(t['cands']):
+                per = sorted(t['marks'][j].elapsed_time(t['marks'][j + 1]) for j in range(ci * self.TUNE_REPS + 1, (ci + 1) * self.TUNE_REPS))
+                ms[g] = 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]) if len(per) % 2 == 0 else per[len(per) // 2]
+            best = min(ms, key=ms.get)
+            if ms[best] > 0.99 * ms[t['cands'][0]]:  # the default stays unless a neighbour is clearly faster
+                best = t['cands'][0]
+            self._set_tri_grid(best)
+            self.tuned_tri_grid, self.tuned_tri_grid_ms = best, ms
+            self._tune = None
+        elif k % self.TUNE_REPS == 0:
+            self._set_tri_grid(t['cands'][k // self.TUNE_REPS])
+
     def forward_inplace(self):
         w = self.ws
+        tuning = self._tune is not None and self.timers is None and self.trace is None and self.debug is None
+        if tuning:
+            self._tune_begin()
         if self._graph_wanted():
             if self._graph is None:
                 self._capture()

@@ -18,7 +18,7 @@ DEFAULTS = dict(
     layer_ahead=True,     # small batches: the next layer's x-independent products inside this layer's position phase
     ahead_v2='auto',      # next layer's Y1 on the node chain's lane behind Y2, P waits for it alone, layer 0's bond-node attention on lane 3:
                           # 'auto' = small batches (8 / 16 / 32 graphs - 3 % / - 3.5 % / - 1 %; 64 / 128 graphs + 0.4 % / + 1.7 %), 'never', 'always'
-    ahead_v2_below=60000, # ... 'auto': fewer bond edges than this (~35 graphs of the headline shape)
+    ahead_v2_below=82000, # ... 'auto': fewer bond edges than this (~55 graphs of the headline shape: 48 graphs 7.75 -> 7.63 ms, 64 graphs 9.97 -> 10.04)
     small_below=10**9,    # ... 'small' = fewer bond edges than this (round 4: the schedule pays at every size, 128 graphs 20.10 -> 19.81 ms)
     pos_tiled='auto',     # position-update attention with a node's row tiles over several waves: 'auto' = launches of few nodes, 'never', 'always'
     pos_tiled_below=1500, # ... 'auto': up to this many target nodes (32 graphs 5.29 -> 5.21 ms; at 64 graphs = 2 560 nodes it loses)
@@ -26,6 +26,7 @@ DEFAULTS = dict(
     geom_split='auto',    # ahead_v2: the layer's closing launch (pg_layer_geom) once per chain, on the chain's own lane: 'auto' = batches
                           # whose node chain is the longer one (4 / 8 graphs 2.29 -> 2.22 / 2.38 -> 2.30 ms; 12 graphs equal; 16 / 32 graphs + 1 %)
     geom_split_below=16000,   # ... 'auto': fewer bond edges than this
+    tune_grid=True,       # small batches: time the neighbouring triplet grids (multiples of 32 workgroups) during the first forwards, keep the fastest
     tri_grid=-1,          # persistent workgroups of the staged triplet kernel (-1: by batch size)
     graph=False,          # hipGraph replay of the forward launch list
     fused_geom='auto',    # coordinate update + bond smearing + direction vectors as one launch on the bond chain's lane (pg_layer_geom):
@@ -45,7 +46,7 @@ _flag = lambda v: v != '0'
 _ENV = {
     'PG_STREAMS': ('streams', _flag), 'PG_ROW_SUBSETS': ('row_subsets', _flag), 'PG_TRI_STAGED': ('tri_staged', _flag),
     'PG_NODE_FUSED': ('node_fused', _flag), 'PG_KNN_GROUP': ('knn_group', _flag), 'PG_KNN_MERGE': ('knn_merge', _tri),
-    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
+    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
     'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
     'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int), 'PG_BWD_SPLIT': ('bwd_split', lambda v: {'0': 'none', '1': 'knn', '2': 'all'}[v]), 'PG_BWD_ATOM_SORT': ('bwd_atom_sort', _flag),
 }

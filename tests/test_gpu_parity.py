@@ -872,3 +872,30 @@ def test_full_size_e3_equivariance(model):
         b = [o.cpu() for o in model(**{k: v.to(DEV) for k, v in moved.items()})[:3]]
     assert rel_err(b[0], a[0]) <= 1e-4 and rel_err(b[2], a[2]) <= 1e-4
     assert rel_err(b[1], a[1] @ Q.t() + tvec) <= 1e-4
+
+
+def test_online_grid_tuning_does_not_change_the_trajectory(model):
+    """Small batches time the neighbouring persistent-grid sizes of the triplet kernel during their first sampler steps and keep the fastest
+    (Engine._tune_*): the queue hands out the same segments whatever the grid, so 30 steps with the tuning phase inside equal 30 steps
+    without it bit for bit, and the phase ends with one of the candidates selected."""
+    from bench import ligphore_workload
+    from phoregen_amd import options
+    w = ligphore_workload(10, seed=3)
+
+    def run(**kw):
+        with options.override(**kw):
+            model._engine = None
+            st = model.begin_sampling(w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'], w['num_atoms'],
+                                      torch.zeros(10, 3), rng='device', seed=5, return_traj=True, num_steps=30)
+            for i in range(30):
+                model.reverse_step(st, i, 999 - i)
+            out = model.finish_sampling(st)
+            eng = st.eng
+        model._engine = None
+        return [t.cpu().clone() for t in out['pred']] + [torch.as_tensor(t).cpu().clone() for t in out['traj'] if t is not None], eng
+    tuned, eng = run()
+    plain, eng0 = run(tune_grid=False)
+    assert eng._tune is None and eng.tuned_tri_grid in (128, 160, 192, 224) and set(eng.tuned_tri_grid_ms) >= {eng.tuned_tri_grid}
+    assert eng0.tuned_tri_grid is None
+    assert len(tuned) == len(plain) and all(torch.equal(a, b) for a, b in zip(tuned, plain))
+
