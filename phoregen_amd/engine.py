@@ -307,10 +307,9 @@ class Engine:
         fused = self.fused_node and mode != hip.SEG_PHORE      # in-kernel query fold / value unfold (csrc/node_attn.hip)
         # fused knn form with two target lists (ligand + pharmacophore targets, different feature weights): ONE launch, the
         # persistent workgroups split between the lists in proportion to their sizes (PgSegAttn.seg_ids2)
-        merged = fused and knn and len(h_dst_lists) == 2 and self.merge_knn_lists and all(n > 0 for _, n, _ in h_dst_lists) and \
-            (self.merge_knn_always or sum(n for _, n, _ in h_dst_lists) >= 2500)   # (measured on the headline shape, with the triplet
-                                                                                   #  grid below: 16 graphs = 1 920 nodes slower
-                                                                                   #  merged, 24 / 32 graphs 3 % faster, 48+ equal)
+        # (at every size since round 4: with the node chain on 32 ... 96 CUs beside the triplet kernel, two launches of 50 + 85 workgroups
+        #  take three rounds where the merged one takes two -- 8 graphs 2.29 -> 2.04 ms per step, 16 graphs 3.05 -> 3.02, 24+ as before)
+        merged = fused and knn and len(h_dst_lists) == 2 and self.merge_knn_lists and all(n > 0 for _, n, _ in h_dst_lists)
         lists = [h_dst_lists[0]] if merged else h_dst_lists
         for seg_ids, n_seg, is_lig in lists:
             if not fused:

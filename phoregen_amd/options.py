@@ -14,7 +14,7 @@ DEFAULTS = dict(
     tri_staged=True,      # csrc/triplet2.hip (False: the gather kernel, triplet.hip)
     node_fused=True,      # node attention folds the query / unfolds the value in-kernel
     knn_group=True,       # neighbour slots partitioned by source kind
-    knn_merge='auto',     # ligand + pharmacophore targets of a knn sub-layer in one launch: 'auto' by batch size, 'never', 'always'
+    knn_merge='auto',     # ligand + pharmacophore targets of a knn sub-layer in one launch ('auto' = 'always' since round 4), 'never' = two launches
     layer_ahead=True,     # small batches: the next layer's x-independent products inside this layer's position phase
     ahead_v2='auto',      # next layer's Y1 on the node chain's lane behind Y2, P waits for it alone, layer 0's bond-node attention on lane 3:
                           # 'auto' = small batches (8 / 16 / 32 graphs - 3 % / - 3.5 % / - 1 %; 64 / 128 graphs + 0.4 % / + 1.7 %), 'never', 'always'
