@@ -82,6 +82,7 @@ class Engine:
         self.layer_ahead = o['layer_ahead']
         # cross-lane order points without the host-visibility fence of a default event (hip.OrderPoint; tools/micro/stream_packets.py)
         self.order_points = o['order_points'] and not o['graph']
+        self.chain_q_from = o['chain_q_from']
         self.tune_grid = o['tune_grid']
         self.tuned_tri_grid = None
         self.geom_split = o['geom_split'] == 'always' or (o['geom_split'] == 'auto' and self.plan.n_bond < o['geom_split_below'])
@@ -435,7 +436,10 @@ class Engine:
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
         ahead = self.layer_ahead and self.multi_stream and E < self.small_below
         v2 = self.ahead_v2 and ahead        # Y1 of the next layer on lane 1 behind Y2, bond-node of layer 0 on lane 3, finer waits (round 4)
-        chain_q = self.multi_stream and E < self.small_below         # small batches: the Q rows on the bond chain's own lane
+        # the Q rows (a K = 20 product, bound by its 256-wide output) behind P on the bond chain's own lane, or beside P on lane 2: lane 0 in
+        # the v2 schedule (there lane 2 would need its own release after the layer's closing launch: measured equal or slower, 8 graphs
+        # 2.05 vs 2.03 ms) and for the largest batches (128 graphs + 0.3 % on the side lane), lane 2 in between (64 graphs 9.98 -> 9.94 ms)
+        chain_q = self.multi_stream and (v2 or E >= self.chain_q_from)
         # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
         # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 192 workgroups, 24 / 32 graphs 4.9 -> 4.7 / 5.87 -> 5.61 with
         # 224 and the merged knn launch; 48 graphs equal either way, from 64 graphs up the full grid is fastest)
@@ -509,8 +513,12 @@ class Engine:
             if li == 0 and pre_join:
                 self._join(prog, pre_join)
             # (v2 from layer 1 on: lanes 2 / 3 have nothing in the first half of the layer, only the node chain's lane is released here)
-            if not (pre and split):                # (split: lane 1 went on behind its own closing launch)
-                self._fork(prog, (1,) if (pre and v2) else (1, 2, 3))
+            q_side = staged and not (chain_q and self.fused_geom)       # the Q rows on lane 2: it reads this layer's smearing (lane 0)
+            if pre and split:                      # (split: lane 1 went on behind its own closing launch)
+                if q_side:
+                    self._fork(prog, (2,))
+            else:
+                self._fork(prog, ((1, 2) if q_side else (1,)) if (pre and v2) else (1, 2, 3))
             # (v2: this layer's first-layer blocks came from lane 1 behind the previous layer's Y2, which lane 0 has joined since; the
             #  triplet queries on lane 2 are waited for in front of the triplet kernel, not in front of P)
             if not self.fused_geom:
@@ -535,7 +543,7 @@ class Engine:
             self._lane = q_lane
             if staged:
                 self._gemm(prog, w.G, 20, L.TB.W_g2, w.Qd, E, 256, add1=Y1c[:, 12 * 128:14 * 128], idx1=p.bond_src)
-                if q_lane != 0:
+                if q_lane != 0 and not (pre and v2):   # (v2 from layer 1 on: the wait for lane 2 in front of the triplet kernel covers it)
                     self._sync(prog, 0, (2,))          # lane 0 (the triplet kernel) waits for the Q rows, not for all of lane 2
             if not pre:
                 self._lane = 3                                                          # triplet queries

@@ -27,6 +27,7 @@ DEFAULTS = dict(
                           # whose node chain is the longer one (4 / 8 graphs 2.29 -> 2.22 / 2.38 -> 2.30 ms; 12 graphs equal; 16 / 32 graphs + 1 %)
     geom_split_below=16000,   # ... 'auto': fewer bond edges than this
     tune_grid=True,       # small batches: time the neighbouring triplet grids (multiples of 32 workgroups) during the first forwards, keep the fastest
+    chain_q_from=150000,  # the Q rows of the triplet MLPs behind P on lane 0 from this many bond edges up (below: beside P on lane 2)
     tri_grid=-1,          # persistent workgroups of the staged triplet kernel (-1: by batch size)
     graph=False,          # hipGraph replay of the forward launch list
     fused_geom='auto',    # coordinate update + bond smearing + direction vectors as one launch on the bond chain's lane (pg_layer_geom):
