@@ -44,14 +44,16 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
         if big_discount is None:
             # measured on shares of the headline batch (tools/predict_scaling.py): per unit of cost a rank on the 4-tile kernels is 5.0 / 5.7 %
             # slower at 16 / 32 graphs per rank, 0.7 % at 64 (the kernels are throughput-bound there)
-            big_discount = 0.05 * min(1.0, max(0.15, (12000.0 - cap_mean) / 6000.0))
+            # (a finer fit -- 3.5 % at 16 graphs per rank, 6 % at 32 -- was tried and lost: the shares scatter by +- 3 % around ANY smooth model,
+            #  grid choice and whole rounds of the node kernels on the CUs that are left: profiles/r04_share_tri_grid.txt)
+            big_discount = 0.05 if cap_mean < 4000.0 else (0.08 if cap_mean < 8000.0 else 0.0075)      # 16 / 32 / 64+ graphs per rank
         big = (num_atoms >= 50).tolist()
         n_big_cost = float(cost[num_atoms >= 50].sum())
         cap0 = float(cost.sum()) / world_size
         n_big_bins = max(1, -(-int(n_big_cost * 1000) // int(cap0 * (1.0 - big_discount) * 1000))) if n_big_cost > 0 else 0
-        # the other ranks share what the big-ligand ranks leave
-        cap_small = (float(cost.sum()) - n_big_bins * cap0 * (1.0 - big_discount)) / max(world_size - n_big_bins, 1) if n_big_bins < world_size else cap0
-        caps = [cap0 * (1.0 - big_discount) if i < n_big_bins else cap_small for i in range(world_size)]
+        # a rank on the 4-tile kernels holds (1 - big_discount) of what the others hold
+        cap_small = float(cost.sum()) / (n_big_bins * (1.0 - big_discount) + (world_size - n_big_bins)) if n_big_bins < world_size else cap0
+        caps = [cap_small * (1.0 - big_discount) if i < n_big_bins else cap_small for i in range(world_size)]
         rest = []
         for g in order.tolist():
             r = next((i for i in range(world_size) if load[i] + float(cost[g]) <= caps[i] * (1.0 + slack) and (not big[g] or i < max(n_big_bins, 1))), None)
@@ -67,37 +69,43 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
         parts[r].append(g)
         load[r] += float(cost[g])
     if by_size and world_size > 1 and len(num_atoms) <= 2048:      # (a large job is level to a fraction of a per cent already)
-        # level what first-fit left: move one graph at a time from the fullest rank (relative to its capacity) to the emptiest while that
-        # lowers the maximum; a 50+-atom ligand never moves to a rank that has none
+        # level what first-fit left: moves and swaps between the fullest rank (relative to its capacity) and any other, emptiest partner first,
+        # while that lowers the larger of the two; a 50+-atom ligand never moves to a rank that has none
         cl = cost.tolist()
         tot = [sum(cl[g] for g in parts[i]) for i in range(world_size)]
         rel = lambda i: tot[i] / caps[i]
-        for _ in range(64):
+        ok = lambda g, dst: not (big[g] and dst >= max(n_big_bins, 1))
+        for _ in range(256):
             hi = max(range(world_size), key=rel)
-            lo = min(range(world_size), key=rel)
-            gap = rel(hi) - rel(lo)
-            best = None
-            ok = lambda g, dst: not (big[g] and dst >= max(n_big_bins, 1))
-            for g in parts[hi]:                            # a move (h = None) or a swap g <-> h
-                for h in [None] + parts[lo]:
-                    if not ok(g, lo) or (h is not None and not ok(h, hi)):
-                        continue
-                    c = cl[g] - (cl[h] if h is not None else 0.0)
-                    a, b = rel(hi) - c / caps[hi], rel(lo) + c / caps[lo]
-                    new_gap = abs(a - b)
-                    if c > 0 and new_gap < gap - 1e-12 and (best is None or new_gap < best[0]):
-                        best = (new_gap, g, h)
-            if best is None:
+            applied = False
+            for lo in sorted((i for i in range(world_size) if i != hi), key=rel):      # emptiest partner first
+                pair_max = max(rel(hi), rel(lo))
+                best = None
+                for g in parts[hi]:                            # a move (h = None) or a swap g <-> h
+                    for h in [None] + parts[lo]:
+                        if not ok(g, lo) or (h is not None and not ok(h, hi)):
+                            continue
+                        c = cl[g] - (cl[h] if h is not None else 0.0)
+                        if c <= 0:
+                            continue
+                        new_max = max(rel(hi) - c / caps[hi], rel(lo) + c / caps[lo])
+                        if new_max < pair_max - 1e-9 and (best is None or new_max < best[0]):
+                            best = (new_max, g, h)
+                if best is None:
+                    continue
+                parts[hi].remove(best[1])
+                parts[lo].append(best[1])
+                tot[hi] -= cl[best[1]]
+                tot[lo] += cl[best[1]]
+                if best[2] is not None:
+                    parts[lo].remove(best[2])
+                    parts[hi].append(best[2])
+                    tot[lo] -= cl[best[2]]
+                    tot[hi] += cl[best[2]]
+                applied = True
                 break
-            parts[hi].remove(best[1])
-            parts[lo].append(best[1])
-            tot[hi] -= cl[best[1]]
-            tot[lo] += cl[best[1]]
-            if best[2] is not None:
-                parts[lo].remove(best[2])
-                parts[hi].append(best[2])
-                tot[lo] -= cl[best[2]]
-                tot[hi] += cl[best[2]]
+            if not applied:
+                break
     return [torch.tensor(sorted(p), dtype=torch.long) for p in parts]
 
 

@@ -485,7 +485,7 @@ def test_partition_balances_the_fitted_step_cost():
     """parallel.partition_graphs on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p) + d.  Every graph lands on exactly one rank; plain LPT
     (by_size=False) keeps the heaviest rank within one graph of the mean; the default groups the largest ligands on the first ranks (the
     attention kernels are instantiated for the row tiles of a batch's largest ligand: ligands of 50+ atoms then do not put EVERY rank on the
-    4-tile kernels) and gives the ranks that hold them up to 5 % less than their share, the others correspondingly more; on a batch whose
+    4-tile kernels) and gives the ranks that hold them 5 % less than the others hold; on a batch whose
     pharmacophore sizes are skewed against the atom counts the fitted cost balances better than n^3 alone does."""
     from phoregen_amd.parallel import COST_US, graph_cost, partition_graphs
     g = torch.Generator().manual_seed(5)
@@ -506,7 +506,7 @@ def test_partition_balances_the_fitted_step_cost():
             lpt_big = [r for r, p in enumerate(partition_graphs(na, world, nph, by_size=False)) if int(na[p].max()) >= 50]
             assert len(lpt_big) > len(with_big)
             loads = torch.stack([cost[p].sum() for p in parts])
-            assert float(loads[with_big].max()) <= mean * 0.96 and float(loads.max()) <= mean * 1.05
+            assert float(loads[with_big].max()) <= mean * 0.975 and float(loads.max()) <= mean * 1.03        # (5 % less than the others hold)
     # the model's terms are the ones the kernels scale with: tiles of the triplet kernel, bond edges, context nodes
     one = graph_cost(torch.tensor([40]), torch.tensor([107]))
     assert abs(float(one) - (COST_US['tile'] * 3 * 40 * 39 + COST_US['bond'] * 40 * 39 + COST_US['node'] * 147 + COST_US['graph'])) < 1e-9
