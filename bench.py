@@ -155,8 +155,8 @@ def executed_flops(eng):
             out['gemm'] += 2 * args[6] * args[5] * args[2]
         elif fn is lib.pg_seg_attn:
             sa = args[1]._obj
-            if sa.mode == hip.SEG_TRIPLET:
-                out['triplet'] += tri_tiles * 112 * 2048 + p.n_bond * 2 * fold
+            if sa.mode == hip.SEG_TRIPLET:               # (one or two launches per layer -- by row tiles of the ligand --: counted once per layer below)
+                pass
             elif sa.mode == hip.SEG_KNN_NODE:            # (one or two launches per sub-layer: counted once per sub-layer below)
                 out['knn_node'] += (sa.n_seg + sa.n_seg2) * 2 * fold
             elif sa.mode == hip.SEG_KNN_POS:
@@ -166,6 +166,7 @@ def executed_flops(eng):
             elif sa.mode == hip.SEG_BOND_POS:
                 out['bond_pos'] += node_tiles * 64 * 2048 + sa.n_seg * fold
     out['knn_node'] += len(eng.pack.layers) * knn_mf * 2048
+    out['triplet'] += len(eng.pack.layers) * (tri_tiles * 112 * 2048 + p.n_bond * 2 * fold)
     out['total'] = sum(out.values())
     return out
 
@@ -375,6 +376,7 @@ def main():
         if time_triplet:
             run.knn_ms, run.knn_mfma = knn, knn_node_mfma(st.eng)
             run.exec_flops = executed_flops(st.eng)
+            run.tri_launches = len(st.eng.tri_calls)
             run.tri_grid = st.eng.prog_fwd[st.eng.tri_calls[0]][1][-1]._obj.tri_grid or 256      # persistent triplet workgroups in use (small batches: tuned online)
             run.knn_launches = 1 if any(a[1]._obj.mode == 0 and a[1]._obj.n_seg2 > 0 for f, a, l in st.eng.prog_fwd if l >= 0 and f is st.eng.lib.pg_seg_attn) else 2
         return times, tri, model.finish_sampling(st)
@@ -433,7 +435,7 @@ def main():
             'repeats': R, 'repeats_ms_per_step': [t / K * 1e3 for t in times], 'statistic': 'median block of `repeats` blocks of `steps` steps',
             'graph_steps_per_sec': K * total_graphs / dt,
             'ranks': world, 'distinct_devices': min(world, n_dev), 'dist_backend': backend,
-            'roofline': {'kernel': 'triplet kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 launches/step), rank 0',
+            'roofline': {'kernel': 'triplet kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 sub-layers/step' + (': each as two launches, ligands of up to 49 atoms on the 3-tile instance and the larger ones behind them' if getattr(run, 'tri_launches', 6) > 6 else '') + '), rank 0',
                          'bound': 'mfma', 'achieved': exec_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': (exec_tf / peak_tf) if exec_tf else None, 'traffic': traffic, 'traffic_source': traffic_src,
                          'avg_launch_ms': tri_avg_ms, 'launches_timed': len(tri_ms),

@@ -406,7 +406,7 @@ __global__ void atom_count_kernel(const float* s_all, const float* s_l, const ui
 using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
-extern "C" int pg_abi_version(void) { return 7; }
+extern "C" int pg_abi_version(void) { return 8; }
 
 // ---- order points between the streams of one step (include/phoregen_hip.h) ----
 // An event here only orders kernels of this device against each other: every kernel ends with a device-scope release of its

@@ -494,7 +494,8 @@ int launch_triplet_staged(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
 #endif
   if (p->Csrc_v != p->Csrc_k + 128 || p->ld_csrc != 256 || ((size_t)p->Csrc_k & 15) || !p->Cdst_k || !p->Cdst_v) return -1;
   if (t->max_nlig - 1 > T2_ROWS || t->max_nlig > T2_XS) return -1;
-  const int tiles = (t->max_nlig - 1 + 15) / 16;
+  const int maxn = (p->tri_max_nlig > 0 && p->tri_max_nlig < t->max_nlig) ? p->tri_max_nlig : t->max_nlig;     // largest ligand among this queue's entries
+  const int tiles = (maxn - 1 + 15) / 16;
   if (train) {
     if (tiles <= 3) return launch_t2<768, 3, true>(t, p, st);
     if (tiles == 4) return launch_t2<768, 4, true>(t, p, st);

@@ -82,6 +82,7 @@ class Engine:
         self.layer_ahead = o['layer_ahead']
         # cross-lane order points without the host-visibility fence of a default event (hip.OrderPoint; tools/micro/stream_packets.py)
         self.order_points = o['order_points'] and not o['graph']
+        self.tri_split, self.tri_split_from = o['tri_split'], o['tri_split_from']
         self.chain_q_from = o['chain_q_from']
         self.tune_grid = o['tune_grid']
         self.tuned_tri_grid = None
@@ -559,12 +560,20 @@ class Engine:
                 self._sync(prog, 0, (2,))          # this layer's triplet queries (lane 2, launched one layer ahead)
             a = L.TB
             self._event(prog, 'triplet', True)
-            self.tri_calls.append(len(prog))
-            self._seg(prog, hip.SEG_TRIPLET, E, p.tri_order, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
-                      ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
-                      W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks,
-                      **(dict(tri_iters=p.tri_iters, n_tri_iters=p.n_tri_iters, tri_counter=p.tri_counter, tri_grid=tri_grid,
-                              Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
+            # one launch, or two when a few ligands need more row tiles than the rest (BatchPlan.tri_split): the ligands of up to 49 atoms on
+            # the 3-tile instance of the kernel, the larger ones behind them with their own queue (the 4-tile instance costs every segment
+            # ~4 %: tools/experiments/triplet_maxt_penalty.py).  Large batches only: 128 graphs 19.78 -> 19.64 ms per step; at 64 graphs the
+            # second grid's tail costs more than the instance saves (9.92 -> 10.04), at 16 graphs per rank much more (3.33 -> 3.60)
+            queues = [(p.tri_iters, p.n_tri_iters, 0, p.tri_counter)]
+            if staged and self.tri_split and p.tri_split is not None and (E >= self.tri_split_from or self.tri_split == 'always'):
+                queues = [p.tri_split['small'], p.tri_split['big']]
+            for q_iters, q_n, q_maxn, q_ctr in queues:
+                self.tri_calls.append(len(prog))
+                self._seg(prog, hip.SEG_TRIPLET, E, p.tri_order, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
+                          ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
+                          W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks,
+                          **(dict(tri_iters=q_iters, n_tri_iters=q_n, tri_counter=q_ctr, tri_grid=tri_grid, tri_max_nlig=q_maxn,
+                                  Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
             self._event(prog, 'triplet', False)
             if last:                               # lane 3 (the triplet queries) has been joined: the bond head takes it
                 self._fork(prog, (3,))

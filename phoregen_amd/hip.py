@@ -47,7 +47,7 @@ class PgSegAttn(C.Structure):
                 ('S', c_fp), ('swn', c_fp), ('resid', c_fp), ('out', c_fp), ('dx', c_fp),
                 ('accumulate_dx', C.c_int), ('alpha', c_fp), ('alpha_rows', C.c_int), ('efeat', c_fp), ('efeat_off', c_ip),
                 ('tri_iters', c_ip), ('n_tri_iters', C.c_int), ('tri_counter', c_ip),
-                ('seg_ids2', c_ip), ('n_seg2', C.c_int), ('Wf_k2', c_fp), ('Wf_v2', c_fp), ('tri_grid', C.c_int), ('pos_tiled', C.c_int)]
+                ('seg_ids2', c_ip), ('n_seg2', C.c_int), ('Wf_k2', c_fp), ('Wf_v2', c_fp), ('tri_grid', C.c_int), ('pos_tiled', C.c_int), ('tri_max_nlig', C.c_int)]
 
 
 class PgSegAttnGrad(C.Structure):

@@ -118,22 +118,37 @@ class BatchPlan:
         # 12-wave rounds, so that the queue can level the workgroups (16 graphs: 320 groups of 7 rounds on 256 workgroups meant
         # 14 rounds for the slowest; in parts of 3 + 2 + 2 rounds about 10)
         want_parts = 1 if len(groups) >= 4 * 256 or not groups else min(4, -(-4 * 256 // len(groups)))
-        its = []
-        for gi, n, j0, a in groups:
-            tiles = (n - 1 + 15) // 16
-            n_seg = a * (n - 1)
-            rounds = (n_seg + waves - 1) // waves
-            parts = max(1, min(want_parts, rounds // 2))
-            r0 = 0
-            for k in range(parts):
-                r1 = r0 + rounds // parts + (1 if k < rounds % parts else 0)
-                s0, s1 = r0 * waves, min(r1 * waves, n_seg)
-                its.append(((r1 - r0) * (tiles + 1.0) + 0.5, int(lig2ctx[lig_off[gi]]), n | (j0 << 8) | (a << 16), int(bond_off[gi]),
-                            0 if parts == 1 else (s0 | (s1 << 16))))
-                r0 = r1
-        its.sort(key=lambda r: -r[0])
-        self.tri_iters = torch.tensor([[r[1], r[2], r[3], r[4]] for r in its], dtype=torch.int32).reshape(-1, 4).to(device)
-        self.n_tri_iters = len(its) if (B and int(nlig.max()) - 1 <= rows_cap and int(nlig.max()) <= 96) else 0
+
+        def queue(grps):
+            its = []
+            for gi, n, j0, a in grps:
+                tiles = (n - 1 + 15) // 16
+                n_seg = a * (n - 1)
+                rounds = (n_seg + waves - 1) // waves
+                parts = max(1, min(want_parts, rounds // 2))
+                r0 = 0
+                for k in range(parts):
+                    r1 = r0 + rounds // parts + (1 if k < rounds % parts else 0)
+                    s0, s1 = r0 * waves, min(r1 * waves, n_seg)
+                    its.append(((r1 - r0) * (tiles + 1.0) + 0.5, int(lig2ctx[lig_off[gi]]), n | (j0 << 8) | (a << 16), int(bond_off[gi]),
+                                0 if parts == 1 else (s0 | (s1 << 16))))
+                    r0 = r1
+            its.sort(key=lambda r: -r[0])
+            return torch.tensor([[r[1], r[2], r[3], r[4]] for r in its], dtype=torch.int32).reshape(-1, 4).to(device), len(its)
+        usable = bool(B and int(nlig.max()) - 1 <= rows_cap and int(nlig.max()) <= 96)
+        self.tri_iters, n_its = queue(groups)
+        self.n_tri_iters = n_its if usable else 0
+        # the same entries as two queues, by the row tiles of the ligand: the kernel is instantiated for the largest ligand a queue holds,
+        # and the instance for 4 (5) tiles costs every segment ~4 % (8 %) -- a few 50+-atom ligands in a batch of smaller ones get their own
+        # launch (engine: options.tri_split) and the rest run on the 3-tile instance
+        small = [g_ for g_ in groups if g_[1] - 1 <= 48]
+        self.tri_split = None
+        if usable and small and len(small) < len(groups):
+            big = [g_ for g_ in groups if g_[1] - 1 > 48]
+            it_s, n_s = queue(small)
+            it_b, n_b = queue(big)
+            self.tri_split = dict(small=(it_s, n_s, max(g_[1] for g_ in small), torch.zeros(2, dtype=torch.int32, device=device)),
+                                  big=(it_b, n_b, 0, torch.zeros(2, dtype=torch.int32, device=device)))
         self.tri_counter = torch.zeros(2, dtype=torch.int32, device=device)      # queue head + exit count; the kernel re-zeroes them
         for name in ('g_ctx_off', 'g_nph', 'g_nlig', 'g_eid_off', 'eid', 'ctx_graph', 'ctx_is_lig', 'lig2ctx',
                      'bond_src', 'bond_dst', 'bond_desc', 'g_bond_off'):

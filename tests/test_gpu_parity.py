@@ -834,6 +834,8 @@ def test_engine_variants_agree(model):
     # the layer's closing launch once per chain (tiny batches) or once on the bond chain's lane: x' is the same expression either way
     assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='always', geom_split='always')))
     assert all(torch.equal(a, b) for a, b in zip(base, run(ahead_v2='always', geom_split='never')))
+    # the triplet kernel as ONE launch instantiated for the batch's largest ligand instead of two launches by row tiles (same segments, same arithmetic)
+    assert all(torch.equal(a, b) for a, b in zip(base, run(tri_split=False)))
     # cross-lane order points as torch events (with the host-visibility fence) instead of the library's fence-free ones
     assert all(torch.equal(a, b) for a, b in zip(base, run(order_points=False)))
     layer_by_layer = run(layer_ahead=False)     # without the next layer's products launched one layer ahead (12 graphs: it is on): same kernels, same bits
@@ -898,4 +900,35 @@ def test_online_grid_tuning_does_not_change_the_trajectory(model):
     assert eng._tune is None and eng.tuned_tri_grid in (128, 160, 192, 224) and set(eng.tuned_tri_grid_ms) >= {eng.tuned_tri_grid}
     assert eng0.tuned_tri_grid is None
     assert len(tuned) == len(plain) and all(torch.equal(a, b) for a, b in zip(tuned, plain))
+
+
+def test_triplet_launch_split_by_row_tiles_is_bit_identical(model):
+    """A batch with a few 50+-atom ligands among smaller ones runs the staged triplet kernel as two launches -- the ligands of up to 49 atoms
+    on the 3-tile instance, the larger ones with their own queue (BatchPlan.tri_split, PgSegAttn.tri_max_nlig): every segment sees the same
+    arithmetic, so three sampler steps equal the single launch on the 4-tile instance bit for bit.  A 66-atom ligand (5 tiles) likewise."""
+    from bench import ligphore_workload
+    from phoregen_amd import options
+    for big in ((55, 50), (66,)):
+        w = ligphore_workload(14, seed=11)
+        n = w['num_atoms'].clamp(max=47).clone()
+        for i, v in enumerate(big):
+            n[3 + 4 * i] = v
+        w['num_atoms'] = n
+
+        def run(**kw):
+            with options.override(tune_grid=False, **kw):
+                model._engine = None
+                st = model.begin_sampling(w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'], w['num_atoms'],
+                                          torch.zeros(14, 3), rng='device', seed=2, return_traj=False, num_steps=3)
+                for i in range(3):
+                    model.reverse_step(st, i, 999 - i)
+                out = [t.cpu().clone() for t in model.finish_sampling(st)['pred']]
+                launches = len(st.eng.tri_calls)
+                split = st.plan.tri_split is not None
+            model._engine = None
+            return out, launches, split
+        two, l2, has = run(tri_split='always')
+        one, l1, _ = run(tri_split=False)
+        assert has and l2 == 2 * l1 == 12
+        assert all(torch.equal(a, b) for a, b in zip(two, one))
 

@@ -19,18 +19,22 @@ st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm']
 model.reverse_step(st, 0, 999)
 eng = st.eng
 hip.lib().pg_debug_force_generic_seg(int(os.environ.get('PG_SEG_DEBUG', '0')))
-fn, args, _lane = eng.prog_fwd[eng.tri_calls[0]]
+# the triplet sub-layer of layer 0: one launch, or two when the batch's 50+-atom ligands run on their own queue (BatchPlan.tri_split)
+per_layer = len(eng.tri_calls) // len(eng.pack.layers)
+calls = [eng.prog_fwd[i] for i in eng.tri_calls[:per_layer]]
 s = hip.stream_ptr()
 torch.cuda.synchronize()
 for _ in range(3):
-    fn(*args, s)
+    for fn, args, _lane in calls:
+        fn(*args, s)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    fn(*args, s)
+    for fn, args, _lane in calls:
+        fn(*args, s)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f'triplet kernel: {ms:.3f} ms/launch, {counts["flops_triplet_kernel"] / ms / 1e9:.1f} TFLOP/s algorithmic, '
+print(f'triplet kernel ({per_layer} launch(es) per layer): {ms:.3f} ms/launch, {counts["flops_triplet_kernel"] / ms / 1e9:.1f} TFLOP/s algorithmic, '
       f'E_bond={counts["e_bond"]} E3={counts["e3"]}')

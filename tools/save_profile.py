@@ -13,24 +13,30 @@ def kernel_stats(src_dir, dst_md, title, cmd, steps):
                       f"{float(r['Percentage']):.2f} | {int(r['TotalDurationNs'])/1e6/steps:.2f} |\n")
 
 def pmc(src_dir, pat, dst_md, dst_json, title):
-    acc = collections.defaultdict(list)
+    # the sub-layer may be one kernel or two (the triplet kernel by row tiles of the ligands): per kernel name the mean over its dispatches,
+    # then the sum over the names = per sub-layer launch
+    short = lambda n: n.split('(')[0].replace('void ', '')
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(src_dir + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             if pat in r['Kernel_Name']:
-                acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    dur = []
+                acc[r['Counter_Name']][short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+    durs = collections.defaultdict(list)
     for f in glob.glob(src_dir + '/**/*kernel_trace.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             if pat in r['Kernel_Name']:
-                dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-    avg = {k: sum(v) / len(v) for k, v in acc.items()}
-    us = sum(dur) / len(dur)
+                durs[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    avg = {k: sum(sum(v) / len(v) for v in by.values()) for k, by in acc.items()}
+    names = sorted(durs)
+    us = sum(sum(v) / len(v) for v in durs.values())
+    dur = [us] * max(len(v) for v in durs.values())
+    joined = ' + '.join(names)
     # MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of
     # wide coalesced reads -> doubled; WRITE_SIZE is exact.
     fetch_b = avg.get('FETCH_SIZE', 0) * 1024 * 2
     write_b = avg.get('WRITE_SIZE', 0) * 1024
     with open(dst_md, 'w') as out:
-        out.write(f'# {title}\n\nrocprofv3 --kernel-trace --pmc <set> (separate passes), kernel `~{pat}`, {len(dur)} dispatches, avg {us:.1f} us\n\n'
+        out.write(f'# {title}\n\nrocprofv3 --kernel-trace --pmc <set> (separate passes), kernel(s) `{joined}`, {len(dur)} dispatches each, avg {us:.1f} us per sub-layer\n\n'
                   '| counter | avg per dispatch |\n|---|---|\n')
         for k in sorted(avg):
             out.write(f'| {k} | {avg[k]:.0f} |\n')
@@ -43,7 +49,8 @@ def pmc(src_dir, pat, dst_md, dst_json, title):
                       f'(MFMA {avg.get("SQ_INSTS_MFMA",0)/1e6:.1f} M)\n')
     if dst_json:
         json.dump({'hbm_bytes_per_launch': fetch_b + write_b, 'read_bytes': fetch_b, 'write_bytes': write_b,
-                   'avg_launch_us': us, 'source': os.path.basename(dst_md)}, open(dst_json, 'w'))
+                   'avg_launch_us': us, 'source': os.path.basename(dst_md), 'kernel': joined,
+                   'avg_us_by_kernel': {k: sum(v) / len(v) for k, v in durs.items()}}, open(dst_json, 'w'))
 
 if __name__ == '__main__':
     if sys.argv[1] == 'stats':
