@@ -88,6 +88,7 @@ class Engine:
         self.tuned_tri_grid = None
         self.geom_split = o['geom_split'] == 'always' or (o['geom_split'] == 'auto' and self.plan.n_bond < o['geom_split_below'])
         self.small_below = o['small_below']
+        self.ahead_below = o['ahead_below']
         # (hipGraph capture of the v2 launch list segfaults inside the runtime -- lanes 2 / 3 wait on lane 1 there while lane 1 waits on
         #  lane 3; the replay variant, off by default and measured slower, keeps the previous list)
         self.ahead_v2 = (o['ahead_v2'] == 'always' or (o['ahead_v2'] == 'auto' and self.plan.n_bond < o['ahead_v2_below'])) and not o['graph']
@@ -435,7 +436,7 @@ class Engine:
         # next layer's x-independent products inside this layer's position phase: measured (same box, alternating runs) 16 graphs
         # 3.93 -> 3.83 ms, 32 graphs 5.94 -> 5.67, 64 graphs 10.55 -> 10.36, 128 graphs 20.12 -> 20.17 (the triplet kernel then
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
-        ahead = self.layer_ahead and self.multi_stream and E < self.small_below
+        ahead = self.layer_ahead and self.multi_stream and E < min(self.small_below, self.ahead_below)
         v2 = self.ahead_v2 and ahead        # Y1 of the next layer on lane 1 behind Y2, bond-node of layer 0 on lane 3, finer waits (round 4)
         # the Q rows (a K = 20 product, bound by its 256-wide output) behind P on the bond chain's own lane, or beside P on lane 2: lane 0 in
         # the v2 schedule (there lane 2 would need its own release after the layer's closing launch: measured equal or slower, 8 graphs

@@ -19,6 +19,8 @@ DEFAULTS = dict(
     ahead_v2='auto',      # next layer's Y1 on the node chain's lane behind Y2, P waits for it alone, layer 0's bond-node attention on lane 3:
                           # 'auto' = small batches (8 / 16 / 32 graphs - 3 % / - 3.5 % / - 1 %; 64 / 128 graphs + 0.4 % / + 1.7 %), 'never', 'always'
     ahead_v2_below=82000, # ... 'auto': fewer bond edges than this (~55 graphs of the headline shape: 48 graphs 7.75 -> 7.63 ms, 64 graphs 9.97 -> 10.04)
+    ahead_below=175000,   # ... up to this many bond edges (96 graphs 14.85 -> 14.5 ms; with the triplet sub-layer in two launches the 128-graph batch
+                          # is 0.5 % faster WITHOUT: 19.64 -> 19.53)
     small_below=10**9,    # ... 'small' = fewer bond edges than this (round 4: the schedule pays at every size, 128 graphs 20.10 -> 19.81 ms)
     pos_tiled='auto',     # position-update attention with a node's row tiles over several waves: 'auto' = launches of few nodes, 'never', 'always'
     pos_tiled_below=1500, # ... 'auto': up to this many target nodes (32 graphs 5.29 -> 5.21 ms; at 64 graphs = 2 560 nodes it loses)
