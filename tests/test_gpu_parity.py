@@ -932,3 +932,30 @@ def test_triplet_launch_split_by_row_tiles_is_bit_identical(model):
         assert has and l2 == 2 * l1 == 12
         assert all(torch.equal(a, b) for a, b in zip(two, one))
 
+
+@pytest.mark.parametrize('graphs', [5, 16, 56, 72])
+def test_four_lanes_equal_one_stream_in_every_schedule_regime(model, graphs):
+    """The engine picks its launch list by batch size (per-chain closing launch below 16 k bond edges, the v2 position phase below 82 k, the Q
+    rows on a side lane up to 150 k, two triplet launches from 120 k): in each regime 25 forwards on four lanes equal the one-stream list
+    on the same inputs bit for bit (tools/stress_bits.py runs the same hunt with more sizes and repeats)."""
+    from bench import ligphore_workload
+    from phoregen_amd import options
+    w = ligphore_workload(graphs, seed=100 + graphs)
+
+    def state(**kw):
+        with options.override(tune_grid=False, **kw):
+            model._engine = None
+            st = model.begin_sampling(w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'], w['num_atoms'],
+                                      torch.zeros(graphs, 3), rng='device', seed=1, return_traj=False, num_steps=4)
+            model.reverse_step(st, 0, 999)
+        return st
+    ref_st = state(streams=False)
+    ref = [t.clone() for t in ref_st.eng.forward_inplace()]
+    st = state()
+    for name in ('in_h_node', 'in_pos', 'in_h_edge', 'in_t'):
+        getattr(st.eng.ws, name).copy_(getattr(ref_st.eng.ws, name))
+    for _ in range(25):
+        out = st.eng.forward_inplace()
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    model._engine = None
+
