@@ -374,20 +374,19 @@ class SegCoreFn(torch.autograd.Function):
         gU = torch.empty_like(t['U'])
         # bond / triplet modes store every dCsrc row exactly once; the knn / phore modes accumulate with atomics
         gYsrc = torch.empty_like(t['Ysrc']) if (full and cfg['mode'] == hip.SEG_TRIPLET) else z(t['Ysrc'])
-        gx = z(t['x']) if cfg['need_gx'] else None
-        gnrm = z(t['nrm']) if (cfg['need_gx'] and t['nrm'] is not None) else None
-        gew = z(t['ew'])
-        # the small weight gradients share one zero-filled buffer (one fill launch instead of six)
-        small = [t[k] for k in ('Wf_k', 'Wf_v', 'bk', 'bv', 'W2xv_l', 'b2xv')]
-        buf = torch.zeros(sum(x.numel() for x in small if x is not None), dtype=torch.float32, device=dev)
+        # the small gradients (weights, coordinates, direction vectors, gate) share ONE zero-filled buffer: one fill launch instead of nine
+        small = [t[k] for k in ('Wf_k', 'Wf_v', 'bk', 'bv', 'W2xv_l', 'b2xv')] + \
+                [t['x'] if cfg['need_gx'] else None, t['nrm'] if cfg['need_gx'] else None, t['ew']]
+        pad4 = lambda k: (k + 3) // 4 * 4                      # (every view starts on a 16-byte boundary)
+        buf = torch.zeros(sum(pad4(x.numel()) for x in small if x is not None), dtype=torch.float32, device=dev)
         views, off = [], 0
         for x in small:
             if x is None:
                 views.append(None)
             else:
                 views.append(buf[off:off + x.numel()].view(x.shape))
-                off += x.numel()
-        gWf_k, gWf_v, gbk, gbv, gW2, gb2 = views
+                off += pad4(x.numel())
+        gWf_k, gWf_v, gbk, gbv, gW2, gb2, gx, gnrm, gew = views
         g = hip.PgSegAttnGrad()
         keep = []
         if pos:
