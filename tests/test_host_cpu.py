@@ -537,3 +537,26 @@ def test_triplet_adjoint_atom_order_is_a_balanced_permutation():
         assert float(sorted_load.max() / sorted_load.mean()) <= 1.03, grid
         assert float(sorted_load.max()) <= float(index_load.max())
     assert float(load(torch.arange(order.numel())).max() / cost.sum() * 7) > 0      # (index order at 256 workgroups: 1.16 x the mean)
+
+
+def test_triplet_queues_by_row_tiles_cover_the_single_queue():
+    """BatchPlan.tri_split: the entries of the staged triplet kernel's queue as two queues, ligands of up to 49 atoms (3 row tiles of 16) and
+    larger ones.  Together they hold exactly the entries of the single queue; the first holds no ligand above 49 atoms and names its largest
+    (PgSegAttn.tri_max_nlig: the kernel instance is picked from it); a batch of one class has no split."""
+    from phoregen_amd.plan import BatchPlan, make_edge_data
+
+    def plan_of(sizes):
+        na = torch.tensor(sizes)
+        ei, be = make_edge_data(na)
+        return BatchPlan(torch.repeat_interleave(torch.arange(len(sizes)), na), torch.zeros(0, dtype=torch.long), ei, be, len(sizes), 'cpu')
+    p = plan_of([20, 50, 33, 49, 56, 8, 2, 41])
+    assert p.tri_split is not None
+    (it_s, n_s, max_s, ctr_s), (it_b, n_b, max_b, ctr_b) = p.tri_split['small'], p.tri_split['big']
+    rows = lambda t, n: sorted(map(tuple, t[:n].tolist()))
+    assert n_s > 0 and n_b > 0
+    assert sorted(rows(it_s, n_s) + rows(it_b, n_b)) == rows(p.tri_iters, p.n_tri_iters)
+    atoms = lambda t, n: {int(v) & 0xff for v in t[:n, 1].tolist()}            # entry word 1 = n | j0 << 8 | a << 16
+    assert max(atoms(it_s, n_s)) == max_s == 49 and min(atoms(it_b, n_b)) == 50 and max_b == 0
+    assert ctr_s.numel() == 2 and ctr_b.numel() == 2 and ctr_s.data_ptr() != ctr_b.data_ptr() != p.tri_counter.data_ptr()
+    assert plan_of([20, 33, 49]).tri_split is None and plan_of([50, 60]).tri_split is None
+
