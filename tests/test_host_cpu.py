@@ -560,3 +560,23 @@ def test_triplet_queues_by_row_tiles_cover_the_single_queue():
     assert ctr_s.numel() == 2 and ctr_b.numel() == 2 and ctr_s.data_ptr() != ctr_b.data_ptr() != p.tri_counter.data_ptr()
     assert plan_of([20, 33, 49]).tri_split is None and plan_of([50, 60]).tri_split is None
 
+
+def test_option_switches_are_consistent(monkeypatch):
+    """phoregen_amd.options: every PG_* variable names a real option and converts; the environment counts only under PHOREGEN_DEBUG=1;
+    override() nests and restores."""
+    from phoregen_amd import options
+    for var, (key, conv) in options._ENV.items():
+        assert key in options.DEFAULTS, (var, key)
+    monkeypatch.setenv('PG_TRI_GRID', '96')
+    monkeypatch.delenv('PHOREGEN_DEBUG', raising=False)
+    assert options.get('tri_grid') == options.DEFAULTS['tri_grid']          # ambient environment: ignored
+    monkeypatch.setenv('PHOREGEN_DEBUG', '1')
+    assert options.get('tri_grid') == 96
+    with options.override(tri_grid=128, knn_merge='never'):
+        assert options.get('tri_grid') == 128 and options.get('knn_merge') == 'never'
+        with options.override(tri_grid=64):
+            assert options.get('tri_grid') == 64 and options.get('knn_merge') == 'never'
+        assert options.get('tri_grid') == 128
+    assert options.get('tri_grid') == 96 and options.get('knn_merge') == options.DEFAULTS['knn_merge']
+    assert set(options.snapshot()) == set(options.DEFAULTS)
+
