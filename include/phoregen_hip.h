@@ -29,13 +29,43 @@ const char* pg_last_error(void);
 int pg_abi_version(void);
 
 /* ---- order points between the HIP streams one denoiser step is spread over (phoregen_amd/engine.py; the reference has no
- * counterpart: it runs on one torch stream).  An event without timestamp and without the system-scope fence of a default HIP
- * event: it orders kernels of ONE device against each other (each kernel ends with its own device-scope release), it does not
- * make results visible to the host -- callers synchronise the stream itself for that. */
+ * counterpart: it runs on one torch stream).  An event without timestamp whose record is a DEVICE-scope release
+ * (hipEventReleaseToDevice) instead of the system-scope fence of a default HIP event: it orders kernels of ONE device against each
+ * other, it does not make results visible to the host -- callers synchronise the stream itself for that. */
 int pg_order_point_create(void** ev);
 int pg_order_point_destroy(void* ev);
 int pg_order_point_record(void* ev, void* stream);
 int pg_order_point_wait(void* ev, void* stream);          /* `stream` continues after the last record of `ev` */
+/* 0 (default): hipEventDisableTiming | hipEventReleaseToDevice, HIP's documented device-scope release at the record.
+ * 1 (measurement only, tools/): hipEventDisableTiming | hipEventDisableSystemFence, the round-4 form whose record carries no release
+ * of its own.  Applies to order points created afterwards. */
+int pg_debug_order_point_fence_free(int on);
+
+/* ---- one denoiser forward as ONE call: a pre-built launch list walked on the host side of the library ---------------------------
+ * (reference: the ~3 000 torch ops one `self.forward` of the loop at models/diffusion.py:432-447 issues from Python.)
+ * A PgLaunch stands for one entry point of this header (`op`), its arguments `a[0 .. n_arg)` in declaration order WITHOUT the
+ * trailing stream -- pointers and integers as 64-bit values, a float as its bit pattern in the low 32 bits -- and the lane it is
+ * enqueued on: streams[lane] of pg_program_run.  PG_OP_RECORD / PG_OP_WAIT are the order points between the lanes: `ev` indexes
+ * events the program owns (pg_order_point_create flags).  Structs an argument points to (PgGemm, PgSegAttn, PgTopo) are NOT copied:
+ * they, and every device buffer, must outlive the program. */
+enum {
+  PG_OP_RECORD = 0, PG_OP_WAIT = 1, PG_OP_GEMM = 2, PG_OP_SEG_ATTN = 3, PG_OP_EMBED_CTX = 4, PG_OP_EMBED_BOND = 5, PG_OP_KNN_CTX = 6,
+  PG_OP_LIG_NORMALS = 7, PG_OP_EDGE_GATE = 8, PG_OP_KNN_GROUP_BY_KIND = 9, PG_OP_BOND_SMEAR = 10, PG_OP_ATTN_FOLD_QUERY = 11,
+  PG_OP_ATTN_UNFOLD_VALUE = 12, PG_OP_APPLY_DX = 13, PG_OP_LAYER_GEOM = 14, PG_OP_ROWS_LINEAR = 15, PG_OP_ATOM_COUNT = 16
+};
+#define PG_PROGRAM_LANES 4
+#define PG_LAUNCH_MAX_ARGS 12
+typedef struct {
+  int32_t op;                          /* PG_OP_* */
+  int32_t lane;                        /* 0 .. PG_PROGRAM_LANES-1 */
+  int32_t ev;                          /* PG_OP_RECORD / PG_OP_WAIT: order point index */
+  int32_t n_arg;
+  uint64_t a[PG_LAUNCH_MAX_ARGS];
+} PgLaunch;
+int pg_program_create(const PgLaunch* list, int n, int n_events, void** prog);   /* validates and copies the list, creates the events */
+int pg_program_run(void* prog, void* const* streams /*[PG_PROGRAM_LANES] hipStream_t*/);
+int pg_program_length(void* prog);
+int pg_program_destroy(void* prog);
 
 /* ---- MFMA lane-map self test (device writes 0 on success) -------------------------------- */
 int pg_selftest_mfma(int* d_result, void* stream);

@@ -260,6 +260,85 @@ def g5_sample(model, name, seed, n_atoms, n_steps, t_total, guidance=None):
     save(name, **arrays)
 
 
+FULL_CK = 50          # g5_sample_full1000*: the carried state is stored after every FULL_CK-th step
+
+
+def g5_sample_full1000(model, name, seed, n_atoms, guidance=None):
+    """The reference's own `sample()` for ALL 1000 steps (diffusion.py:391-525), CPU generator seeded right in front of the
+    sampler's first draw (`seed_all(seed + 1)` inside the forced atom-count call: a test re-creates the draws by seeding the same
+    generator and drawing in the reference's order, SURVEY.md Appendix B -- 3.3 MB of recorded noise stay out of the fixture).
+    Stored, thinned: the types of every step (int8), the positions of every step, the final `pred`; per step and row the top-2 gap
+    of (Gumbel + log-posterior) of the reference's categorical draw (float16: how close each draw was to flipping); after every
+    50th step the carried state the trajectory does not hold (log-posteriors, un-centred positions); float64 sums of every draw
+    (a host whose generator stream differs is told apart from a parity failure); per-step max |logit| (scale of the bounds)."""
+    import models.diffusion as rd
+    data = real_phore_data(seed)
+    T = model.num_timesteps
+    rec = dict(gap=[[], []], scale=[[], []], usum=[[], []], post=[[], []], pos_in=[], eps_sum=[])
+    orig_lsc, orig_fwd, orig_randn_like = rd.log_sample_categorical, model.forward, torch.randn_like
+    calls = {'n': 0}
+
+    def lsc(logits):
+        """The reference's function makes the draw; the same uniform numbers are then re-drawn from the saved generator state
+        to measure the margin of that draw."""
+        state = torch.get_rng_state()
+        idx = orig_lsc(logits)
+        after = torch.get_rng_state()
+        torch.set_rng_state(state)
+        u = torch.rand_like(logits)
+        assert torch.equal(torch.get_rng_state(), after)
+        top = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + logits).topk(2, dim=-1)
+        assert torch.equal(top.indices[:, 0], idx)
+        k = calls['n'] % 2                                   # node, edge, node, edge, ... (diffusion.py:457,465)
+        rec['gap'][k].append((top.values[:, 0] - top.values[:, 1]).to(torch.float16))
+        rec['usum'][k].append(float(u.double().sum()))
+        rec['post'][k].append(logits.detach().clone())
+        calls['n'] += 1
+        return idx
+
+    def fwd(**kw):
+        out = orig_fwd(**kw)
+        rec['pos_in'].append(kw['pos_pert'].detach().clone())
+        rec['scale'][0].append(float(out[0].abs().max()))
+        rec['scale'][1].append(float(out[2].abs().max()))
+        return out
+
+    def randn_like(x, *a, **k):                              # transition.py:55 (the position noise of every step)
+        out = orig_randn_like(x, *a, **k)
+        rec['eps_sum'].append(float(out.double().sum()))
+        return out
+
+    orig_sample_nodes = model.sample_nodes
+    init = {}
+
+    def forced_nodes(data_, batch_size, device, sample_mode='uniform', normal_scale=4.0):
+        orig_sample_nodes(data_, batch_size, device, sample_mode, normal_scale)
+        seed_all(seed + 1)
+        return torch.tensor(n_atoms)
+
+    model.sample_nodes, model.forward = forced_nodes, fwd
+    rd.log_sample_categorical, torch.randn_like = lsc, randn_like
+    try:
+        res = model.sample(data, len(n_atoms), 'cpu', pos_guidance_opt=guidance)
+    finally:
+        rd.log_sample_categorical, torch.randn_like = orig_lsc, orig_randn_like
+        del model.forward
+        model.sample_nodes = orig_sample_nodes
+    assert calls['n'] == 2 * T and len(rec['pos_in']) == T and len(rec['eps_sum']) == T
+    ck = list(range(FULL_CK - 1, T - 1, FULL_CK))            # loop indices i: the state after step i = the input of step i + 1
+    arrays = dict(phore_x=data['phore'].x, phore_pos=data['phore'].pos, phore_norm=data['phore'].norm, center=data.center,
+                  n_atoms=np.array(n_atoms), sample_seed=np.array(seed + 1), ck_steps=np.array(ck),
+                  traj_node=res['traj'][0].argmax(-1).to(torch.int8), traj_pos=res['traj'][1],
+                  traj_edge=res['traj'][2].argmax(-1).to(torch.int8),
+                  pred_node=res['pred'][0], pred_pos=res['pred'][1], pred_edge=res['pred'][2],
+                  gap_node=torch.stack(rec['gap'][0]), gap_edge=torch.stack(rec['gap'][1]),
+                  scale_node=np.array(rec['scale'][0], dtype=np.float32), scale_edge=np.array(rec['scale'][1], dtype=np.float32),
+                  u_node_sum=np.array(rec['usum'][0]), u_edge_sum=np.array(rec['usum'][1]), eps_sum=np.array(rec['eps_sum']),
+                  ck_log_node=torch.stack([rec['post'][0][i] for i in ck]), ck_log_edge=torch.stack([rec['post'][1][i] for i in ck]),
+                  ck_pos=torch.stack([rec['pos_in'][i + 1] for i in ck]), pos_init=rec['pos_in'][0])
+    save(name, **arrays)
+
+
 # --------------------------------------------------------------------------------------------
 # G7  state_dict manifest
 # --------------------------------------------------------------------------------------------
@@ -401,10 +480,22 @@ def profile_fixtures(profile):
     g6_compute_loss(model, f'g6_loss_a_{profile}', seed=61, n_atoms=[6, 9], n_phore=[7, 12])
 
 
+GUIDANCE = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}]
+
+
+def full1000_fixtures(model):
+    g5_sample_full1000(model, 'g5_sample_full1000_a', seed=2040, n_atoms=[6, 9, 7])
+    g5_sample_full1000(model, 'g5_sample_full1000_guid', seed=2041, n_atoms=[8, 6], guidance=GUIDANCE)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'len':        # only the bond_len_loss fixture (added in round 3)
         model, cfg = build_model(seed=0)
         g6_compute_loss(model, 'g6_loss_len', seed=67, n_atoms=[7, 10, 5], n_phore=[9, 14, 6], bond_len_loss=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'full1000':   # only the full-length free-running fixtures (added in round 5; ~10 min)
+        model, cfg = build_model(seed=0)
+        full1000_fixtures(model)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'profiles':
         for prof in ('gamma_signed', 'trained_like'):
@@ -429,3 +520,4 @@ if __name__ == '__main__':
               guidance=[{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}])
     for prof in ('gamma_signed', 'trained_like'):
         profile_fixtures(prof)
+    full1000_fixtures(model)

@@ -406,16 +406,21 @@ __global__ void atom_count_kernel(const float* s_all, const float* s_l, const ui
 using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
-extern "C" int pg_abi_version(void) { return 8; }
+extern "C" int pg_abi_version(void) { return 9; }
 
 // ---- order points between the streams of one step (include/phoregen_hip.h) ----
-// An event here only orders kernels of this device against each other: every kernel ends with a device-scope release of its
-// own, so the event needs neither a timestamp nor the system-scope fence (L2 write-back for the host) a default event carries.
-// Measured on a dependent chain (tools/micro/stream_packets.py): a record costs the chain 5.1 -> 3.7 us, a full cross-stream
-// hop 29 -> 25 us.
+// An event here only orders kernels of this device against each other: it needs neither a timestamp nor the system-scope fence (L2
+// write-back for the host) a default event carries.  The record is a device-scope release (hipEventReleaseToDevice, the flag HIP
+// documents for exactly this).  Round 4 shipped hipEventDisableSystemFence instead -- documented for timing-only events, its record
+// carries no release of its own and visibility then rests on every kernel packet's own release/acquire, a runtime detail; that
+// form stays reachable for measurement only (pg_debug_order_point_fence_free; tools/micro/stream_packets.py measured a record at
+// 5.1 -> 3.7 us and a cross-stream hop at 29 -> 25 us against a default event).
+static int g_order_point_fence_free = 0;
+extern "C" int pg_debug_order_point_fence_free(int on) { g_order_point_fence_free = on; return 0; }
 extern "C" int pg_order_point_create(void** ev) {
   hipEvent_t e = nullptr;
-  const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+  const unsigned flags = hipEventDisableTiming | (g_order_point_fence_free ? hipEventDisableSystemFence : hipEventReleaseToDevice);
+  const hipError_t rc = hipEventCreateWithFlags(&e, flags);
   if (rc != hipSuccess) { set_error("pg_order_point_create: %s", hipGetErrorString(rc)); return 1; }
   *ev = e;
   return 0;

@@ -55,6 +55,19 @@ class _TorchPoint:
         stream.wait_event(self.ev)
 
 
+class _Tap:
+    """A launch-list entry that is not a kernel launch: 'order' (records / waits of order points between the lanes), 'event' (a timing
+    event when Engine.timers is set) or 'mark' (clones of tensors when Engine.debug is set)."""
+    __slots__ = ('kind', '__name__', 'ops', 'start', 'lane', 'tensors')
+
+    def __init__(self, kind, name, ops=None, start=None, lane=0, tensors=()):
+        self.kind, self.__name__, self.ops, self.start, self.lane, self.tensors = kind, name, ops, start, lane, tensors
+
+    @property
+    def name(self):
+        return self.__name__
+
+
 class Engine:
     def __init__(self, pack: ModelPack, plan, knn_k=32, full=True, phore_only=False):
         self.lib = hip.lib()
@@ -103,6 +116,12 @@ class Engine:
         self.graph_mode = '1' if o['graph'] else '0'
         self._graph = None
         self._lane = 0
+        self._n_points = 0       # order points of this engine's launch lists
+        self._points = {}        # ... their events in the Python runner (created at first use)
+        # the launch lists run inside the library (pg_program_run: ONE foreign call per forward) unless a debug / timing / trace tap is
+        # active, the order points are torch events, or the list is being captured into a hipGraph
+        self.c_program = o['c_program'] and (self.order_points or not self.multi_stream)
+        self._compiled = {}
         self._side = None
         self.stream_set = 0      # (experiments: a second set of side lanes)
         self._alloc()
@@ -158,106 +177,90 @@ class Engine:
         prog.append((fn, args, self._lane if self.multi_stream else 0))
 
     def _point(self):
-        """A new cross-lane order point: the library's fence-free event, or a torch event (option `order_points` off; hipGraph capture)."""
+        """A new cross-lane order point: the library's device-scope event, or a torch event (option `order_points` off; hipGraph capture)."""
         if self.order_points:
             return hip.OrderPoint()
         return _TorchPoint()
+
+    # Entries of a launch list that are not kernel launches are `_Tap` records (plain data: a launch list holds no reference to its
+    # Engine, so an Engine is freed by reference counting alone).  Order points are numbered per Engine (`_n_points`); the Python
+    # runner creates the event of a point at its first record and re-records it every step (a wait refers to the record that precedes
+    # it, so re-use across steps is safe), the C runner (pg_program_*) owns one event per point.
+    def _new_point(self):
+        self._n_points += 1
+        return self._n_points - 1
+
+    def _order(self, prog, name, ops):
+        if self.multi_stream and ops:
+            prog.append((_Tap('order', name, ops=ops), None, -1))
 
     def _fork(self, prog, lanes):
         """Side lanes start after everything enqueued so far on lane 0."""
         if not self.multi_stream:
             return
-        evs = []                                    # one event per tap, created at the first run and re-recorded every step (a
-                                                    # wait refers to the record that precedes it, so re-use across steps is safe)
-        def tap(streams):
-            if not evs:
-                evs.append(self._point())
-            evs[0].record(streams[0])
-            for l in lanes:
-                evs[0].wait(streams[l])
-            return 0
-        tap.__name__ = 'fork'
-        prog.append((tap, None, -1))
+        pt = self._new_point()
+        self._order(prog, 'fork', [('record', pt, 0)] + [('wait', pt, l) for l in lanes])
 
     def _join(self, prog, lanes):
         """Lane 0 continues after the side lanes have drained."""
-        if not self.multi_stream:
-            return
-        evs = []
-        def tap(streams):
-            if not evs:
-                evs.extend(self._point() for _ in lanes)
-            for ev, l in zip(evs, lanes):
-                ev.record(streams[l])
-                ev.wait(streams[0])
-            return 0
-        tap.__name__ = 'join'
-        prog.append((tap, None, -1))
+        self._sync(prog, 0, lanes, name='join')
 
-    def _sync(self, prog, waiter, on):
+    def _sync(self, prog, waiter, on, name='sync'):
         """Lane `waiter` continues after everything enqueued SO FAR on the lanes `on` (a join of a point, not of the whole lane)."""
         if not self.multi_stream:
             return
-        evs = []
-        def tap(streams):
-            if not evs:
-                evs.extend(self._point() for _ in on)
-            for ev, l in zip(evs, on):
-                ev.record(streams[l])
-                ev.wait(streams[waiter])
-            return 0
-        tap.__name__ = 'sync'
-        prog.append((tap, None, -1))
+        ops = []
+        for l in on:
+            pt = self._new_point()
+            ops += [('record', pt, l), ('wait', pt, waiter)]
+        self._order(prog, name, ops)
 
     def _record(self, prog, lane):
         """Mark this point of `lane`; `_wait` lets another lane continue after it (a `_sync` whose wait is placed later in the list)."""
-        evs = []
-        if self.multi_stream:
-            def tap(streams):
-                if not evs:
-                    evs.append(self._point())
-                evs[0].record(streams[lane])
-                return 0
-            tap.__name__ = 'record'
-            prog.append((tap, None, -1))
-        return evs
+        if not self.multi_stream:
+            return None
+        pt = self._new_point()
+        self._order(prog, 'record', [('record', pt, lane)])
+        return pt
 
-    def _wait(self, prog, waiter, evs):
+    def _wait(self, prog, waiter, pt):
         if not self.multi_stream:
             return
-        def tap(streams):
-            evs[0].wait(streams[waiter])
-            return 0
-        tap.__name__ = 'wait'
-        prog.append((tap, None, -1))
+        self._order(prog, 'wait', [('wait', pt, waiter)])
 
     def _event(self, prog, name, start):
         """Timing tap: when `self.timers` is a dict, record a HIP event around a kernel -- on the lane (stream) the kernel is
         launched on, i.e. the lane that is current while the launch list is built."""
-        lane = self._lane if self.multi_stream else 0
-        def tap(streams):
+        prog.append((_Tap('event', name, start=start, lane=self._lane if self.multi_stream else 0), None, -1))
+
+    def _mark(self, prog, name, *tensors, lane=0):
+        """Debug tap: when `self.debug` is a dict, clone the named tensors at this point of the launch list (of `lane`)."""
+        prog.append((_Tap('mark', name, tensors=tensors, lane=lane if self.multi_stream else 0), None, -1))
+
+    def _tap(self, tap, streams):
+        """The Python runner's side of a `_Tap`."""
+        if tap.kind == 'order':
+            for what, pt, lane in tap.ops:
+                ev = self._points.get(pt)
+                if ev is None:
+                    ev = self._points[pt] = self._point()
+                if what == 'record':
+                    ev.record(streams[lane])
+                else:
+                    ev.wait(streams[lane])
+        elif tap.kind == 'event':
             if self.timers is not None:
                 ev = torch.cuda.Event(enable_timing=True)
-                ev.record(streams[lane])
-                self.timers.setdefault(name, []).append((start, ev))
-            return 0
-        tap.__name__ = 'event_' + name
-        prog.append((tap, None, -1))
+                ev.record(streams[tap.lane])
+                self.timers.setdefault(tap.name, []).append((tap.start, ev))
+        elif self.debug is not None:                 # 'mark'
+            with torch.cuda.stream(streams[tap.lane]):
+                self.debug[tap.name] = tuple(t.clone() for t in tap.tensors)
 
     def kernel_ms(self, name):
         """Per-launch durations (ms) collected since `self.timers = {}`; call after a device synchronize."""
         evs = self.timers.get(name, [])
         return [a.elapsed_time(b) for (sa, a), (sb, b) in zip(evs[0::2], evs[1::2]) if sa and not sb]
-
-    def _mark(self, prog, name, *tensors, lane=0):
-        """Debug tap: when `self.debug` is a dict, clone the named tensors at this point of the launch list (of `lane`)."""
-        def tap(streams):
-            if self.debug is not None:
-                with torch.cuda.stream(streams[lane if self.multi_stream else 0]):
-                    self.debug[name] = tuple(t.clone() for t in tensors)
-            return 0
-        tap.__name__ = 'tap_' + name
-        prog.append((tap, None, -1))
 
     def _gemm(self, prog, X, K1, W, Y, M, N, bias=None, X2=None, K2=0, ln=None, add1=None, idx1=None, add2=None,
               idx2=None, scale=1.0, act=hip.ACT_NONE, rows=None):
@@ -696,7 +699,20 @@ class Engine:
             self._join(prog, (2, 3))
         self.final_idx = cur
 
-    def _run(self, prog):
+    def _compile(self, prog):
+        """The launch list as PgLaunch records inside the library (order points renumbered densely per program)."""
+        recs, slot = [], {}
+        for fn, args, lane in prog:
+            if lane >= 0:
+                recs.append(hip.launch_record(fn, args, lane))
+            elif fn.kind == 'order':
+                for what, pt, l in fn.ops:
+                    L = hip.PgLaunch()
+                    L.op, L.lane, L.ev, L.n_arg = (hip.OP_RECORD if what == 'record' else hip.OP_WAIT), l, slot.setdefault(pt, len(slot)), 0
+                    recs.append(L)
+        return hip.Program(recs, len(slot))
+
+    def _run(self, prog, compiled=True):
         cur = torch.cuda.current_stream()
         if self._side is None:
             self._side = side_streams(cur.device_index, self.stream_set)
@@ -704,8 +720,17 @@ class Engine:
         sp = [st.cuda_stream for st in streams]
         if self.trace is not None:
             return self._run_traced(prog, streams, sp)
+        if compiled and self.c_program and self.timers is None and self.debug is None and not torch.cuda.is_current_stream_capturing():
+            ent = self._compiled.get(id(prog))
+            if ent is None or ent[0] is not prog:
+                ent = self._compiled[id(prog)] = (prog, self._compile(prog))
+            ent[1].run((C.c_void_p * hip.PG_PROGRAM_LANES)(*sp))
+            return
         for fn, args, lane in prog:
-            rc = fn(streams) if lane < 0 else fn(*args, sp[lane])
+            if lane < 0:
+                self._tap(fn, streams)
+                continue
+            rc = fn(*args, sp[lane])
             if rc:
                 hip.check(rc, fn.__name__)
 
@@ -714,17 +739,17 @@ class Engine:
         it without a profiler attached (a kernel-trace profiler adds device-side latency to every dispatch)."""
         for fn, args, lane in prog:
             if lane < 0:
-                rc = fn(streams)
-            else:
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(streams[lane])
-                rc = fn(*args, sp[lane])
-                b.record(streams[lane])
-                what = fn.__name__
-                if what in ('pg_gemm', 'pg_seg_attn'):
-                    s = args[-1]._obj
-                    what += f'[{s.M}x{s.N}x{s.K1}+{s.K2}]' if what == 'pg_gemm' else f'[mode {s.mode}, {s.n_seg}+{s.n_seg2}]'
-                self.trace.append((what, lane, a, b))
+                self._tap(fn, streams)
+                continue
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(streams[lane])
+            rc = fn(*args, sp[lane])
+            b.record(streams[lane])
+            what = fn.__name__
+            if what in ('pg_gemm', 'pg_seg_attn'):
+                s = args[-1]._obj
+                what += f'[{s.M}x{s.N}x{s.K1}+{s.K2}]' if what == 'pg_gemm' else f'[mode {s.mode}, {s.n_seg}+{s.n_seg2}]'
+            self.trace.append((what, lane, a, b))
             if rc:
                 hip.check(rc, fn.__name__)
 
@@ -757,10 +782,16 @@ class Engine:
 
     def _tune_begin(self):
         """One timing event at the START of every forward of the tuning phase: the period between two of them is a whole sampler step
-        (denoiser, posterior kernels, whatever overlaps), which is what the choice is about."""
+        (denoiser, posterior kernels, whatever overlaps), which is what the choice is about.  The decision (after ~20 forwards of a new
+        Engine) waits ONCE on the host for the last mark; results do not depend on the grid (the queue hands out the same segments)."""
         t = self._tune
         if t['skip'] > 0:                            # the first forwards of an engine pay one-time costs (kernel attributes, allocator)
             t['skip'] -= 1
+            return
+        cur = torch.cuda.current_stream().cuda_stream
+        if t.setdefault('stream', cur) != cur:       # the caller changed streams between forwards: the marks cannot be compared -> keep the default
+            self._set_tri_grid(t['cands'][0])
+            self._tune = None
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
@@ -784,6 +815,8 @@ class Engine:
     def forward_inplace(self):
         w = self.ws
         tuning = self._tune is not None and self.timers is None and self.trace is None and self.debug is None
+        if tuning and torch.cuda.is_current_stream_capturing():      # (the decision takes one host wait: never inside a caller's capture)
+            tuning = False
         if tuning:
             self._tune_begin()
         if self._graph_wanted():

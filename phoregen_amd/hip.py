@@ -3,6 +3,7 @@
 There is NO fallback: if the library is missing or no GPU is visible the product path raises.
 """
 import ctypes as C
+import struct
 import sys
 import os
 
@@ -61,6 +62,19 @@ class PgSegAttnGrad(C.Structure):
                 ('dlogit', c_fp), ('gfeat_v', c_fp)]
 
 
+PG_PROGRAM_LANES, PG_LAUNCH_MAX_ARGS = 4, 12
+
+
+class PgLaunch(C.Structure):
+    _fields_ = [('op', C.c_int32), ('lane', C.c_int32), ('ev', C.c_int32), ('n_arg', C.c_int32), ('a', C.c_uint64 * PG_LAUNCH_MAX_ARGS)]
+
+
+OP_RECORD, OP_WAIT = 0, 1
+# entry point -> PG_OP_* (include/phoregen_hip.h): what a launch list handed to pg_program_create may hold
+PROGRAM_OPS = {'pg_gemm': 2, 'pg_seg_attn': 3, 'pg_embed_ctx': 4, 'pg_embed_bond': 5, 'pg_knn_ctx': 6, 'pg_lig_normals': 7,
+               'pg_edge_gate': 8, 'pg_knn_group_by_kind': 9, 'pg_bond_smear': 10, 'pg_attn_fold_query': 11,
+               'pg_attn_unfold_value': 12, 'pg_apply_dx': 13, 'pg_layer_geom': 14, 'pg_rows_linear': 15, 'pg_atom_count': 16}
+
 SEG_KNN_NODE, SEG_KNN_POS, SEG_BOND_NODE, SEG_BOND_POS, SEG_TRIPLET, SEG_PHORE = range(6)
 ACT_NONE, ACT_SSP, ACT_RELU = 0, 1, 2
 
@@ -73,6 +87,11 @@ _PROTOS = {
     'pg_order_point_destroy': (C.c_int, [C.c_void_p]),
     'pg_order_point_record': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pg_order_point_wait': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pg_debug_order_point_fence_free': (C.c_int, [C.c_int]),
+    'pg_program_create': (C.c_int, [C.POINTER(PgLaunch), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'pg_program_run': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    'pg_program_length': (C.c_int, [C.c_void_p]),
+    'pg_program_destroy': (C.c_int, [C.c_void_p]),
     'pg_selftest_mfma': (C.c_int, [c_ip, C.c_void_p]),
     'pg_selftest_philox': (C.c_int, [c_ip, C.c_int, c_ip, C.c_void_p]),
     'pg_debug_force_generic_seg': (C.c_int, [C.c_int]),
@@ -169,13 +188,57 @@ class OrderPoint:
             check(1, 'pg_order_point_wait')
 
     def __del__(self):
-        # (at interpreter shutdown the runtime may already be gone: the process's events go with it)
-        if self.h and not sys.is_finalizing():
-            try:
+        # (at interpreter shutdown the runtime -- and this module's globals -- may already be gone: the process's events go with it)
+        try:
+            if self.h and not sys.is_finalizing():
                 self._lib.pg_order_point_destroy(self.h)
-            except Exception:
-                pass
-            self.h = None
+                self.h = None
+        except Exception:
+            pass
+
+
+def launch_record(fn, args, lane):
+    """One call of the launch list as a PgLaunch: the arguments as ctypes would pass them (without the trailing stream)."""
+    L = PgLaunch()
+    L.op, L.lane, L.ev, L.n_arg = PROGRAM_OPS[fn.__name__], lane, -1, len(args)
+    assert len(args) == len(fn.argtypes) - 1 <= PG_LAUNCH_MAX_ARGS, fn.__name__
+    for i, (a, ty) in enumerate(zip(args, fn.argtypes)):
+        if a is None:
+            v = 0
+        elif ty is C.c_float:
+            v = int.from_bytes(struct.pack('<f', a.value if isinstance(a, C.c_float) else float(a)), 'little')
+        elif hasattr(a, '_obj'):                    # byref(struct): the struct's address (the engine keeps the struct alive)
+            v = C.addressof(a._obj)
+        elif isinstance(a, C._SimpleCData):
+            v = a.value or 0
+        else:
+            v = int(a)
+        L.a[i] = v & 0xFFFFFFFFFFFFFFFF
+    return L
+
+
+class Program:
+    """A launch list inside the library (pg_program_*): one foreign call per run."""
+    __slots__ = ('h', '_lib', 'n')
+
+    def __init__(self, records, n_events):
+        self._lib = lib()
+        arr = (PgLaunch * max(len(records), 1))(*records)
+        self.h = C.c_void_p()
+        check(self._lib.pg_program_create(arr, len(records), n_events, C.byref(self.h)), 'pg_program_create')
+        self.n = len(records)
+
+    def run(self, stream_ptrs):
+        if self._lib.pg_program_run(self.h, stream_ptrs):
+            check(1, 'pg_program_run')
+
+    def __del__(self):
+        try:
+            if self.h and not sys.is_finalizing():
+                self._lib.pg_program_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 def check(rc, what=''):

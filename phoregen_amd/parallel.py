@@ -32,6 +32,8 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
     n + p (p ranges 23 .. 203), so n^3 alone picks the wrong slowest rank.  Returns a list of LongTensors of graph ids
     (ascending inside each rank, so results can be re-assembled deterministically)."""
     cost = graph_cost(num_atoms, n_phore)
+    if num_atoms.numel() == 0 or float(cost.sum()) <= 0.0:           # an empty job: every rank gets an empty shard (no capacities to divide by)
+        return [torch.arange(num_atoms.numel(), dtype=torch.long) if r == 0 else torch.empty(0, dtype=torch.long) for r in range(world_size)]
     order = torch.argsort(cost, descending=True, stable=True)
     load = [0.0] * world_size
     parts = [[] for _ in range(world_size)]

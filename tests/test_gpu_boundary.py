@@ -238,3 +238,35 @@ def test_config2_full_size_sample_call(model):
     assert torch.equal(small['pred'][2].argmax(-1), res['pred'][2][:e10].argmax(-1))
     scale = max(1.0, float(res['pred'][1].abs().max()))
     assert float((small['pred'][1] - res['pred'][1][:n10]).abs().max()) <= 1e-6 * scale
+
+
+def test_engines_of_consecutive_batches_are_freed_by_reference_counting(model):
+    """A config-4 shard builds a new BatchPlan + Engine (workspace, launch lists, programs inside the library) per batch
+    (sample_all.py:69-183 serves one pharmacophore after the other).  With the cyclic collector OFF, twelve batches of different plans
+    must leave `torch.cuda.memory_allocated()` where it was after the first: an Engine is released when the next one replaces it, not
+    whenever the collector happens to run (round 4: the launch-list closures held every Engine in a reference cycle)."""
+    import gc
+    import weakref
+    from bench import config4_job
+    from phoregen_amd.parallel import sample_job_shard
+    job = config4_job(n_phores=12, samples=6, seed=99)
+    gc.collect()
+    gc.disable()
+    try:
+        levels, engines = [], []
+        for b in range(12):
+            ids = torch.arange(b * 6, b * 6 + 6)
+            pred = sample_job_shard(model, job, ids, batch_size=6, seed=b, num_steps=2)
+            engines.append(weakref.ref(model._engine))
+            del pred
+            torch.cuda.synchronize()
+            levels.append(torch.cuda.memory_allocated())
+        assert all(e() is None for e in engines[:-1]), [e() is None for e in engines]      # only the current engine is alive
+        # the batches differ in size (p ~ N(80, 25), n ~ N(40, 6)): the current engine's own workspace is all that varies; a leak would
+        # add one workspace per batch (12 x by the end)
+        assert max(levels) < 2.0 * levels[0] and levels[-1] < 2.0 * min(levels), levels
+        model._engine = model._plan = None
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() < min(levels), (torch.cuda.memory_allocated(), levels)
+    finally:
+        gc.enable()

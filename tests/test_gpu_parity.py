@@ -618,6 +618,154 @@ def test_device_rng_sampler_runs_and_is_reproducible(model):
     assert torch.isfinite(a['pred'][1]).all() and a['traj'][0].sum(-1).eq(1).all()
 
 
+FLIP_GAP_MULT = 2 * 5 * TOL      # x max |logit| of the step: a categorical draw whose top-2 margin is below this is a tie at fp32 precision
+KINK_EPS = 2e-5                  # [A] a bond this close to min_d / max_d of the atom_prox guidance sits ON the kink of its relu at fp32 precision
+
+
+@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid'])
+def test_sampler_free_running_1000_steps_matches_reference(name):
+    """ALL 1000 reverse steps, free-running, against the reference's own `sample()` on the same seed (models/diffusion.py:391-525;
+    fixture: oracle/make_golden.py g5_sample_full1000): the CPU generator is seeded like the reference run and the draws are taken in
+    the reference's order (their float64 sums are checked against the fixture, so a host with another generator
+    stream is told apart from a parity failure).  Atom and bond types must be bit-exact at EVERY step and every graph's coordinates
+    within 1e-4 RMSD at every step.
+
+    A graph may leave the reference's trajectory only through one of the two DISCONTINUITIES of the reference's own algorithm, and the
+    test demands the evidence:
+      * a categorical draw that was a tie at fp32 precision in BOTH implementations (top-2 margin of Gumbel + log-posterior below
+        2 x 5 x TOL x max|logit|: the reference's margin from the fixture, ours recomputed here);
+      * with guidance: a bond within KINK_EPS of min_d / max_d of the atom_prox energy (utils/sample_utils.py:135-143: the gradient
+        of relu(d - max_d) + relu(min_d - d) jumps by a unit vector / (bonds x graphs) ~ 0.01 A there; the reference's autograd and
+        ANY other fp32 evaluation take different sides of the kink when d agrees to 1e-6 only.  The oracle itself -- bit-identical to the
+        reference over all 1000 steps WITHOUT guidance -- leaves the reference's guided trajectory the same way).
+    Such a graph is taken out, handed the reference's carried state at the next 50-step checkpoint and held to the full bounds again;
+    the number of graphs that finished without a hand-over is reported (gpurun_out/free_running_1000.jsonl).
+
+    WITHOUT guidance the run is one free trajectory of 1000 steps.  WITH guidance it is 20 free-running segments of 50 steps, each
+    started from the reference's state: the reference's guided dynamics are not reproducible to 1e-4 over 1000 steps by any fp32
+    implementation, kinks aside -- the center_prox gradient is the UNIT vector of (ligand centroid - pharmacophore centre), a
+    difference the guidance itself holds at 0.02 .. 0.07 A (one step of the drift moves the centroid by 1 / (graphs) = 0.06 A), so
+    every step re-injects the centroid's rounding error amplified 15 .. 50 x.  Measured: the oracle (bit-identical to the reference
+    over the whole unguided run) drifts off the reference's guided trajectory like the HIP path does (free-running HIP: RMSD 1e-4
+    after ~800 steps, no kink involved; oracle: first type flip at step 918, RMSD 0.05 at the end).  Every one of the 1000 steps is
+    still covered free-running, every 50-step segment to the full bounds."""
+    import json
+    import os
+    import torch.nn.functional as F
+    g = golden(name)
+    model = _model_for(name)
+    guid = GUID if 'guid' in name else None
+    na = t(g['n_atoms'])
+    B, p, T = len(na), g['phore_x'].shape[0], 1000
+    bp = torch.repeat_interleave(torch.arange(B), p)
+    torch.manual_seed(int(g['sample_seed']))
+    st = model.begin_sampling(t(g['phore_x']).repeat(B, 1), t(g['phore_pos']).repeat(B, 1), t(g['phore_norm']).repeat(B, 1), bp, na,
+                              t(g['center']).unsqueeze(0).expand(B, 3), rng='cpu', seed=0,
+                              guidance_center=t(g['phore_pos'])[t(g['phore_x'])[:, 12] != 1].mean(0))
+    w, N, E = st.eng.ws, st.N, st.E
+    bn, be = st.plan.batch_node.to(DEV), st.plan.batch_edge.to(DEV)
+    src, dst = st.plan.edge_index.to(DEV)
+    cnt = torch.bincount(bn, minlength=B).float()
+    ref_n, ref_e, ref_p = t(g['traj_node']).long().to(DEV), t(g['traj_edge']).long().to(DEV), t(g['traj_pos']).to(DEV)
+    assert torch.equal(w.in_h_node.argmax(-1), ref_n[0]) and torch.equal(w.in_h_edge.argmax(-1), ref_e[0])
+    assert np.allclose(w.in_pos.cpu().numpy(), g['pos_init'], rtol=0, atol=1e-5)       # (randn may differ in the last ulp between CPU kinds)
+    BIG = 10 ** 6
+    first_bad = torch.full((B,), BIG, device=DEV)                  # first step whose result left the reference's trajectory, per graph
+    bad_types = torch.zeros(T, B, dtype=torch.bool, device=DEV)
+    rmsd = torch.zeros(T + 1, B, device=DEV)
+    kink = torch.full((T, B), 9.0, device=DEV)
+    gap_n, gap_e = torch.zeros(T, N, device=DEV), torch.zeros(T, E, device=DEV)
+    ck = {int(i): k for k, i in enumerate(g['ck_steps'])}
+    events, seg_end_rmsd = [], []
+
+    def margins(u, logp):
+        top = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + logp).topk(2, dim=-1).values
+        return top[:, 0] - top[:, 1]
+
+    def explain(gi, s, resynced_after):
+        """Why graph gi left the reference's trajectory at step s."""
+        ev = dict(graph=gi, diverged_at=s, resynced_after=resynced_after, rmsd_at=float(rmsd[s + 1, gi]), types_differ=bool(bad_types[s, gi]),
+                  kink_margin=float(kink[s, gi]), flips=[])
+        bound = FLIP_GAP_MULT * float(max(g['scale_node'][s], g['scale_edge'][s]))
+        for kind, traj, ref, batch, ref_gap, hip_gap in (('node', st.node_traj, ref_n, bn, g['gap_node'], gap_n), ('edge', st.edge_traj, ref_e, be, g['gap_edge'], gap_e)):
+            for r in ((traj[s + 1].argmax(-1) != ref[s + 1]) & (batch == gi)).nonzero().flatten().tolist():
+                ev['flips'].append(dict(kind=kind, row=r, ref_gap=float(ref_gap[s, r]), hip_gap=float(hip_gap[s, r]), bound=bound))
+        ties = bool(ev['flips']) and all(f['ref_gap'] <= f['bound'] and f['hip_gap'] <= f['bound'] for f in ev['flips'])
+        on_kink = guid is not None and ev['kink_margin'] <= KINK_EPS
+        ev['explained_by'] = 'guidance kink' if on_kink else ('categorical tie' if ties and ev['rmsd_at'] <= 1e-4 else None)
+        return ev
+
+    for i in range(T):
+        step = T - 1 - i
+        un, ue = torch.rand(N, 12), torch.rand(E, 6)                                  # Appendix B item 5: rand, rand, then randn
+        eps = torch.randn(N, 3)
+        assert float(un.double().sum()) == g['u_node_sum'][i] and float(ue.double().sum()) == g['u_edge_sum'][i], \
+            f'step {i}: torch CPU generator stream differs from the one the fixture was recorded with'
+        assert abs(float(eps.double().sum()) - g['eps_sum'][i]) < 1e-4
+        un, ue = un.to(DEV), ue.to(DEV)
+        x_t = w.in_pos.clone() if guid else None
+        model.reverse_step(st, i, step, guid, draws=(un, ue, eps))
+        gap_n[i], gap_e[i] = margins(un, st.log_node[st.cur]), margins(ue, st.log_edge[st.cur])
+        if guid:                                                  # distance of every guided bond from the kinks of its energy, per graph
+            d = (x_t[src] - x_t[dst]).norm(dim=-1)
+            m = torch.minimum((d - guid[0]['max_d']).abs(), (d - guid[0]['min_d']).abs())
+            m = torch.where(w.in_h_edge.argmax(-1) > 0, m, torch.full_like(m, 9.0))
+            kink[i] = kink[i].scatter_reduce(0, be, m, 'amin')
+        bad = torch.zeros(B, device=DEV).index_add_(0, bn, (w.in_h_node.argmax(-1) != ref_n[i + 1]).float())
+        bad.index_add_(0, be, (w.in_h_edge.argmax(-1) != ref_e[i + 1]).float())
+        bad_types[i] = bad > 0
+        rmsd[i + 1] = (torch.zeros(B, device=DEV).index_add_(0, bn, ((st.pos_traj[i + 1] - ref_p[i + 1]) ** 2).sum(-1)) / cnt).sqrt()
+        first_bad = torch.where(((bad > 0) | (rmsd[i + 1] > 1e-4)) & (first_bad == BIG), torch.full_like(first_bad, i), first_bad)
+        if i in ck or i == T - 1:                                                 # one host look per 50 steps
+            fb = first_bad.cpu()
+            seg_end_rmsd.append(float(rmsd[i + 1].max()))
+            for gi in range(B):
+                if fb[gi] < BIG:
+                    events.append(explain(gi, int(fb[gi]), i))
+                if i in ck and (fb[gi] < BIG or guid is not None):                # (guided: every graph, at every checkpoint -- see above)
+                    k = ck[i]                                                     # the reference's carried state after step i
+                    mn, me = (bn == gi), (be == gi)
+                    w.in_h_node[mn] = F.one_hot(ref_n[i + 1][mn], 12).float()
+                    w.in_h_edge[me] = F.one_hot(ref_e[i + 1][me], 6).float()
+                    w.in_pos[mn] = t(g['ck_pos'][k]).to(DEV)[mn]
+                    st.log_node[st.cur][mn] = t(g['ck_log_node'][k]).to(DEV)[mn]
+                    st.log_edge[st.cur][me] = t(g['ck_log_edge'][k]).to(DEV)[me]
+            first_bad.fill_(BIG)
+    torch.cuda.synchronize()
+    valid = torch.ones(T + 1, B, dtype=torch.bool)
+    for ev in events:
+        valid[ev['diverged_at'] + 1: ev['resynced_after'] + 2, ev['graph']] = False      # frames written by a state that had left the trajectory
+    rm = rmsd.cpu()
+    worst = float(rm[valid].max())
+    res = model.finish_sampling(st)
+    clean = sorted(set(range(B)) - {ev['graph'] for ev in events})
+    sel = torch.isin(st.plan.batch_node.cpu(), torch.tensor(clean, dtype=torch.long))
+    pred_rmsd = float(((res['pred'][1].cpu() - t(g['pred_pos'])) ** 2).sum(-1)[sel].mean().sqrt()) if clean else float('nan')
+    rec = dict(fixture=name, graphs=B, atoms=N, bond_rows=E, steps=T, guidance=bool(guid), graphs_identical_all_1000_steps=len(clean),
+               departures=events, graph_steps_on_the_reference_trajectory=int(valid[1:].sum()), graph_steps_total=T * B,
+               free_running_segments=1 if guid is None else len(ck) + 1, worst_segment_end_rmsd=max(seg_end_rmsd),
+               worst_rmsd_any_step_on_trajectory=worst, final_frame_rmsd=[float(x) for x in rm[T]], pred_pos_rmsd=pred_rmsd,
+               min_margin_hip=[float(gap_n.min()), float(gap_e.min())], min_kink_margin=float(kink.min()) if guid else None)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'free_running_1000.jsonl'), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+    print(json.dumps(rec))
+    for ev in events:                                     # every departure is one of the reference algorithm's own discontinuities
+        assert ev['explained_by'] is not None, ev
+    assert worst <= 1e-4, (worst, rec)
+    if clean:
+        assert pred_rmsd <= 1e-4, pred_rmsd
+        assert torch.equal(res['pred'][0].cpu().argmax(-1)[sel], t(g['pred_node']).argmax(-1)[sel])
+    if guid is None:
+        assert len(clean) >= B - 1, rec                   # without guidance only a categorical tie can take a graph out: at most one per fixture
+    else:
+        assert len(events) <= 4 and int(valid[1:].sum()) >= 0.8 * T * B, rec      # a few kinks at most: >= 80 % of all graph-steps on the trajectory
+
+
 def test_full_1000_step_trajectory_stays_finite_and_one_hot(model):
     """All 1000 reverse steps with the device RNG and guidance on a small ragged batch: every trajectory frame finite,
     discrete states one-hot, shapes of the reference contract (diffusion.py:505-525), decode_data on the result."""
@@ -959,3 +1107,41 @@ def test_four_lanes_equal_one_stream_in_every_schedule_regime(model, graphs):
         assert all(torch.equal(a, b) for a, b in zip(out, ref))
     model._engine = None
 
+
+
+@pytest.mark.parametrize('graphs', [5, 40])
+def test_library_side_launch_list_equals_the_python_walk(model, graphs):
+    """pg_program_run (one foreign call per forward: the launch list, lanes and order points inside the library) against the same list
+    walked from Python, and both against the one-stream list: 40 forwards each, bit for bit.  The compiled program holds every launch of
+    the list plus one record / wait per order-point operation."""
+    from bench import ligphore_workload
+    from phoregen_amd import hip, options
+    w = ligphore_workload(graphs, seed=300 + graphs)
+
+    def state(**kw):
+        with options.override(tune_grid=False, **kw):
+            model._engine = None
+            st = model.begin_sampling(w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'], w['num_atoms'],
+                                      torch.zeros(graphs, 3), rng='device', seed=1, return_traj=False, num_steps=4)
+            model.reverse_step(st, 0, 999)
+        return st
+    ref_st = state(streams=False, c_program=False)
+    ref = [t.clone() for t in ref_st.eng.forward_inplace()]
+    assert not ref_st.eng._compiled
+    for c_program in (True, False):
+        st = state(c_program=c_program)
+        eng = st.eng
+        for name in ('in_h_node', 'in_pos', 'in_h_edge', 'in_t'):
+            getattr(eng.ws, name).copy_(getattr(ref_st.eng.ws, name))
+        for _ in range(40):
+            out = eng.forward_inplace()
+            assert all(torch.equal(a, b) for a, b in zip(out, ref)), c_program
+        if c_program:
+            prog = eng.prog_fwd
+            n_launch = sum(1 for _, _, lane in prog if lane >= 0)
+            n_order = sum(len(f.ops) for f, _, lane in prog if lane < 0 and f.kind == 'order')
+            compiled = eng._compiled[id(prog)][1]
+            assert eng.lib.pg_program_length(compiled.h) == n_launch + n_order == compiled.n and n_order > 0
+        else:
+            assert id(eng.prog_fwd) not in eng._compiled
+    model._engine = None

@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pg_abi_version() == 8
+    assert lib.pg_abi_version() == 9
     assert isinstance(lib.pg_last_error(), bytes)
 
 
@@ -507,6 +507,10 @@ def test_partition_balances_the_fitted_step_cost():
             assert len(lpt_big) > len(with_big)
             loads = torch.stack([cost[p].sum() for p in parts])
             assert float(loads[with_big].max()) <= mean * 0.975 and float(loads.max()) <= mean * 1.03        # (5 % less than the others hold)
+    # an empty job (a shard of a finished sampling job): empty shards for every rank, at any world size
+    for world in (1, 2, 8):
+        parts = partition_graphs(torch.tensor([], dtype=torch.long), world)
+        assert len(parts) == world and all(p.numel() == 0 and p.dtype == torch.long for p in parts)
     # the model's terms are the ones the kernels scale with: tiles of the triplet kernel, bond edges, context nodes
     one = graph_cost(torch.tensor([40]), torch.tensor([107]))
     assert abs(float(one) - (COST_US['tile'] * 3 * 40 * 39 + COST_US['bond'] * 40 * 39 + COST_US['node'] * 147 + COST_US['graph'])) < 1e-9
@@ -580,3 +584,35 @@ def test_option_switches_are_consistent(monkeypatch):
     assert options.get('tri_grid') == 96 and options.get('knn_merge') == options.DEFAULTS['knn_merge']
     assert set(options.snapshot()) == set(options.DEFAULTS)
 
+
+
+def test_launch_records_carry_the_arguments_ctypes_would_pass():
+    """hip.launch_record: one entry of an engine launch list as the PgLaunch the library walks (include/phoregen_hip.h): pointers and
+    integers as 64-bit values, a float as its bit pattern, NULL as 0, byref(struct) as the struct's address; the library validates op,
+    argument count, lane and order-point index when a program is created (no GPU needed for either)."""
+    import ctypes as C
+    import struct
+    from phoregen_amd import hip
+    lib = hip.load_library()
+    topo, g = hip.PgTopo(), hip.PgGemm()
+    L = hip.launch_record(lib.pg_edge_gate, (C.byref(topo), 0x7f0000001000, 0x7f0000002000, None, 32, 5, 6, 7, 8, 9, C.c_float(-0.375), 11), 1)
+    assert (L.op, L.lane, L.n_arg) == (hip.PROGRAM_OPS['pg_edge_gate'], 1, 12)
+    assert L.a[0] == C.addressof(topo) and L.a[1] == 0x7f0000001000 and L.a[3] == 0 and L.a[4] == 32
+    assert struct.unpack('<f', struct.pack('<I', L.a[10]))[0] == -0.375
+    L2 = hip.launch_record(lib.pg_gemm, (C.byref(g),), 0)
+    assert L2.a[0] == C.addressof(g) and L2.n_arg == 1
+    L3 = hip.launch_record(lib.pg_knn_ctx, (C.byref(topo), 1, -1, 2, 3), 3)          # a negative int keeps its value through the 64-bit slot
+    assert C.c_int64(L3.a[2]).value == -1
+    # the library side: validation without touching the GPU (no events asked for)
+    h = C.c_void_p()
+    arr = (hip.PgLaunch * 2)(L, L2)
+    assert lib.pg_program_create(arr, 2, 0, C.byref(h)) == 0 and lib.pg_program_length(h) == 2 and lib.pg_program_destroy(h) == 0
+    bad = hip.PgLaunch()
+    bad.op, bad.lane, bad.ev, bad.n_arg = hip.OP_WAIT, 0, 3, 0
+    assert lib.pg_program_create((hip.PgLaunch * 1)(bad), 1, 2, C.byref(h)) != 0 and b'order point 3 of 2' in lib.pg_last_error()
+    bad.op, bad.ev, bad.lane = hip.PROGRAM_OPS['pg_gemm'], -1, 7
+    bad.n_arg = 1
+    assert lib.pg_program_create((hip.PgLaunch * 1)(bad), 1, 0, C.byref(h)) != 0 and b'lane 7' in lib.pg_last_error()
+    bad.lane, bad.n_arg = 0, 3
+    assert lib.pg_program_create((hip.PgLaunch * 1)(bad), 1, 0, C.byref(h)) != 0 and b'takes 1 arguments' in lib.pg_last_error()
+    assert set(hip.PROGRAM_OPS) <= set(hip.EXPORTS)

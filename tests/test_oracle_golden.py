@@ -175,6 +175,66 @@ def test_g5_sampler(name):
         assert np.array_equal(res['lig_info'][2].numpy(), g['lig_edge_index'])
 
 
+@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid'])
+def test_g5_full_length_fixture_windows(name):
+    """The 1000-step fixtures of the reference's own `sample()` (oracle/make_golden.py g5_sample_full1000): the draws are re-created by
+    seeding torch's CPU generator like the reference run (their float64 sums are in the fixture), the initial state must come out bit
+    for bit, and from three of the stored checkpoints (t = 949, 499, 49) the oracle free-runs 10 steps: types bit-exact, coordinates
+    <= 1e-5 A from the reference's trajectory.  (The whole 1000-step run of the oracle -- 5 min of CPU -- equals the reference's bit
+    for bit without guidance: 0 type mismatches, RMSD 0.0, profiles/r05_oracle_vs_reference_full1000.txt.)"""
+    import torch.nn.functional as F
+    g = golden(name)
+    o = _oracle_for(name)
+    guid = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}] if 'guid' in name else None
+    na = t(g['n_atoms'])
+    B, p, T = len(na), g['phore_x'].shape[0], 1000
+    bn = torch.repeat_interleave(torch.arange(B), na)
+    ei, be = po.make_edge_data(na)
+    N, E = bn.numel(), be.numel()
+    center = t(g['center'])
+    state = torch.get_rng_state()
+    try:
+        torch.manual_seed(int(g['sample_seed']))
+        pos0 = torch.randn(N, 3) - center                                               # Appendix B items 3-4
+        un0, ue0 = torch.rand(N, 12, dtype=torch.float64), torch.rand(E, 6, dtype=torch.float64)
+        draws = [(torch.rand(N, 12), torch.rand(E, 6), torch.randn(N, 3)) for _ in range(T)]
+    finally:
+        torch.set_rng_state(state)
+    assert all(float(d[0].double().sum()) == g['u_node_sum'][i] and float(d[1].double().sum()) == g['u_edge_sum'][i]
+               for i, d in enumerate(draws)), 'torch CPU generator stream differs from the one the fixture was recorded with'
+    assert np.abs(np.array([float(d[2].double().sum()) for d in draws]) - g['eps_sum']).max() < 1e-4
+    assert np.allclose(pos0.numpy(), g['pos_init'], rtol=0, atol=2e-6) and np.array_equal(g['traj_pos'][0], g['pos_init'])   # (randn: last ulp may differ between CPU kinds)
+    log_pn = torch.log(torch.from_numpy(o.tab_node['init_prob']) + 1e-30).clamp_min(-32.)
+    log_pe = torch.log(torch.from_numpy(o.tab_edge['init_prob']) + 1e-30).clamp_min(-32.)
+    assert np.array_equal(po.gumbel_argmax(log_pn.unsqueeze(0).repeat(N, 1), un0).numpy(), g['traj_node'][0])
+    assert np.array_equal(po.gumbel_argmax(log_pe.unsqueeze(0).repeat(E, 1), ue0).numpy(), g['traj_edge'][0])
+    hp, pp, pn = t(g['phore_x']).repeat(B, 1), t(g['phore_pos']).repeat(B, 1), t(g['phore_norm']).repeat(B, 1)
+    bp = torch.repeat_interleave(torch.arange(B), p)
+    pc = t(g['phore_pos'])[t(g['phore_x'])[:, 12] != 1].mean(0)
+    ck = list(g['ck_steps'])
+    worst = 0.0
+    with torch.no_grad():
+        for after in (49, 499, 949):
+            k = ck.index(after)
+            pos, log_node, log_edge = t(g['ck_pos'][k]), t(g['ck_log_node'][k]), t(g['ck_log_edge'][k])
+            h_node = F.one_hot(t(g['traj_node'][after + 1]).long(), 12).float()
+            h_edge = F.one_hot(t(g['traj_edge'][after + 1]).long(), 6).float()
+            for i in range(after + 1, after + 11):
+                tt = torch.full((B,), T - 1 - i)
+                v, x0, bond, _ = o.forward(h_node, pos, bn, h_edge, ei, be, tt, hp, pp, pn, bp)
+                un, ue, eps = draws[i]
+                log_node = po.q_v_posterior(o.tab_node, F.log_softmax(v, -1), log_node, tt, bn)
+                h_node = F.one_hot(po.gumbel_argmax(log_node, un), 12).float()
+                log_edge = po.q_v_posterior(o.tab_edge, F.log_softmax(bond, -1), log_edge, tt, be)
+                h_edge = F.one_hot(po.gumbel_argmax(log_edge, ue), 6).float()
+                grad = po.guidance_grad(guid, pos, bn, h_edge, ei, be, B, pc) if guid else 0.
+                pos = po.pos_prev_from_recon(o.tab_pos, pos, x0, tt, bn, eps, grad)
+                assert np.array_equal(h_node.argmax(-1).numpy(), g['traj_node'][i + 1]), (name, i)
+                assert np.array_equal(h_edge.argmax(-1).numpy(), g['traj_edge'][i + 1]), (name, i)
+                worst = max(worst, float((pos + center - t(g['traj_pos'][i + 1])).norm(dim=-1).max()))
+    assert worst <= 1e-5, worst
+
+
 def _train_batch(g):
     keys = ('ligand_x', 'ligand_pos', 'ligand_batch', 'ligand_ptr', 'f_edge_index', 'f_edge_attr', 'f_edge_batch',
             'phore_x', 'phore_pos', 'phore_norm', 'phore_batch') + (('edge_index',) if 'edge_index' in g.files else ())
