@@ -192,7 +192,7 @@ def algorithmic_counts(n_at, n_ph, knn=32, H=128):
     tiles = int((triplet_tiles(n_at) * n_at * (n_at - 1)).sum())
     tri_exec = tiles * 112 * 2048 + e_bond * (2 * 2 * H * H)
     return dict(n_all=n_all, n_lig=n_lig, e_knn=e_knn, e_bond=e_bond, e3=e3, flops_step=6 * layer_f,
-                flops_triplet_kernel=tri_kernel, flops_triplet_executed=tri_exec, tri_tiles=tiles, bytes_step=step_b,
+                flops_triplet_kernel=tri_kernel, flops_triplet_executed=tri_exec, flops_triplet_mfma=tiles * 112 * 2048, tri_tiles=tiles, bytes_step=step_b,
                 tri_useful_rows=e3, tri_padded_rows=16 * tiles)      # (e3 = n(n-1)(n-2) useful rows)
 
 
@@ -241,6 +241,26 @@ def cpu_baseline(work, n_sample_graphs=8, n_steps=3, max_threads=16):
     return dict(value=graph_steps / 128.0, unit='denoise-steps/s (128-graph batch)', cores=cores, kind='port',
                 sample=f'K = {n_steps} timed reverse steps (+1 warm-up) of oracle/phoregen_oracle.py on the first {n_sample_graphs} '
                        f'graphs ({N} atoms, {E} bond edges) of the workload, {dt:.2f} s/step, scaled linearly to 128 graphs')
+
+
+def measured_mfma_peak(dev):
+    """fp32 matrix rate this GPU sustains now (TFLOP/s): pg_micro_mfma_f32 (csrc/micro.hip: 4 waves per SIMD issuing nothing but
+    v_mfma_f32_16x16x4_f32), best of 3 launches of ~1.7 ms, HIP events on the launch stream.  After the timed region."""
+    import ctypes as C
+    from phoregen_amd import hip
+    lib = hip.lib()
+    sink = torch.zeros(16, device=dev)
+    flops = C.c_double()
+    best = 0.0
+    for it in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        hip.check(lib.pg_micro_mfma_f32(1024, 200 if it == 0 else 2000, sink.data_ptr(), C.byref(flops), hip.stream_ptr()), 'pg_micro_mfma_f32')
+        b.record()
+        b.synchronize()
+        if it:
+            best = max(best, flops.value / (a.elapsed_time(b) * 1e-3) / 1e12)
+    return best
 
 
 def _free_port():
@@ -419,6 +439,8 @@ def main():
         exec_tf = counts['flops_triplet_executed'] / (tri_avg_ms * 1e-3) / 1e12 if tri_ms else None
         alg_tf = counts['flops_triplet_kernel'] / (tri_avg_ms * 1e-3) / 1e12 if tri_ms else None
         traffic, traffic_src = _traffic_record('pg::triplet')
+        meas_tf = measured_mfma_peak(dev)
+        mfma_only_tf = counts['flops_triplet_mfma'] / (tri_avg_ms * 1e-3) / 1e12 if tri_ms else None
         scale = 1.0 if not args.weak else float(world)
         line = {
             'metric': 'denoise-steps/sec (batch=128, ~40-atom graphs)', 'value': scale * K / dt, 'unit': 'steps/s',
@@ -438,6 +460,12 @@ def main():
             'roofline': {'kernel': 'triplet kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 sub-layers/step' + (': each as two launches, ligands of up to 49 atoms on the 3-tile instance and the larger ones behind them' if getattr(run, 'tri_launches', 6) > 6 else '') + '), rank 0',
                          'bound': 'mfma', 'achieved': exec_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': (exec_tf / peak_tf) if exec_tf else None, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'frac_mfma_only': (mfma_only_tf / peak_tf) if mfma_only_tf else None,
+                         'peak_measured': meas_tf, 'frac_vs_measured_peak': (exec_tf / meas_tf) if exec_tf else None,
+                         'frac_mfma_only_vs_measured_peak': (mfma_only_tf / meas_tf) if mfma_only_tf else None,
+                         'peak_note': '`peak` = nominal dense fp32 MFMA rate (MI355X_MICROARCH.md); `peak_measured` = pg_micro_mfma_f32 in this '
+                                      'process after the timed region (4 waves per SIMD issuing only v_mfma_f32_16x16x4_f32, best of 3 launches); '
+                                      '`frac_mfma_only` leaves the query fold / value unfold (vector-ALU FLOPs) out of the numerator',
                          'avg_launch_ms': tri_avg_ms, 'launches_timed': len(tri_ms),
                          'timed_in': f'block {R} of {R} of the timed region (every launch of its {K} steps; HIP events on the launch stream)',
                          'flops_per_launch': counts['flops_triplet_executed'],

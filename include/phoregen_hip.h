@@ -67,6 +67,11 @@ int pg_program_run(void* prog, void* const* streams /*[PG_PROGRAM_LANES] hipStre
 int pg_program_length(void* prog);
 int pg_program_destroy(void* prog);
 
+/* ---- measurement aid: `workgroups` x 4 waves issue `iters` x 16 v_mfma_f32_16x16x4_f32 each (8 independent chains) and nothing else;
+ * *flops (host, optional) = the FLOPs of the launch.  bench.py times it with HIP events: the fp32 matrix rate this GPU sustains,
+ * quoted beside the nominal peak.  1024 workgroups = 4 waves per SIMD of 256 CUs. */
+int pg_micro_mfma_f32(int workgroups, int iters, float* sink, double* flops, void* stream);
+
 /* ---- MFMA lane-map self test (device writes 0 on success) -------------------------------- */
 int pg_selftest_mfma(int* d_result, void* stream);
 /* ---- raw words of the device generator (Philox4x32-10, Salmon et al. SC'11) for known-answer tests:

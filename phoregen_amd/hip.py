@@ -92,6 +92,7 @@ _PROTOS = {
     'pg_program_run': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     'pg_program_length': (C.c_int, [C.c_void_p]),
     'pg_program_destroy': (C.c_int, [C.c_void_p]),
+    'pg_micro_mfma_f32': (C.c_int, [C.c_int, C.c_int, c_fp, C.POINTER(C.c_double), C.c_void_p]),
     'pg_selftest_mfma': (C.c_int, [c_ip, C.c_void_p]),
     'pg_selftest_philox': (C.c_int, [c_ip, C.c_int, c_ip, C.c_void_p]),
     'pg_debug_force_generic_seg': (C.c_int, [C.c_int]),
