@@ -829,8 +829,9 @@ class Engine:
         return w.out_v, x0, w.out_bond
 
 
-def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, batch, phore_norm, return_all):
-    """Entry used by models.uni_denoiser.UniTransformerO2TwoUpdateGeneralBond.forward (ctx-ordered inputs)."""
+def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, batch, phore_norm, return_all, record=False):
+    """Entry used by models.uni_denoiser.UniTransformerO2TwoUpdateGeneralBond.forward (ctx-ordered inputs).  `record`: gradients are
+    being recorded -> the autograd-composed form of the same kernels (training.TrainForward.denoise) instead of the launch list."""
     from .plan import BatchPlan
     dev = h.device
     if dev.type != 'cuda':
@@ -845,6 +846,17 @@ def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, b
     plan = BatchPlan(batch[lig_ctx], batch[ph_ctx], edge_index, batch[lig_ctx][edge_index[0]], B, dev)
     if not torch.equal(plan.lig2ctx_long, lig_ctx):
         raise ValueError('phoregen_amd: context must be ordered [phore..., ligand...] per graph (compose_context)')
+    if record:
+        from .training import TrainForward
+        params = {'denoiser.' + k: v for k, v in {**dict(module.named_buffers()), **dict(module.named_parameters())}.items()}
+        tf = TrainForward(params, plan, knn_k=module.k, num_layers=module.num_layers, denoiser_only=True)
+        hb_in = h_bond.float() if plan.edge_identity else h_bond.float().index_select(0, plan.edge_ref_long)    # internal bond order
+        nrm_ph = torch.zeros(h.size(0), 3, dtype=torch.float32, device=dev).index_copy(0, plan.phore2ctx_long, phore_norm.float())
+        h_out, x_out, hb_out = tf.denoise(h.float(), x.float(), hb_in, nrm_ph)
+        out = {'x': x_out, 'h': h_out, 'h_bond': hb_out if plan.edge_identity else hb_out.index_select(0, plan.edge_int_long)}
+        if return_all:
+            out.update(all_x=[x, out['x']], all_h=[h, out['h']], all_h_bond=[h_bond, out['h_bond']])
+        return out
     sd = {'denoiser.' + k: v for k, v in module.state_dict().items()}
     eng = Engine(_DenoiserOnlyPack(sd, module.num_layers), plan, knn_k=module.k, full=False)
     w = eng.ws

@@ -117,12 +117,9 @@ class UniTransformerO2TwoUpdateGeneralBond(nn.Module):
         if mask_ligand_atom is not None and mask_ligand_atom is not mask_ligand and \
                 not torch.equal(mask_ligand_atom.bool(), mask_ligand.bool()):
             raise NotImplementedError('phoregen_amd: mask_ligand_atom must equal mask_ligand (diffusion.py:208-216 passes one mask)')
-        if torch.is_grad_enabled() and (h.requires_grad or x.requires_grad or h_bond.requires_grad or
-                                        any(p.requires_grad for p in self.parameters())):
-            # this entry runs the forward kernels only; gradients are recorded through PhoreDiff.forward / compute_loss, whose
-            # tape holds the HIP adjoints of the same layers (phoregen_amd/training.py)
-            raise RuntimeError('phoregen_amd: UniTransformerO2TwoUpdateGeneralBond.forward (the denoiser module on its own) does not '
-                               'record gradients; call it under torch.no_grad(), or differentiate through PhoreDiff.forward / '
-                               'PhoreDiff.compute_loss')
+        # like the reference's module, differentiable when gradients are being recorded (the same kernels with their HIP adjoints on the
+        # autograd tape, phoregen_amd/training.py); under torch.no_grad() the pre-built launch list of the sampler runs instead
+        record = torch.is_grad_enabled() and (h.requires_grad or x.requires_grad or h_bond.requires_grad or
+                                              any(p.requires_grad for p in self.parameters()))
         from ..engine import denoiser_forward_standalone
-        return denoiser_forward_standalone(self, h, x, bond_index, h_bond, mask_ligand, batch, phore_norm, return_all)
+        return denoiser_forward_standalone(self, h, x, bond_index, h_bond, mask_ligand, batch, phore_norm, return_all, record=record)

@@ -478,10 +478,15 @@ def rows(x, idx):
 class TrainForward:
     """Differentiable PhoreDiff.forward on one batch plan (same launch order as engine.Engine, autograd-composed)."""
 
-    def __init__(self, params, plan, knn_k=32, num_layers=6, ex_col=12):
+    def __init__(self, params, plan, knn_k=32, num_layers=6, ex_col=12, denoiser_only=False):
         self.lib = hip.lib()
         self.sd, self.plan, self.k, self.L, self.ex_col = params, plan, knn_k, num_layers, ex_col
-        self.pack = ModelPack(params, num_layers, detach=False)
+        if denoiser_only:       # the denoiser module on its own (models/uni_denoiser.py forward under autograd): its layers, nothing else
+            from .packing import LayerPack
+            self.pack = type('DenoiserPack', (), {})()
+            self.pack.layers = LayerPack(params, [f'denoiser.base_block.{l}' for l in range(num_layers)]).unstack(num_layers)
+        else:
+            self.pack = ModelPack(params, num_layers, detach=False)
         self.dev = plan.device
 
     # -- one attention sub-layer. `blk(c0, c1)` yields columns [c0, c1) of its first-layer blocks
@@ -567,6 +572,19 @@ class TrainForward:
         x = torch.zeros(n, 3, dtype=torch.float32, device=dev).index_copy(0, p.lig2ctx_long, pos_pert.float())
         x = x.index_copy(0, p.phore2ctx_long, pos_phore.float())
         nrm_ph = torch.zeros(n, 3, dtype=torch.float32, device=dev).index_copy(0, p.phore2ctx_long, phore_norm.float())
+        h, x, hb = self.denoise(h, x, hb, nrm_ph)
+        v0, b0 = pk.v0, pk.b0
+        v = linear(shifted_softplus(linear(h.index_select(0, p.lig2ctx_long), v0[0], v0[1])), v0[2], v0[3])
+        bond = linear(shifted_softplus(linear(hb, b0[0], b0[1])), b0[2], b0[3])
+        if not p.edge_identity:
+            bond = bond.index_select(0, p.edge_int_long)                    # back to the caller's edge order
+        return v, x.index_select(0, p.lig2ctx_long), bond, counts
+
+    def denoise(self, h, x, hb, nrm_ph):
+        """UniTransformerO2TwoUpdateGeneralBond.forward (uni_denoiser.py:396-430) on ctx-ordered h [n,128], x [n,3], bond rows hb [E,128] in
+        the plan's internal order, pharmacophore normals in ctx rows: knn graph + gate once, then the layers.  -> (h, x, hb)."""
+        p, pk, sd, dev, lib = self.plan, self.pack, self.sd, self.dev, self.lib
+        n, E = p.n_ctx, p.n_bond
         is_lig = p.ctx_is_lig.bool().unsqueeze(-1)
 
         # knn graph + global edge gate, once per forward (uni_denoiser.py:396-415)
@@ -634,10 +652,4 @@ class TrainForward:
                                   max_rows=max_lig)
             x = x + (dxe + dxb) * is_lig.to(x.dtype)
             h, hb = h_new, hb_new
-
-        v0, b0 = pk.v0, pk.b0
-        v = linear(shifted_softplus(linear(h.index_select(0, p.lig2ctx_long), v0[0], v0[1])), v0[2], v0[3])
-        bond = linear(shifted_softplus(linear(hb, b0[0], b0[1])), b0[2], b0[3])
-        if not p.edge_identity:
-            bond = bond.index_select(0, p.edge_int_long)                    # back to the caller's edge order
-        return v, x.index_select(0, p.lig2ctx_long), bond, counts
+        return h, x, hb

@@ -294,6 +294,44 @@ def test_two_pass_adjoints_equal_the_one_wave_form(model):
         assert err < 2e-5, (k, err)
 
 
+@pytest.mark.parametrize('switch', [dict(dgrad_mm=False), dict(rows_sum=False), dict(tri_onepass=False), dict(wide_gemm=False),
+                                    dict(bwd_atom_sort=False), dict(bwd_split='knn'), dict(bwd_grid=64)])
+def test_every_training_switch_gives_the_default_paths_gradients(model, switch):
+    """options.py keeps a handful of reachable variants of the training path (the in-tree tiled GEMM instead of the library GEMM for the
+    input gradients, atomic index_add instead of pg_bond_rows_sum, the generic two-pass triplet / node adjoints instead of the one-pass
+    forms fed by the forward's softmax weights, one GEMM per first-layer block instead of the wide one, the triplet adjoint without
+    the cost-sorted atom order, the knn-only split, a smaller persistent grid).  Each of them must give the default path's loss and
+    gradients on a ragged batch (same sums, other association / atomic order: <= 2e-5 relative per parameter; the loss to 1e-6)."""
+    from oracle.make_inputs import synthetic_train_batch
+    from phoregen_amd import options
+    from phoregen_amd.data import TrainBatch
+    b = synthetic_train_batch(79, [2, 21, 3, 50, 9], [5, 33, 4, 12, 30])
+    gen = torch.Generator().manual_seed(7)
+    N, E = b['ligand_x'].numel(), b['f_edge_attr'].numel()
+    draws = dict(time_draw=torch.tensor([620, 870, 415, 77, 940]), pos_noise=torch.randn(N, 3, generator=gen),
+                 u_node=torch.rand(N, 12, generator=gen), u_edge=torch.rand(E, 6, generator=gen))
+    keys = ('ligand_x', 'ligand_pos', 'ligand_batch', 'ligand_ptr', 'f_edge_index', 'f_edge_attr', 'f_edge_batch',
+            'phore_x', 'phore_pos', 'phore_norm', 'phore_batch')
+    out = {}
+    for name, kw in (('default', {}), ('variant', switch)):
+        with options.override(**kw):
+            model._plan = None
+            model.zero_grad()
+            loss, _ = model.compute_loss(TrainBatch(*[b[k] for k in keys]), draws=draws)
+            loss.backward()
+        out[name] = (float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert abs(out['variant'][0] - out['default'][0]) <= 1e-6 * abs(out['default'][0]), (out['variant'][0], out['default'][0])
+    ref, var = out['default'][1], out['variant'][1]
+    assert ref.keys() == var.keys()
+    gmax = max(float(v.norm()) for v in ref.values())
+    worst = 0.0
+    for k, r in ref.items():
+        if float(r.norm()) < 1e-6 * gmax:
+            continue
+        worst = max(worst, float((var[k].double() - r.double()).norm() / r.double().norm()))
+    assert worst < 2e-5, (switch, worst)
+
+
 def test_gradients_with_a_maximum_size_ligand(model):
     """A 78-atom ligand (the reference's max_atom; 5 row tiles, the 2-wave triplet adjoint) next to a 5-atom one."""
     from oracle import phoregen_oracle as po
@@ -433,13 +471,45 @@ def test_forward_is_differentiable_like_the_reference(model):
     errs['pos_pert'] = float((pos.grad.cpu() - pos_ref.grad).norm() / pos_ref.grad.norm())
     print({k: f'{e:.1e}' for k, e in errs.items()})
     assert max(errs.values()) <= GRAD_TOL, errs
-    # the denoiser module on its own runs the forward kernels only: under autograd it says so instead of returning constants
-    with pytest.raises(RuntimeError, match='does not record gradients'):
-        z = torch.zeros(4, 128, device='cuda')
-        model.denoiser(z, torch.zeros(4, 3, device='cuda'), None, torch.zeros(2, 0, dtype=torch.long, device='cuda'),
-                       torch.zeros(0, 128, device='cuda'), torch.ones(4, dtype=torch.bool, device='cuda'), None,
-                       torch.zeros(4, dtype=torch.long, device='cuda'))
     model.eval()
+
+
+def test_denoiser_module_on_its_own_is_differentiable_like_the_reference(model):
+    """uni_denoiser.py:396-430 called directly (`model.denoiser(h, x, None, bond_index, h_bond, mask, mask, batch, phore_norm)`) in the
+    default state of a loaded model -- grad mode on, parameters requiring grad -- returns the no_grad launch list's values WITH a
+    gradient function; a functional of its outputs reaches its parameters and inputs with the gradients autograd gives through the
+    oracle's restatement of the same module (reference recorded inputs: G3 fixture, layer 0 in)."""
+    g = golden('g3_forward_a')
+    dev = 'cuda'
+    h, x, bi, hb, mask, batch, pn = (t(g['L0_in_' + k]) for k in ('h', 'x', 'bond_index', 'h_bond', 'mask_ligand', 'batch', 'phore_norm'))
+    gen = torch.Generator().manual_seed(3)
+    R = [torch.randn(h.shape, generator=gen), torch.randn(x.shape, generator=gen), torch.randn(hb.shape, generator=gen)]
+    # oracle: the same module restated, differentiated by autograd
+    orc = make_oracle(0)
+    probe = ['denoiser.edge_pred_layer.net.0.weight', 'denoiser.base_block.0.bond_layer.hk_func.net.0.weight',
+             'denoiser.base_block.2.node_layer_with_edge.hv_func.net.3.weight', 'denoiser.base_block.5.pos_layer_with_bond.xq_func.net.0.weight',
+             'denoiser.base_block.4.lin_node.weight']
+    for k in probe:
+        orc.sd[k].requires_grad_(True)
+    h_ref = h.clone().requires_grad_(True)
+    ho, hbo, xo = orc.denoiser(h_ref, x, bi, hb, mask.bool(), batch, pn)
+    ((ho * R[0]).sum() + (xo * R[1]).sum() + (hbo * R[2]).sum()).backward()
+    # HIP: module forward under autograd vs under no_grad
+    model.zero_grad(set_to_none=True)
+    args = [a.to(dev) for a in (h, x)] + [None, bi.to(dev), hb.to(dev), mask.to(dev), mask.to(dev), batch.to(dev)]
+    h_in = args[0].clone().requires_grad_(True)
+    out = model.denoiser(h_in, *args[1:], phore_norm=pn.to(dev))
+    assert all(out[k].requires_grad for k in ('h', 'x', 'h_bond'))
+    with torch.no_grad():
+        fast = model.denoiser(*args, phore_norm=pn.to(dev))
+    for k in ('h', 'x', 'h_bond'):
+        assert rel_err(out[k].detach().cpu(), fast[k].cpu()) <= 2e-5, k
+        assert rel_err(out[k].detach().cpu(), g['L5_out_' + k]) <= 2e-5, k
+    ((out['h'] * R[0].to(dev)).sum() + (out['x'] * R[1].to(dev)).sum() + (out['h_bond'] * R[2].to(dev)).sum()).backward()
+    params = dict(model.named_parameters())
+    errs = {k: float((params[k].grad.cpu() - orc.sd[k].grad).norm() / orc.sd[k].grad.norm().clamp(min=1e-30)) for k in probe}
+    errs['h'] = float((h_in.grad.cpu() - h_ref.grad).norm() / h_ref.grad.norm())
+    assert max(errs.values()) <= GRAD_TOL, errs
 
 
 def test_config5_full_size_gradient_of_a_graph_inside_the_batch_equals_the_graph_alone(model):
