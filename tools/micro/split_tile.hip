@@ -50,6 +50,22 @@ __device__ __forceinline__ void split_f16(const float* x, h8& hi, h8& lo) {
   }
 }
 
+// ---- robust 2-term f16 split: lo' = (x - hi) * 2^11 (the MFMA flushes f16 subnormals: an unscaled residual of |x| < 2^-3 would be lost);
+//      products with ONE lo' factor are accumulated apart and folded in with 2^-11 ----
+__device__ __forceinline__ void split_f16s(const float* x, h8& hi, h8& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x[2 * p], x[2 * p + 1]));
+    float r0, r1;
+    const unsigned hp = __builtin_bit_cast(unsigned, h);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hp), "v"(x[2 * p]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hp), "v"(x[2 * p + 1]));
+    const h2 l = __builtin_convertvector((f2){r0 * 2048.0f, r1 * 2048.0f}, h2);
+    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
+  }
+}
+
 // ---- 3-term bf16 split of 8 floats: hi = top 16 bits of x, mid = top 16 bits of (x - hi), lo = top 16 bits of (x - hi - mid) ----
 __device__ __forceinline__ unsigned pack_top16(float a, float b) {      // (a's top half in the low 16 bits, b's in the high): one v_perm_b32
   return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, a), 0x07060302u);
@@ -104,6 +120,10 @@ __global__ __launch_bounds__(768) void tile_kernel(float* out, unsigned long lon
 #pragma unroll
         for (int t = 0; t < 4; ++t) split_f16<MODE == 3>(U + 8 * t, Uh[t], Ul[t]);
       }
+      if constexpr (MODE == 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) split_f16s(U + 8 * t, Uh[t], Ul[t]);
+      }
       if constexpr (MODE == 2) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) split_bf16(U + 8 * t, Ubh[t], Ubm[t], Ubl[t]);
@@ -129,6 +149,18 @@ __global__ __launch_bounds__(768) void tile_kernel(float* out, unsigned long lon
         lg = mfma_f16(zl, Uh[t], lg);
         lg = mfma_f16(zh, Uh[t], lg);
       }
+    } else if constexpr (MODE == 4) {
+      f4 x4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        h8 zh, zl;
+        split_f16s(z + 8 * t, zh, zl);
+        x4 = mfma_f16(zh, Ul[t], x4);
+        x4 = mfma_f16(zl, Uh[t], x4);
+        lg = mfma_f16(zh, Uh[t], lg);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lg[r] = __builtin_fmaf(x4[r], 1.0f / 2048.0f, lg[r]);
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -165,6 +197,26 @@ __global__ __launch_bounds__(768) void tile_kernel(float* out, unsigned long lon
           sT[2 * q + o] = mfma_f16(xh, al, sT[2 * q + o]);
           sT[2 * q + o] = mfma_f16(xl, ah, sT[2 * q + o]);
           sT[2 * q + o] = mfma_f16(xh, ah, sT[2 * q + o]);
+        }
+      }
+    } else if constexpr (MODE == 4) {
+      const float aw8[8] = {aw[0], aw[1], aw[2], aw[3], 0.f, 0.f, 0.f, 0.f};
+      h8 ah, al;
+      split_f16s(aw8, ah, al);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        h8 a, b;
+        split_f16s(z + 8 * q, a, b);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          h8 xh = {a[4 * o], a[4 * o + 1], a[4 * o + 2], a[4 * o + 3], 0, 0, 0, 0};
+          h8 xl = {b[4 * o], b[4 * o + 1], b[4 * o + 2], b[4 * o + 3], 0, 0, 0, 0};
+          f4 x4 = mfma_f16(xh, al, (f4){0.f, 0.f, 0.f, 0.f});
+          x4 = mfma_f16(xl, ah, x4);
+          f4 t = mfma_f16(xh, ah, sT[2 * q + o]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[r] = __builtin_fmaf(x4[r], 1.0f / 2048.0f, t[r]);
+          sT[2 * q + o] = t;
         }
       }
     } else {
@@ -231,6 +283,18 @@ __global__ __launch_bounds__(64) void check_kernel(const float* Z /*[16][128]*/,
       acc = mfma_f16(zl, uh, acc);
       acc = mfma_f16(zh, uh, acc);
     }
+  } else if constexpr (MODE == 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      h8 zh, zl, uh, ul;
+      split_f16s(z + 8 * t, zh, zl);
+      split_f16s(u + 8 * t, uh, ul);
+      acc2 = mfma_f16(zh, ul, acc2);
+      acc2 = mfma_f16(zl, uh, acc2);
+      acc = mfma_f16(zh, uh, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[r] = __builtin_fmaf(acc2[r], 1.0f / 2048.0f, acc[r]); acc2[r] = 0.f; }
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -247,8 +311,8 @@ __global__ __launch_bounds__(64) void check_kernel(const float* Z /*[16][128]*/,
   for (int r = 0; r < 4; ++r) R[(4 * g + r) * 16 + m] = acc[r] + acc2[r];
 }
 
-static const char* kName[4] = {"fp32   64 x v_mfma_f32_16x16x4_f32", "f16x2  36 x v_mfma_f32_16x16x32_f16 + split", "bf16x3 72 x v_mfma_f32_16x16x32_bf16 + split",
-                                "f16x2+ 48 x ..x32_f16: lo rounded + lo.lo term"};
+static const char* kName[5] = {"fp32   64 x v_mfma_f32_16x16x4_f32", "f16x2  36 x v_mfma_f32_16x16x32_f16 + split", "bf16x3 72 x v_mfma_f32_16x16x32_bf16 + split",
+                                "f16x2+ 48 x ..x32_f16: lo rounded + lo.lo term", "f16x2s 36 x ..x32_f16: residual scaled 2^11, folded"};
 
 template <int MODE> void bench(float* out, unsigned long long* clk, int tiles) {
   const int wgs = 256, waves = wgs * 12;
@@ -283,10 +347,10 @@ int main(int argc, char** argv) {
   const int tiles = argc > 1 ? atoi(argv[1]) : 6000;
   float* out; unsigned long long* clk;
   hipMalloc(&out, 256 * 768 * 4); hipMalloc(&clk, 256 * 12 * 16);
-  for (int rep = 0; rep < 2; ++rep) { bench<0>(out, clk, tiles); bench<1>(out, clk, tiles); bench<3>(out, clk, tiles); bench<2>(out, clk, tiles); }
+  for (int rep = 0; rep < 2; ++rep) { bench<0>(out, clk, tiles); bench<1>(out, clk, tiles); bench<3>(out, clk, tiles); bench<4>(out, clk, tiles); bench<2>(out, clk, tiles); }
   // ---- numerics on LayerNorm-ed rows: z = ReLU(LN(x) * gamma + beta), U = query-folded weights ~ N(0, 0.3) ----
   float *dZ, *dU, *dR; hipMalloc(&dZ, 16 * 128 * 4); hipMalloc(&dU, 128 * 16 * 4); hipMalloc(&dR, 1024);
-  double worst[4] = {0, 0, 0, 0};
+  double worst[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   srand(12345);
   auto gauss = []() { double a = 0; for (int i = 0; i < 12; ++i) a += rand() / (double)RAND_MAX; return a - 6.0; };
   for (int trial = 0; trial < 200; ++trial) {
@@ -299,15 +363,19 @@ int main(int argc, char** argv) {
       const double rs = 1.0 / sqrt(var / 128 + 1e-5);
       for (int c = 0; c < 128; ++c) Z[r * 128 + c] = (float)fmax((x[c] - mu) * rs * (0.5 + (c % 5) * 0.3) + 0.1 * ((c % 3) - 1), 0.0);
     }
-    for (auto& u : U) u = (float)(gauss() * 0.3);
+    const int small = trial & 1;          // odd trials: U ~ N(0, 0.02) -- the f16 residual of such values is subnormal (< 2^-14)
+    for (auto& u : U) u = (float)(gauss() * (small ? 0.02 : 0.3));
     std::vector<double> ref(256, 0.0);
     for (int r = 0; r < 16; ++r) for (int h = 0; h < 16; ++h) { double a = 0; for (int c = 0; c < 128; ++c) a += (double)Z[r * 128 + c] * (double)U[c * 16 + h]; ref[r * 16 + h] = a; }
     hipMemcpy(dZ, Z.data(), Z.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice);
-    worst[0] = fmax(worst[0], check<0>(Z, U, ref, dZ, dU, dR));
-    worst[1] = fmax(worst[1], check<1>(Z, U, ref, dZ, dU, dR));
-    worst[2] = fmax(worst[2], check<2>(Z, U, ref, dZ, dU, dR));
-    worst[3] = fmax(worst[3], check<3>(Z, U, ref, dZ, dU, dR));
+    worst[small][0] = fmax(worst[small][0], check<0>(Z, U, ref, dZ, dU, dR));
+    worst[small][1] = fmax(worst[small][1], check<1>(Z, U, ref, dZ, dU, dR));
+    worst[small][2] = fmax(worst[small][2], check<2>(Z, U, ref, dZ, dU, dR));
+    worst[small][3] = fmax(worst[small][3], check<3>(Z, U, ref, dZ, dU, dR));
+    worst[small][4] = fmax(worst[small][4], check<4>(Z, U, ref, dZ, dU, dR));
   }
-  for (int mo = 0; mo < 4; ++mo) printf("%-46s max |error| / max |result| vs float64 over 200 tiles of LayerNorm-ed rows: %.2e\n", kName[mo], worst[mo]);
+  for (int mo = 0; mo < 5; ++mo)
+    printf("%-52s max |error| / max |result| vs float64, 100 tiles of LayerNorm-ed rows each: U ~ N(0, 0.3): %.2e   U ~ N(0, 0.02): %.2e\n",
+           kName[mo], worst[0][mo], worst[1][mo]);
   return 0;
 }
