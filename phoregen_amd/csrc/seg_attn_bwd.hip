@@ -1090,7 +1090,10 @@ extern "C" int pg_debug_bwd_prof(unsigned long long* out, int reset) {
 }
 #endif
 
-extern "C" int pg_seg_attn_bwd_waves(int mode) { (void)mode; return 4; }
+// waves per workgroup the row buffer must be sized for (PgSegAttnGrad.rowbuf: grid x waves x rows x 48 floats): the LARGEST workgroup of any
+// form this mode can be launched in -- the generic / one-wave forms use 4 waves, the triplet's value pass of the two-pass form 8 (the
+// one-pass kernels do not touch the buffer today; sizing it for them anyway keeps a later change from writing past it)
+extern "C" int pg_seg_attn_bwd_waves(int mode) { return mode == PG_SEG_TRIPLET ? 8 : 4; }
 
 extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, void* stream) {
   if (!t || !p || !gr) { set_error("pg_seg_attn_bwd: null argument"); return PG_ERR_ARG; }

@@ -25,6 +25,45 @@ def _st():
     return hip.stream_ptr()
 
 
+class _ZeroPool:
+    """Small zero-filled buffers of one training step from ONE fill launch.  The adjoints accumulate weight / bias / coordinate gradients
+    with atomics into caller-zeroed memory: ~800 buffers per step, most of them a few KB, each a `torch.zeros` = one 4 us fill launch on
+    the critical stream (profiles/r05_train_kernel_stats.md: 817 fills = 3.4 ms per step).  A step takes them as 64-byte-aligned views
+    of one block, allocated and filled at the step's first request with the size the previous step needed (a request that does not fit,
+    or is larger than `max_bytes`, is an ordinary torch.zeros).  The block is NEW memory every step (never re-zeroed in place): a
+    gradient that autograd hands on as a view of it -- p.grad of an identity-packed parameter -- keeps its block alive and is never
+    overwritten by a later step."""
+
+    def __init__(self, max_bytes=1 << 20):
+        self.max_bytes, self.need, self.block, self.off, self.dev = max_bytes, 0, None, 0, None
+
+    def begin_step(self):
+        self.capacity = (self.need + 1023) // 1024 * 1024       # floats requested by the previous step
+        self.need, self.block, self.off = 0, None, 0
+
+    def zeros(self, *shape, device, dtype=torch.float32):
+        n = 1
+        for d in shape:
+            n *= d
+        if dtype != torch.float32 or n * 4 > self.max_bytes or n == 0:
+            return torch.zeros(*shape, dtype=dtype, device=device)
+        n16 = (n + 15) // 16 * 16
+        self.need += n16
+        if self.block is None and getattr(self, 'capacity', 0) >= n16:
+            self.block, self.off, self.dev = torch.zeros(self.capacity, dtype=torch.float32, device=device), 0, device
+        if self.block is None or self.dev != device or self.off + n16 > self.block.numel():
+            return torch.zeros(*shape, dtype=dtype, device=device)
+        v = self.block[self.off:self.off + n].view(*shape)
+        self.off += n16
+        return v
+
+    def zeros_like(self, t):
+        return self.zeros(*t.shape, device=t.device, dtype=t.dtype)
+
+
+zero_pool = _ZeroPool()
+
+
 def _rowmajor(t):
     return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
 
@@ -43,7 +82,7 @@ def _dgrad(gY, W, gX):
 def _wgrad(gY, X, N, K, want_bias):
     """(gW [N,K], gb [N] | None) = (gY^T X, column sums of gY): pg_gemm_wgrad (row-split partial tiles + atomics).  The library
     GEMM was measured on this contraction over 10^5 rows and is slower (training step 188.5 -> 204.9 ms)."""
-    buf = torch.zeros(N * K + (N if want_bias else 0), dtype=torch.float32, device=X.device)   # one fill for both
+    buf = zero_pool.zeros(N * K + (N if want_bias else 0), device=X.device)   # one fill for both (small ones: a view of the step's zero block)
     gW = buf[:N * K].view(N, K)
     gb = buf[N * K:] if want_bias else None
     hip.check(hip.lib().pg_gemm_wgrad(gY.data_ptr(), gY.stride(0), X.data_ptr(), X.stride(0), X.shape[0], N, K,
@@ -210,7 +249,7 @@ class LnReluFn(torch.autograd.Function):
         X, gamma, beta = ctx.saved_tensors
         gY = _rowmajor(gY)
         gX = torch.empty_like(X)
-        gg, gb = torch.zeros_like(gamma), torch.zeros_like(beta)
+        gg, gb = zero_pool.zeros_like(gamma), zero_pool.zeros_like(beta)
         hip.check(hip.lib().pg_ln_relu_bwd(X.data_ptr(), X.stride(0), gamma.data_ptr(), beta.data_ptr(), gY.data_ptr(),
                                            gY.stride(0), X.shape[0], gX.data_ptr(), gX.stride(0), gg.data_ptr(),
                                            gb.data_ptr(), _st()), 'pg_ln_relu_bwd')
@@ -233,7 +272,7 @@ def _unfold(S, swn, W2_l, b2, ids, n_ids, out):
 
 
 def _fold_wgrad(X, T, ids, n_ids, W2_l):
-    gW = torch.zeros_like(W2_l)
+    gW = zero_pool.zeros_like(W2_l)
     hip.check(hip.lib().pg_attn_fold_wgrad(X.data_ptr(), X.stride(0), T.data_ptr(), n_ids, hip.ptr(ids), gW.data_ptr(),
                                            _st()), 'pg_attn_fold_wgrad')
     return gW
@@ -283,7 +322,7 @@ class UnfoldFn(torch.autograd.Function):
         # launch (five elementwise / reduction passes over [n, 128] in tensor ops; an indexed assignment of a Python scalar there
         # once cost 149 ms per step: it uploads the scalar with a BLOCKING copy)
         gswn = (torch.zeros_like if ctx.ids is not None else torch.empty_like)(swn)
-        gb2 = torch.zeros_like(b2)
+        gb2 = zero_pool.zeros_like(b2)
         hip.check(hip.lib().pg_attn_unfold_bias_grad(gout.data_ptr(), gout.stride(0), swn.data_ptr(), b2.data_ptr(), ctx.n_ids,
                                                      hip.ptr(ctx.ids), gswn.data_ptr(), gb2.data_ptr(), _st()), 'pg_attn_unfold_bias_grad')
         return gS, gswn, _fold_wgrad(gout, S, ctx.ids, ctx.n_ids, W2_l), gb2, None, None
@@ -378,7 +417,7 @@ class SegCoreFn(torch.autograd.Function):
         small = [t[k] for k in ('Wf_k', 'Wf_v', 'bk', 'bv', 'W2xv_l', 'b2xv')] + \
                 [t['x'] if cfg['need_gx'] else None, t['nrm'] if cfg['need_gx'] else None, t['ew']]
         pad4 = lambda k: (k + 3) // 4 * 4                      # (every view starts on a 16-byte boundary)
-        buf = torch.zeros(sum(pad4(x.numel()) for x in small if x is not None), dtype=torch.float32, device=dev)
+        buf = zero_pool.zeros(sum(pad4(x.numel()) for x in small if x is not None), device=dev)
         views, off = [], 0
         for x in small:
             if x is None:
@@ -408,7 +447,7 @@ class SegCoreFn(torch.autograd.Function):
         # one persistent workgroup per CU (the adjoints hold a CU's LDS / registers alone): every workgroup stages its weight tables and
         # flushes its weight-gradient accumulators (hundreds of atomics per wave) ONCE, and no partial last round of workgroups is
         # left -- training step 179.5 ms with 1 024 workgroups, 171-173 with 512, 168 with 256 (320: 205, 8 192: 206)
-        grid = max(1, min((cfg['n_seg'] + waves - 1) // waves, options.get('bwd_grid')))
+        grid = max(1, min((cfg['n_seg'] + 3) // 4, options.get('bwd_grid')))          # (the forms' smallest workgroup has 4 waves)
         rows = (cfg['max_rows'] + 15) // 16 * 16
         rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
         g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
@@ -425,7 +464,8 @@ class SegCoreFn(torch.autograd.Function):
                 g.S, g.swn = S_.data_ptr(), sw_.data_ptr()
                 keep += [S_, sw_]
             split_modes = {'knn': (hip.SEG_KNN_NODE, hip.SEG_KNN_POS), 'all': (hip.SEG_TRIPLET, hip.SEG_KNN_NODE, hip.SEG_KNN_POS)}
-            if cfg['mode'] in split_modes.get(options.get('bwd_split'), ()):
+            # (the library takes the triplet's two-pass form for ligands of up to 64 atoms only: no scratch for a launch that will not use it)
+            if cfg['mode'] in split_modes.get(options.get('bwd_split'), ()) and (cfg['mode'] != hip.SEG_TRIPLET or cfg['max_rows'] <= 64):
                 # scratch of the two-pass form (value pass, then key pass): d logit (position update: one value per row) and the value
                 # pass's d feat rows, indexed like the forward's per-row record
                 n_rows_rec = a_.numel() // (32 if pos else 16)
@@ -558,6 +598,7 @@ class TrainForward:
         return torch.exp(coeff * (t.float().unsqueeze(-1) - off.view(1, -1)) ** 2)
 
     def forward(self, h_node_pert, pos_pert, h_edge_pert, time_step, h_phore, pos_phore, phore_norm, batch_phore):
+        zero_pool.begin_step()
         p, pk, sd, dev, lib = self.plan, self.pack, self.sd, self.dev, self.lib
         n, E = p.n_ctx, p.n_bond
         hp_emb = self.phore_encode(h_phore, pos_phore)
