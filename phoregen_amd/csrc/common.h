@@ -75,7 +75,10 @@ __device__ __forceinline__ float ssp(float v) {  // shifted softplus (models/com
   return sp - 0.69314718055994530942f;
 }
 
-constexpr int kNumCU = 256;
+// compute units of the CURRENT device (256 on an MI355X in SPX mode; a partitioned device reports its share): the persistent grids and
+// the grid caps of the launches are sized from it.  Queried once per device (graph_ops.hip).
+int num_cu();
+#define kNumCU (::pg::num_cu())
 
 #ifdef PG_ABLATE
 inline int ablate_from_env(const char* name) {

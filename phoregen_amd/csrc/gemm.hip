@@ -284,7 +284,7 @@ extern "C" int pg_rows_linear(const float* X, int ldx, int K, const float* W, co
   if (M == 0) return PG_OK;
   if (K == 128 && (ldx & 3) == 0 && ((size_t)X & 15) == 0) {
     int blocks = (M + 63) / 64;
-    if (blocks > 8 * pg::kNumCU) blocks = 8 * pg::kNumCU;
+    if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
     hipLaunchKernelGGL(pg::rows_linear_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, W, b, n_out, M, rows, Y, ldy);
     return pg::check_launch("pg_rows_linear");
   }

@@ -401,6 +401,18 @@ __global__ void atom_count_kernel(const float* s_all, const float* s_l, const ui
   (void)red;
 }
 
+int num_cu() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 }  // namespace pg
 
 using namespace pg;
