@@ -10,8 +10,20 @@ from phoregen_amd.parallel import graph_cost, partition_graphs
 from phoregen_amd.weights import init_deterministic_
 
 model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to('cuda')
-full = ligphore_workload(128, seed=1234)
-W, K = 6, 30
+# `seed=N` / `config4` among the arguments: another draw of the headline shape / a 128-graph batch of the config-4 shape (p ~ N(80, 25), several
+# pharmacophores) -- the cost model and the size thresholds were fitted on seed 1234 only (round-4 review)
+_seed = next((int(a.split('=')[1]) for a in sys.argv[1:] if a.startswith('seed=')), 1234)
+if 'config4' in sys.argv[1:]:
+    from bench import config4_job
+    job = config4_job(n_phores=16, samples=8, seed=_seed)
+    hp, pp, pn, bp, na, _ = job.batch_inputs(torch.arange(128))
+    full = dict(h_phore=hp, pos_phore=pp, phore_norm=pn, batch_phore=bp, num_atoms=na, n_phore=job.n_phore)
+    print(f'workload: 128 graphs of the config-4 shape (16 pharmacophores x 8 samples, seed {_seed})')
+else:
+    full = ligphore_workload(128, seed=_seed)
+    print(f'workload: headline shape, seed {_seed}')
+sys.argv = [a for a in sys.argv if not a.startswith('seed=') and a != 'config4']
+W, K = 24, 30          # (24 untimed steps: the online choice of the triplet grid of a small share is made inside them)
 
 
 def ms_per_step(work, gids):
