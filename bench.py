@@ -363,7 +363,7 @@ def main():
         n_total = min(W + 32 + R * K, max(T, W + R * K))       # room for up to 32 more untimed steps (grid tuning of small batches, below)
         st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm'], work['batch_phore'],
                                   work['num_atoms'], torch.zeros(int(work['num_atoms'].numel()), 3), rng='device', seed=0,
-                                  return_traj=True, num_steps=n_total, graph_ids=gids)
+                                  return_traj=True, num_steps=n_total, graph_ids=gids, pipeline=True)
         for i in range(W):
             model.reverse_step(st, i, T - 1 - i)
         # small batches time neighbouring triplet grids during their first ~20 steps (Engine._tune_*): those steps stay outside the timed

@@ -140,7 +140,8 @@ int pg_embed_ctx(const PgTopo* t, const float* h_node_pert /*[n_lig,12]*/, const
                  const float* t_offset /*[10]*/, const float* t_coeff /*[10]*/,
                  const float* h_phore_emb /*[n_phore,128]*/, const float* pos_phore /*[n_phore,3]*/,
                  const int* phore2ctx /*[n_phore]*/, float* h_ctx /*[n_ctx,128]*/, float* x_ctx /*[n_ctx,3]*/,
-                 void* stream);
+                 void* stream);      /* h_ctx == NULL / x_ctx == NULL: that half is skipped (the features of the NEXT reverse step are embedded
+                                        as soon as its types are drawn, the coordinates when its positions are: phoregen_amd/engine.py) */
 int pg_embed_bond(const PgTopo* t, const float* h_edge_pert /*[n_bond,6], caller's order (t->edge_ref)*/, const int* bond_graph,
                   const int64_t* time_step, const float* W_edge /*[118,6]*/, const float* t_offset,
                   const float* t_coeff, float* h_bond /*[n_bond,128]*/, void* stream);

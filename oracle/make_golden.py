@@ -263,7 +263,7 @@ def g5_sample(model, name, seed, n_atoms, n_steps, t_total, guidance=None):
 FULL_CK = 50          # g5_sample_full1000*: the carried state is stored after every FULL_CK-th step
 
 
-def g5_sample_full1000(model, name, seed, n_atoms, guidance=None):
+def g5_sample_full1000(model, name, seed, n_atoms, guidance=None, ck_every=FULL_CK, sparse_edge_gaps=False):
     """The reference's own `sample()` for ALL 1000 steps (diffusion.py:391-525), CPU generator seeded right in front of the
     sampler's first draw (`seed_all(seed + 1)` inside the forced atom-count call: a test re-creates the draws by seeding the same
     generator and drawing in the reference's order, SURVEY.md Appendix B -- 3.3 MB of recorded noise stay out of the fixture).
@@ -325,17 +325,26 @@ def g5_sample_full1000(model, name, seed, n_atoms, guidance=None):
         del model.forward
         model.sample_nodes = orig_sample_nodes
     assert calls['n'] == 2 * T and len(rec['pos_in']) == T and len(rec['eps_sum']) == T
-    ck = list(range(FULL_CK - 1, T - 1, FULL_CK))            # loop indices i: the state after step i = the input of step i + 1
+    # loop indices i: the state after step i = the input of step i + 1  (ck_every=None: no checkpoints -- a large fixture stays small)
+    ck = list(range(ck_every - 1, T - 1, ck_every)) if ck_every else []
     arrays = dict(phore_x=data['phore'].x, phore_pos=data['phore'].pos, phore_norm=data['phore'].norm, center=data.center,
                   n_atoms=np.array(n_atoms), sample_seed=np.array(seed + 1), ck_steps=np.array(ck),
                   traj_node=res['traj'][0].argmax(-1).to(torch.int8), traj_pos=res['traj'][1],
                   traj_edge=res['traj'][2].argmax(-1).to(torch.int8),
                   pred_node=res['pred'][0], pred_pos=res['pred'][1], pred_edge=res['pred'][2],
-                  gap_node=torch.stack(rec['gap'][0]), gap_edge=torch.stack(rec['gap'][1]),
+                  gap_node=torch.stack(rec['gap'][0]),
                   scale_node=np.array(rec['scale'][0], dtype=np.float32), scale_edge=np.array(rec['scale'][1], dtype=np.float32),
                   u_node_sum=np.array(rec['usum'][0]), u_edge_sum=np.array(rec['usum'][1]), eps_sum=np.array(rec['eps_sum']),
-                  ck_log_node=torch.stack([rec['post'][0][i] for i in ck]), ck_log_edge=torch.stack([rec['post'][1][i] for i in ck]),
-                  ck_pos=torch.stack([rec['pos_in'][i + 1] for i in ck]), pos_init=rec['pos_in'][0])
+                  pos_init=rec['pos_in'][0])
+    if ck:
+        arrays.update(ck_log_node=torch.stack([rec['post'][0][i] for i in ck]), ck_log_edge=torch.stack([rec['post'][1][i] for i in ck]),
+                      ck_pos=torch.stack([rec['pos_in'][i + 1] for i in ck]))
+    ge = torch.stack(rec['gap'][1])
+    if sparse_edge_gaps:          # thousands of bond rows: only the margins below 0.02 are kept (a row that is not listed had a larger one)
+        st_, row_ = (ge < 0.02).nonzero(as_tuple=True)
+        arrays.update(gap_edge_step=st_.to(torch.int16), gap_edge_row=row_.to(torch.int16), gap_edge_val=ge[st_, row_], gap_edge_floor=np.array(0.02))
+    else:
+        arrays['gap_edge'] = ge
     save(name, **arrays)
 
 
@@ -486,6 +495,8 @@ GUIDANCE = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_
 def full1000_fixtures(model):
     g5_sample_full1000(model, 'g5_sample_full1000_a', seed=2040, n_atoms=[6, 9, 7])
     g5_sample_full1000(model, 'g5_sample_full1000_guid', seed=2041, n_atoms=[8, 6], guidance=GUIDANCE)
+    # ligands of realistic size: 34 atoms = 3 row tiles of the triplet kernel, 21 atoms = 2 (1 542 bond rows; ~15 min of CPU)
+    g5_sample_full1000(model, 'g5_sample_full1000_n34', seed=2042, n_atoms=[34, 21], ck_every=None, sparse_edge_gaps=True)
 
 
 if __name__ == '__main__':
@@ -493,9 +504,13 @@ if __name__ == '__main__':
         model, cfg = build_model(seed=0)
         g6_compute_loss(model, 'g6_loss_len', seed=67, n_atoms=[7, 10, 5], n_phore=[9, 14, 6], bond_len_loss=True)
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'full1000':   # only the full-length free-running fixtures (added in round 5; ~10 min)
+    if len(sys.argv) > 1 and sys.argv[1] == 'full1000':   # only the full-length free-running fixtures (added in round 5; ~20 min)
         model, cfg = build_model(seed=0)
         full1000_fixtures(model)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'full1000_n34':
+        model, cfg = build_model(seed=0)
+        g5_sample_full1000(model, 'g5_sample_full1000_n34', seed=2042, n_atoms=[34, 21], ck_every=None, sparse_edge_gaps=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'profiles':
         for prof in ('gamma_signed', 'trained_like'):

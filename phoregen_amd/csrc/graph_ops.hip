@@ -62,20 +62,22 @@ __global__ void embed_ctx_kernel(PgTopo t, const float* h_node, const float* pos
   if (node >= t.n_lig + t.n_phore) return;
   if (node < t.n_lig) {
     const int ctx = t.lig2ctx[node];
-    float v;
-    if (c < 118) {
-      v = 0.f;
+    if (h_ctx) {
+      float v;
+      if (c < 118) {
+        v = 0.f;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) v += h_node[node * 12 + k] * W_node[c * 12 + k];
-    } else {
-      v = time_smear((float)time_step[t.ctx_graph[ctx]], t_off, t_coeff, c - 118);
+        for (int k = 0; k < 12; ++k) v += h_node[node * 12 + k] * W_node[c * 12 + k];
+      } else {
+        v = time_smear((float)time_step[t.ctx_graph[ctx]], t_off, t_coeff, c - 118);
+      }
+      h_ctx[(size_t)ctx * 128 + c] = v;
     }
-    h_ctx[(size_t)ctx * 128 + c] = v;
-    if (c < 3) x_ctx[ctx * 3 + c] = pos[node * 3 + c];
+    if (x_ctx && c < 3) x_ctx[ctx * 3 + c] = pos[node * 3 + c];
   } else {
     const int p = node - t.n_lig, ctx = phore2ctx[p];
-    h_ctx[(size_t)ctx * 128 + c] = h_phore_emb[(size_t)p * 128 + c];
-    if (c < 3) x_ctx[ctx * 3 + c] = pos_phore[p * 3 + c];
+    if (h_ctx) h_ctx[(size_t)ctx * 128 + c] = h_phore_emb[(size_t)p * 128 + c];
+    if (x_ctx && c < 3) x_ctx[ctx * 3 + c] = pos_phore[p * 3 + c];
   }
 }
 

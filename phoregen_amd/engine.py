@@ -105,6 +105,7 @@ class Engine:
         # (hipGraph capture of the v2 launch list segfaults inside the runtime -- lanes 2 / 3 wait on lane 1 there while lane 1 waits on
         #  lane 3; the replay variant, off by default and measured slower, keeps the previous list)
         self.ahead_v2 = (o['ahead_v2'] == 'always' or (o['ahead_v2'] == 'auto' and self.plan.n_bond < o['ahead_v2_below'])) and not o['graph']
+        self.step_ahead = o['step_ahead']
         self.pos_tiled, self.pos_tiled_below = o['pos_tiled'], o['pos_tiled_below']
         self.tri_grid = o['tri_grid']                  # persistent triplet workgroups (-1: by batch size)
         # apply_dx + bond smearing + direction vectors as one launch on lane 0: small batches (measured, same box: 16 graphs 3.52 -> 3.40 ms
@@ -129,6 +130,7 @@ class Engine:
             self.prog_phore = self._build_phore_program()
             if not phore_only:                       # (sample_nodes: pharmacophore encoder + count heads only)
                 self.prog_fwd = self._build_forward_program()
+                self.prog_step = self.prog_ahead = None      # the pipelined sampler step (built at first use: `pipelined_programs`)
 
     # ------------------------------------------------------------------ workspace
     def _alloc(self):
@@ -138,6 +140,7 @@ class Engine:
         w.in_h_node, w.in_pos = _f(p.n_lig, 12, device=d), _f(p.n_lig, 3, device=d)
         w.in_h_edge = _f(E, 6, device=d)
         w.in_t = torch.zeros(p.n_graphs, dtype=torch.int64, device=d)
+        w.in_t_next = torch.zeros(p.n_graphs, dtype=torch.int64, device=d)      # t of the NEXT reverse step (its features are embedded one step ahead)
         w.h_phore_ctx, w.x_phore_ctx = _f(n, 18, device=d, zero=True), _f(n, 3, device=d, zero=True)
         w.pos_phore, w.phore_norm = _f(p.n_phore, 3, device=d), _f(p.n_phore, 3, device=d)
         w.nrm_phore_ctx = _f(n, 3, device=d, zero=True)          # phore_norm in ctx row order (pg_layer_geom)
@@ -384,21 +387,38 @@ class Engine:
         torch.index_select(w.enc_ctx, 0, p.phore2ctx_long, out=w.hp_emb)
 
     # ------------------------------------------------------------------ one denoiser forward
-    def _build_forward_program(self):
+    def _embed_bond(self, prog, in_t):
+        w, p, pk = self.ws, self.plan, self.pack
+        self._call(prog, self.lib.pg_embed_bond, p.topo_ref, w.in_h_edge.data_ptr(), p.bond_graph.data_ptr(), in_t.data_ptr(),
+                   pk.W_edge_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), w.hb[0].data_ptr())
+
+    def _embed_ctx(self, prog, in_t, features=True, coords=True):
+        w, p, pk = self.ws, self.plan, self.pack
+        self._call(prog, self.lib.pg_embed_ctx, p.topo_ref, w.in_h_node.data_ptr(), w.in_pos.data_ptr(), in_t.data_ptr(),
+                   pk.W_node_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), w.hp_emb.data_ptr(),
+                   w.pos_phore.data_ptr(), p.phore2ctx.data_ptr(), w.h[0].data_ptr() if features else None,
+                   w.x[0].data_ptr() if coords else None)
+
+    def _build_forward_program(self, step_ahead=False):
+        """One denoiser forward.  step_ahead (the pipelined sampler step, `pipelined_programs`): the features of this step were embedded,
+        and layer 0's coordinate-free products launched, by `prog_ahead` at the end of the PREVIOUS step: only the coordinates are embedded
+        here, layer 0 runs like every later layer, and the program ends without joining lanes 2 / 3 (the categorical posteriors and the
+        next step's `prog_ahead` follow on them)."""
         w, p, pk, prog, lib = self.ws, self.plan, self.pack, [], self.lib
         n, E, t = p.n_ctx, p.n_bond, p.topo_ref
         lig = [(p.lig2ctx, p.n_lig, True)]
         both = [(p.lig2ctx, p.n_lig, True), (p.phore2ctx, p.n_phore, False)]
         h, x, hb = w.h, w.x, w.hb
-        # the bond embedding runs beside the node embedding, the knn search and the edge gate (joined before layer 0 forks)
-        self._fork(prog, (2,))
-        self._lane = 2
-        self._call(prog, lib.pg_embed_bond, t, w.in_h_edge.data_ptr(), p.bond_graph.data_ptr(), w.in_t.data_ptr(),
-                   pk.W_edge_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), hb[0].data_ptr())
-        self._lane = 0
-        self._call(prog, lib.pg_embed_ctx, t, w.in_h_node.data_ptr(), w.in_pos.data_ptr(), w.in_t.data_ptr(),
-                   pk.W_node_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), w.hp_emb.data_ptr(),
-                   w.pos_phore.data_ptr(), p.phore2ctx.data_ptr(), h[0].data_ptr(), x[0].data_ptr())
+        if step_ahead:
+            self._lane = 0
+            self._embed_ctx(prog, w.in_t, features=False)
+        else:
+            # the bond embedding runs beside the node embedding, the knn search and the edge gate (joined before layer 0 forks)
+            self._fork(prog, (2,))
+            self._lane = 2
+            self._embed_bond(prog, w.in_t)
+            self._lane = 0
+            self._embed_ctx(prog, w.in_t)
         # heads (diffusion.py:221-241).  Neither waits for the last layer's position update: the bond head starts on a side lane as
         # soon as the last triplet kernel has written h_bond, the node head as soon as the last lin_node has written h
         def bond_head(hb_final):
@@ -413,10 +433,69 @@ class Engine:
             self._gemm(prog, h_final, 128, W0, w.head, n, 128, bias=b0, act=hip.ACT_SSP)
             self._call(prog, lib.pg_rows_linear, w.head.data_ptr(), 128, 128, W2.data_ptr(), b2.data_ptr(), 12, p.n_lig,
                        p.lig2ctx.data_ptr(), w.out_v.data_ptr(), 12)
-        self._denoiser_program(prog, lig, both, heads=(bond_head, node_head), pre_join=(2,))
+        self._denoiser_program(prog, lig, both, heads=(bond_head, node_head), pre_join=None if step_ahead else (2,), step_ahead=step_ahead)
         return prog
 
-    def _denoiser_program(self, prog, lig, both, heads=None, pre_join=None):
+    def _build_ahead_program(self):
+        """What the NEXT reverse step can do before its coordinates exist (they come last, from the Gaussian posterior): embed its atom /
+        bond features from the types the categorical posteriors have just drawn (its t is in `ws.in_t_next`), layer 0's first-layer
+        blocks, knn-node query, triplet queries and bond-node sub-layer -- the products every later layer gets from the layer in front
+        of it (`layer_ahead`).  Lane 2 behind the node posterior, lane 3 behind the bond posterior; `prog_step` picks the results up with
+        whole-lane order points (the programs own their events, so an event cannot cross from one to the other)."""
+        w, p, pk, prog = self.ws, self.plan, self.pack, []
+        lig = [(p.lig2ctx, p.n_lig, True)]
+        both = [(p.lig2ctx, p.n_lig, True), (p.phore2ctx, p.n_phore, False)]
+        L0 = pk.layers[0]
+        self._sync(prog, 3, (2,))         # (the caller writes `in_t_next` on lane 2 right in front of this program)
+        self._lane = 3
+        self._embed_bond(prog, w.in_t_next)
+        hb_done = self._record(prog, 3)
+        self._lane = 2
+        self._embed_ctx(prog, w.in_t_next, coords=False)
+        self._first_layer_gemm(prog, L0, w.h[0], w.Y1)
+        y1_done = self._record(prog, 2)
+        self._query_gemm(prog, L0.NE, w.Y1, 0, both, 3)
+        self._wait(prog, 2, hb_done)
+        self._triplet_queries(prog, L0, w.hb[0], w.Y1)
+        self._lane = 3
+        self._wait(prog, 3, y1_done)
+        self._bond_node_rows(prog, L0, w.hb[0], w.Y1)
+        self._node_attention(prog, hip.SEG_BOND_NODE, L0.NB, w.Y1, 5 * 128, w.x[0], lig, out=w.aggB, csrc=w.CsB2, buf=2)
+        self._lane = 0
+        return prog
+
+    def pipelined_programs(self):
+        """(prog_step, prog_ahead) of the pipelined sampler step, or None when this engine's schedule has no layer-ahead form."""
+        if not (self.step_ahead and self.multi_stream and self.layer_ahead and self.fused_geom and self.staged_triplet and self.plan.n_tri_iters
+                and self.order_points and self.plan.n_bond < min(self.small_below, self.ahead_below)):
+            return None
+        if self.prog_step is None:
+            tri_calls, self.tri_calls = self.tri_calls, []
+            self.prog_step = self._build_forward_program(step_ahead=True)
+            self.step_tri_calls, self.tri_calls = self.tri_calls, tri_calls
+            self.prog_ahead = self._build_ahead_program()
+        return self.prog_step, self.prog_ahead
+
+    def _first_layer_gemm(self, prog, L, h_in, Y1):
+        # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
+        # (ligand atoms: targets and sources of bond edges)
+        p, n = self.plan, self.plan.n_ctx
+        if self.row_subsets:
+            self._gemm(prog, h_in, 128, L.W_node1[:640], Y1[:, :640], n, 640, bias=L.b_node1[:640])
+            self._gemm(prog, h_in, 128, L.W_node1[640:], Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
+        else:
+            self._gemm(prog, h_in, 128, L.W_node1, Y1, n, 1920, bias=L.b_node1)
+
+    def _triplet_queries(self, prog, L, hb_in, Y1):
+        w, p, E = self.ws, self.plan, self.plan.n_bond
+        self._gemm(prog, hb_in, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
+        self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b), scale=HEAD_SCALE)
+
+    def _bond_node_rows(self, prog, L, hb_in, Y1):
+        w, p, E = self.ws, self.plan, self.plan.n_bond
+        self._gemm(prog, hb_in, 128, L.NB.W_hb, w.CsB2, E, 256, add1=Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
+
+    def _denoiser_program(self, prog, lig, both, heads=None, pre_join=None, step_ahead=False):
         """uni_denoiser.py:396-430: knn graph + gate once, then the layers.  State starts in slot 0."""
         w, p, pk, lib = self.ws, self.plan, self.pack, self.lib
         n, E, t = p.n_ctx, p.n_bond, p.topo_ref
@@ -469,21 +548,10 @@ class Engine:
             w.x_node = [torch.empty_like(x[0]), torch.empty_like(x[0])]
             w.dxe2 = torch.zeros_like(w.dxe)
 
-        def first_layer_gemm(L, h_in, Y1):
-            # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
-            # (ligand atoms: targets and sources of bond edges)
-            if self.row_subsets:
-                self._gemm(prog, h_in, 128, L.W_node1[:640], Y1[:, :640], n, 640, bias=L.b_node1[:640])
-                self._gemm(prog, h_in, 128, L.W_node1[640:], Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
-            else:
-                self._gemm(prog, h_in, 128, L.W_node1, Y1, n, 1920, bias=L.b_node1)
-
-        def triplet_queries(L, hb_in, Y1):
-            self._gemm(prog, hb_in, 128, L.TB.W_q_hb, w.qhid, E, 128, add1=Y1[:, 14 * 128:15 * 128], idx1=p.bond_dst)
-            self._gemm(prog, w.qhid, 128, L.TB.W2q, w.qT, E, 128, bias=L.TB.b2q, ln=(L.TB.q_ln_g, L.TB.q_ln_b), scale=HEAD_SCALE)
-
-        def bond_node_rows(L, hb_in, Y1):
-            self._gemm(prog, hb_in, 128, L.NB.W_hb, w.CsB2, E, 256, add1=Y1[:, 7 * 128:9 * 128], idx1=p.bond_src)
+        first_layer_gemm = lambda L_, h_in, Y1_: self._first_layer_gemm(prog, L_, h_in, Y1_)
+        triplet_queries = lambda L_, hb_in, Y1_: self._triplet_queries(prog, L_, hb_in, Y1_)
+        bond_node_rows = lambda L_, hb_in, Y1_: self._bond_node_rows(prog, L_, hb_in, Y1_)
+        assert not step_ahead or (ahead and self.fused_geom and staged)
 
         for li, L in enumerate(pk.layers):
             nxt = 1 - cur
@@ -493,7 +561,8 @@ class Engine:
             Y1c, Y1n = (w.Y1, w.Y1) if not v2 else ((w.Y1, w.Y1b) if li % 2 == 0 else (w.Y1b, w.Y1))
             xc1 = w.x_node[cur] if (split and li > 0) else xc      # the node chain's coordinates
             dxe = w.dxe2 if (split and li % 2) else w.dxe           # (alternating: lane 1 writes the next while lane 0's closing launch may read this one)
-            pre = ahead and li > 0            # Y1, the triplet queries and the bond-node rows of this layer were launched by the previous one
+            pre = ahead and (li > 0 or step_ahead)      # Y1, the triplet queries and the bond-node rows of this layer were launched by the previous one
+            pre0 = step_ahead and li == 0                # ... layer 0 of a pipelined step: by `prog_ahead` at the end of the previous STEP (lanes 2 / 3)
             if self.fused_geom:
                 # direction vectors and bond-length smearing of this layer came with the previous layer's coordinate update (ONE
                 # launch on lane 0, pg_layer_geom); layer 0 forms them from the embedded coordinates the same way
@@ -510,8 +579,9 @@ class Engine:
                 self._lane = 3
                 self._call(prog, lib.pg_bond_smear, t, xc.data_ptr(), w.G.data_ptr())
                 self._lane = 0
-            if pre and not v2:
+            if (pre and not v2) or pre0:
                 # lane 2 carried this layer's first-layer blocks and triplet queries through the previous layer's position updates
+                # (pipelined step, layer 0: through the end of the previous step)
                 self._sync(prog, 0, (2,))
             elif not pre:
                 first_layer_gemm(L, hc, Y1c)
@@ -519,7 +589,7 @@ class Engine:
                 self._join(prog, pre_join)
             # (v2 from layer 1 on: lanes 2 / 3 have nothing in the first half of the layer, only the node chain's lane is released here)
             q_side = staged and not (chain_q and self.fused_geom)       # the Q rows on lane 2: it reads this layer's smearing (lane 0)
-            if pre and split:                      # (split: lane 1 went on behind its own closing launch)
+            if pre and split and not pre0:         # (split: lane 1 went on behind its own closing launch)
                 if q_side:
                     self._fork(prog, (2,))
             else:
@@ -560,7 +630,7 @@ class Engine:
                     self._wait(prog, 0, q3_done)   # (lane 3 goes on with the bond-node attention: not joined)
                 else:
                     self._join(prog, (3,))
-            if pre and v2:
+            if pre and v2 and not pre0:            # (pre0: lane 0 has waited for lane 2 at the layer's start)
                 self._sync(prog, 0, (2,))          # this layer's triplet queries (lane 2, launched one layer ahead)
             a = L.TB
             self._event(prog, 'triplet', True)
@@ -596,13 +666,17 @@ class Engine:
             self._lane = 1
             if not pre:
                 self._query_gemm(prog, L.NE, Y1c, 0, both, 0)
-            if pre and v2:
+            if pre0:
+                self._sync(prog, 1, (2,))              # this layer's first-layer blocks and knn-node query (lane 2, `prog_ahead`)
+            elif pre and v2:
                 self._wait(prog, 1, ne_done)           # this layer's knn-node query (lane 3, launched one layer ahead)
             self._event(prog, 'knn_node', True)       # (the launches of the sub-layer: ligand targets, pharmacophore targets)
             self._node_attention(prog, hip.SEG_KNN_NODE, L.NE, Y1c, 0, xc1, both, out=w.aggE, buf=0, query_done=True,
                                  qbuf=3 if pre else None)
             self._event(prog, 'knn_node', False)
-            if pre or v2:
+            if pre0:
+                self._sync(prog, 1, (3,))              # aggB: the bond-node attention of `prog_ahead` (lane 3)
+            elif pre or v2:
                 self._wait(prog, 1, bn_done)           # aggB: the bond-node attention on lane 3 (launched one layer ahead from layer 1 on)
             else:
                 self._sync(prog, 1, (2,))              # aggB
@@ -675,6 +749,8 @@ class Engine:
             self._node_attention(prog, hip.SEG_KNN_POS, L.PE, w.Y2, 0, xc1, lig, dx=dxe, buf=0)
             self._lane = 0
             self._gemm(prog, hbn, 128, L.PB.W_hb, w.CsB, E, 256, add1=w.Y2[:, 7 * 128:9 * 128], idx1=p.bond_src)
+            if step_ahead and last:
+                csb_done = self._record(prog, 0)       # the last reader of this step's final h_bond outside lane 3: `prog_ahead` may embed the next
             if not v2:
                 self._wait(prog, 0, q_done)
             self._node_attention(prog, hip.SEG_BOND_POS, L.PB, w.Y2, 5 * 128, xc, lig, dx=w.dxb, csrc=w.CsB, buf=1, query_done=True)
@@ -695,7 +771,11 @@ class Engine:
                 self._call(prog, lib.pg_apply_dx, t, xc.data_ptr(), dxe.data_ptr(), w.dxb.data_ptr(), xn.data_ptr())
             self._mark(prog, f'L{li}', hn, hbn, xn, dxe, w.dxb, hbc)
             cur = nxt
-        if heads is not None:
+        if heads is not None and step_ahead:
+            # no join: the categorical posteriors and `prog_ahead` follow on lanes 2 / 3 (the caller joins when it needs the results:
+            # `join_lanes`); lane 3 -- where the next step's bond embedding overwrites h_bond -- waits for the bond-pos rows' read of it
+            self._wait(prog, 3, csb_done)
+        elif heads is not None:
             self._join(prog, (2, 3))
         self.final_idx = cur
 
@@ -779,6 +859,9 @@ class Engine:
     def _set_tri_grid(self, grid):
         for i in self.tri_calls:
             self.prog_fwd[i][1][-1]._obj.tri_grid = grid
+        if getattr(self, 'prog_step', None) is not None:
+            for i in self.step_tri_calls:
+                self.prog_step[i][1][-1]._obj.tri_grid = grid
 
     def _tune_begin(self):
         """One timing event at the START of every forward of the tuning phase: the period between two of them is a whole sampler step
@@ -811,6 +894,40 @@ class Engine:
             self._tune = None
         elif k % self.TUNE_REPS == 0:
             self._set_tri_grid(t['cands'][k // self.TUNE_REPS])
+
+    def lane_stream(self, lane):
+        """hipStream_t of a lane for launches the caller adds beside a program (lane 0 = torch's current stream)."""
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = side_streams(cur.device_index, self.stream_set)
+        return cur if lane == 0 else self._side[lane - 1]
+
+    def join_lanes(self, lanes=(2, 3)):
+        """The caller's stream continues after everything enqueued so far on the side lanes."""
+        cur = torch.cuda.current_stream()
+        for l in lanes:
+            ev = torch.cuda.Event()
+            ev.record(self.lane_stream(l))
+            cur.wait_event(ev)
+
+    def fork_lanes(self, lanes=(2, 3)):
+        """The side lanes continue after everything enqueued so far on the caller's stream."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        for l in lanes:
+            self.lane_stream(l).wait_event(ev)
+
+    def step_forward(self):
+        """The denoiser forward of a pipelined sampler step (`prog_step`): returns like `forward_inplace`, WITHOUT joining lanes 2 / 3
+        (out_v is complete on lane 2, out_bond on lane 3)."""
+        w = self.ws
+        tuning = self._tune is not None and self.timers is None and self.trace is None and self.debug is None and \
+            not torch.cuda.is_current_stream_capturing()
+        if tuning:
+            self._tune_begin()
+        self._run(self.prog_step)
+        x0 = torch.index_select(w.x[self.final_idx], 0, self.plan.lig2ctx_long)
+        return w.out_v, x0, w.out_bond
 
     def forward_inplace(self):
         w = self.ws

@@ -351,9 +351,11 @@ class PhoreDiff(nn.Module):
     @torch.no_grad()
     def sample_batch(self, h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, pos_guidance_opt=None,
                      rng='device', seed=0, return_traj=True, guidance_center=None, num_steps=None, on_step=None,
-                     graph_ids=None, guidance_batch=None):
+                     graph_ids=None, guidance_batch=None, pipeline=True):
         """Sampler over a batch of (possibly different) pharmacophores: the multi-pharmacophore entry point
         the reference lacks.  `centers` [B,3] are added back to coordinates as the reference does.
+        pipeline (device RNG, no `on_step`): the loop runs as a software pipeline over the reverse steps (`_reverse_step_pipelined`:
+            same kernels on the same operands, the same trajectory bit for bit; tested).
         graph_ids [B] (device RNG): the noise of graph g is keyed by (seed, graph_ids[g]) and by positions INSIDE the graph,
             so a graph draws the same noise in any batch / shard (default: 0..B-1).
         guidance_center [3] or [B,3]: target of the `center_prox` energy (default: per graph, the mean of its non-EX
@@ -362,7 +364,7 @@ class PhoreDiff(nn.Module):
             shard of a larger logical batch passes the full batch size so that it reproduces the unsharded run)."""
         st = self.begin_sampling(h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, rng=rng, seed=seed,
                                  return_traj=return_traj, num_steps=num_steps, guidance_center=guidance_center,
-                                 graph_ids=graph_ids, guidance_batch=guidance_batch)
+                                 graph_ids=graph_ids, guidance_batch=guidance_batch, pipeline=pipeline and on_step is None)
         T = self.num_timesteps
         for i, step in enumerate(range(T)[::-1][:st.n_steps]):
             self.reverse_step(st, i, step, pos_guidance_opt)
@@ -374,7 +376,9 @@ class PhoreDiff(nn.Module):
     @torch.no_grad()
     @_on_model_device
     def begin_sampling(self, h_phore, pos_phore, phore_norm, batch_phore, num_atoms, centers, rng='device', seed=0,
-                       return_traj=True, num_steps=None, guidance_center=None, graph_ids=None, guidance_batch=None):
+                       return_traj=True, num_steps=None, guidance_center=None, graph_ids=None, guidance_batch=None, pipeline=False):
+        """pipeline=True: `reverse_step` must then be called for consecutive steps with nothing written to the carried state in
+        between (the next step's features are embedded at the end of the step before it); the teacher-forced tests leave it off."""
         dev = self._device()
         lib = hip.lib()
         B = int(num_atoms.numel())
@@ -391,6 +395,11 @@ class PhoreDiff(nn.Module):
         st.eng, st.plan, st.num_atoms, st.N, st.E, st.B = eng, plan, num_atoms, N, E, B
         st.cpu, st.seed, st.return_traj = rng == 'cpu', seed, return_traj
         st.n_steps = self.num_timesteps if num_steps is None else num_steps
+        st.pipelined = bool(pipeline) and rng == 'device' and eng.pipelined_programs() is not None
+        st.next_step = None              # (pipelined: the step whose features `prog_ahead` has embedded)
+        # (pipelined: the posteriors of step s run on the side lanes, possibly while lane 0 has begun step s - 1: the step number they
+        #  read alternates between two buffers)
+        st.t_buf = [torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(2)] if st.pipelined else None
         st.centers = centers.to(dev).float().contiguous()                                # [B,3]
         st.center_rows = st.centers[plan.batch_node]                                     # [N,3]
         st.graph_key = (torch.arange(B) if graph_ids is None else graph_ids.detach().cpu()).to(torch.int32).to(dev)
@@ -450,11 +459,14 @@ class PhoreDiff(nn.Module):
             gc = guidance_center.to(dev).float()
             st.gc = (gc.unsqueeze(0).expand(B, 3) if gc.dim() == 1 else gc).contiguous()
         else:
-            keep = (h_phore[:, self.ex_col] != 1).float().unsqueeze(-1)
-            bp = plan.phore_graph.long()
-            sums = torch.zeros(B, 3, device=dev).index_add_(0, bp, pos_phore.float() * keep)
-            cnt = torch.zeros(B, 1, device=dev).index_add_(0, bp, keep)
-            st.gc = (sums / cnt).contiguous()              # (0/0 = nan for a pharmacophore of exclusion spheres only, as in the reference)
+            # summed on the host, in node order: a device index_add_ accumulates with atomics in whatever order the hardware serves them,
+            # and the centre -- hence every guided coordinate -- would differ by an ulp from run to run (round 5: found by the
+            # pipelined-loop test; once per batch, a few hundred rows)
+            keep = (h_phore[:, self.ex_col] != 1).float().unsqueeze(-1).cpu()
+            bp = plan.phore_graph.long().cpu()
+            sums = torch.zeros(B, 3).index_add_(0, bp, pos_phore.float().cpu() * keep)
+            cnt = torch.zeros(B, 1).index_add_(0, bp, keep)
+            st.gc = (sums / cnt).to(dev).contiguous()      # (0/0 = nan for a pharmacophore of exclusion spheres only, as in the reference)
         st.x0 = None
         return st
 
@@ -463,6 +475,10 @@ class PhoreDiff(nn.Module):
     def reverse_step(self, st, i, step, pos_guidance_opt=None, draws=None):
         """One iteration of the loop at diffusion.py:432-517 on the state held in the engine workspace.
         `draws` = (u_node [N,12], u_edge [E,6], eps [N,3]) overrides the noise source (teacher-forced tests)."""
+        if getattr(st, 'pipelined', False):
+            if draws is not None:
+                raise RuntimeError('phoregen_amd: reverse_step(draws=...) on a pipelined sampler state (begin_sampling(pipeline=True))')
+            return self._reverse_step_pipelined(st, i, step, pos_guidance_opt)
         lib, eng, plan = hip.lib(), st.eng, st.plan
         pk, w, N, E = eng.pack, eng.ws, st.N, st.E
         dev = self._device()
@@ -511,9 +527,76 @@ class PhoreDiff(nn.Module):
             w.in_pos.data_ptr(), tp(st.pos_traj), s), 'posterior(pos)')          # in place: x_t -> x_{t-1}
         st.cur = 1 - cur
 
+    def _reverse_step_pipelined(self, st, i, step, pos_guidance_opt=None):
+        """`reverse_step` as one stage of a software pipeline over the reverse steps (device RNG).  The order of a step's results is
+        types first (the heads finish inside the last layer), coordinates last; the next step can use its types long before its
+        coordinates exist.  So: the denoiser program ends WITHOUT joining its side lanes; the node posterior follows the node head on
+        lane 2, the bond posterior the bond head on lane 3; behind them `Engine.prog_ahead` embeds the next step's features and runs layer
+        0's coordinate-free products (first-layer blocks, queries, bond-node sub-layer) -- all beside the last layer's position phase,
+        the Gaussian posterior and the next step's coordinate embedding / knn search on lanes 0 / 1.  Same kernels on the same operands
+        as `reverse_step`: the trajectory is the same bit for bit (tests/test_gpu_parity.py)."""
+        lib, eng, plan = hip.lib(), st.eng, st.plan
+        pk, w, N, E = eng.pack, eng.ws, st.N, st.E
+        tp = lambda tr: tr[i + 1].data_ptr() if tr is not None else None
+        s2, s3 = eng.lane_stream(2), eng.lane_stream(3)
+        if st.next_step is None:                       # first step: nothing was launched ahead yet
+            eng.fork_lanes((2, 3))                     # (the initial state was written on the caller's stream)
+            with torch.cuda.stream(s2):
+                w.in_t_next.fill_(step)
+            eng._run(eng.prog_ahead)
+        elif st.next_step != step:
+            raise RuntimeError(f'phoregen_amd: pipelined sampler state expects step {st.next_step}, got {step}')
+        tb = st.t_buf[step & 1]
+        tb.fill_(step)
+        _, st.x0, _ = eng.step_forward()
+        cur = st.cur
+        hip.check(lib.pg_posterior_categorical(
+            w.out_v.data_ptr(), st.log_node[cur].data_ptr(), plan.lig_graph.data_ptr(), tb.data_ptr(),
+            pk.node_tab[0].data_ptr(), pk.node_tab[1].data_ptr(), N, 12, None, st.seed, 0, step,
+            plan.g_lig_off.data_ptr(), st.graph_key.data_ptr(),
+            st.log_node[1 - cur].data_ptr(), w.in_h_node.data_ptr(), tp(st.node_traj), s2.cuda_stream), 'posterior(node)')
+        hip.check(lib.pg_posterior_categorical(
+            w.out_bond.data_ptr(), st.log_edge[cur].data_ptr(), plan.bond_graph.data_ptr(), tb.data_ptr(),
+            pk.edge_tab[0].data_ptr(), pk.edge_tab[1].data_ptr(), E, 6, None, st.seed, 1, step,
+            plan.g_bond_off.data_ptr(), st.graph_key.data_ptr(),
+            st.log_edge[1 - cur].data_ptr(), w.in_h_edge.data_ptr(), tp(st.edge_traj), s3.cuda_stream), 'posterior(edge)')
+        last = step == 0 or i + 1 >= st.n_steps
+        if not last:
+            with torch.cuda.stream(s2):
+                w.in_t_next.fill_(step - 1)
+            eng._run(eng.prog_ahead)
+        s = hip.stream_ptr()
+        grad = None
+        if pos_guidance_opt:                                         # diffusion.py:476-502 (reads the bond types just drawn on lane 3)
+            eng.join_lanes((3,))
+            grad = st.grad
+            grad.zero_()
+            for o in pos_guidance_opt:
+                atom = o['type'] == 'atom_prox'
+                if not atom and o['type'] != 'center_prox':
+                    continue
+                hip.check(lib.pg_guidance_grad(
+                    plan.topo_ref, w.in_pos.data_ptr(), w.in_h_edge.data_ptr(), plan.lig_graph.data_ptr(),
+                    plan.g_lig_off.data_ptr(), int(atom), float(o.get('min_d', 1.2)), float(o.get('max_d', 2.8)),
+                    int(not atom), hip.ptr(st.gc), st.guidance_batch, st.cnt_ws.data_ptr(), st.mean_ws.data_ptr(),
+                    st.gtmp.data_ptr(), s), 'guidance')
+                grad += st.gtmp
+        hip.check(lib.pg_posterior_position(
+            w.in_pos.data_ptr(), st.x0.data_ptr(), plan.lig_graph.data_ptr(), tb.data_ptr(),
+            pk.pos_tab[0].data_ptr(), pk.pos_tab[1].data_ptr(), pk.pos_tab[2].data_ptr(), hip.ptr(grad), None,
+            st.seed, 2, step, N, plan.g_lig_off.data_ptr(), st.graph_key.data_ptr(),
+            st.centers.data_ptr() if st.return_traj else None,
+            w.in_pos.data_ptr(), tp(st.pos_traj), s), 'posterior(pos)')
+        st.cur = 1 - cur
+        st.next_step = step - 1
+        if last:
+            eng.join_lanes((2, 3))
+
     @_on_model_device
     def finish_sampling(self, st):
         w, plan = st.eng.ws, st.plan
+        if getattr(st, 'pipelined', False):
+            st.eng.join_lanes((2, 3))              # (out_v / out_bond / the discrete trajectories are completed on the side lanes)
         return {'pred': [w.out_v.clone(), st.x0 + st.center_rows, w.out_bond.clone()],
                 'traj': [st.node_traj, st.pos_traj, st.edge_traj],
                 'lig_info': [st.num_atoms.to(self._device()), plan.batch_node, plan.edge_index, plan.batch_edge]}

@@ -25,6 +25,9 @@ DEFAULTS = dict(
     small_below=10**9,    # ... 'small' = fewer bond edges than this (round 4: the schedule pays at every size, 128 graphs 20.10 -> 19.81 ms)
     pos_tiled='auto',     # position-update attention with a node's row tiles over several waves: 'auto' = launches of few nodes, 'never', 'always'
     pos_tiled_below=1500, # ... 'auto': up to this many target nodes (32 graphs 5.29 -> 5.21 ms; at 64 graphs = 2 560 nodes it loses)
+    step_ahead=True,      # the sampler loop as a software pipeline over reverse steps: the categorical posteriors behind their heads on the side
+                          # lanes, the NEXT step's feature embedding and layer 0's coordinate-free products (first-layer blocks, queries, bond-node
+                          # sub-layer) behind them, beside the last layer's position phase / the Gaussian posterior (`Engine.pipelined_programs`)
     c_program=True,       # a forward = ONE call into the library (pg_program_run walks the launch list); False: the list is walked from Python
     order_points=True,    # cross-lane order points as device-scope HIP events (pg_order_point_*); False: torch.cuda.Event()
     geom_split='auto',    # ahead_v2: the layer's closing launch (pg_layer_geom) once per chain, on the chain's own lane: 'auto' = batches
@@ -54,7 +57,7 @@ _flag = lambda v: v != '0'
 _ENV = {
     'PG_STREAMS': ('streams', _flag), 'PG_ROW_SUBSETS': ('row_subsets', _flag), 'PG_TRI_STAGED': ('tri_staged', _flag),
     'PG_NODE_FUSED': ('node_fused', _flag), 'PG_KNN_GROUP': ('knn_group', _flag), 'PG_KNN_MERGE': ('knn_merge', _tri),
-    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_C_PROGRAM': ('c_program', _flag), 'PG_CHAIN_Q_FROM': ('chain_q_from', int), 'PG_AHEAD_BELOW': ('ahead_below', int), 'PG_TRI_SPLIT': ('tri_split', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
+    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_C_PROGRAM': ('c_program', _flag), 'PG_STEP_AHEAD': ('step_ahead', _flag), 'PG_CHAIN_Q_FROM': ('chain_q_from', int), 'PG_AHEAD_BELOW': ('ahead_below', int), 'PG_TRI_SPLIT': ('tri_split', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
     'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
     'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int), 'PG_BWD_SPLIT': ('bwd_split', lambda v: {'0': 'none', '1': 'knn', '2': 'all'}[v]), 'PG_BWD_ATOM_SORT': ('bwd_atom_sort', _flag),
 }

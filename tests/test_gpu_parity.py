@@ -622,7 +622,7 @@ FLIP_GAP_MULT = 2 * 5 * TOL      # x max |logit| of the step: a categorical draw
 KINK_EPS = 2e-5                  # [A] a bond this close to min_d / max_d of the atom_prox guidance sits ON the kink of its relu at fp32 precision
 
 
-@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid'])
+@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid', 'g5_sample_full1000_n34'])
 def test_sampler_free_running_1000_steps_matches_reference(name):
     """ALL 1000 reverse steps, free-running, against the reference's own `sample()` on the same seed (models/diffusion.py:391-525;
     fixture: oracle/make_golden.py g5_sample_full1000): the CPU generator is seeded like the reference run and the draws are taken in
@@ -675,8 +675,14 @@ def test_sampler_free_running_1000_steps_matches_reference(name):
     rmsd = torch.zeros(T + 1, B, device=DEV)
     kink = torch.full((T, B), 9.0, device=DEV)
     gap_n, gap_e = torch.zeros(T, N, device=DEV), torch.zeros(T, E, device=DEV)
-    ck = {int(i): k for k, i in enumerate(g['ck_steps'])}
+    ck = {int(i): k for k, i in enumerate(g['ck_steps'])}          # (`n34`: ligands of 34 / 21 atoms = 3 / 2 row tiles; no checkpoints stored)
     events, seg_end_rmsd = [], []
+    if 'gap_edge' in g.files:
+        ref_gap_edge = lambda s_, r_: float(g['gap_edge'][s_, r_])
+    else:                              # sparse: only the margins below `gap_edge_floor` were kept
+        _sparse = {(int(a), int(b)): float(c) for a, b, c in zip(g['gap_edge_step'], g['gap_edge_row'], g['gap_edge_val'])}
+        ref_gap_edge = lambda s_, r_: _sparse.get((s_, r_), float(g['gap_edge_floor']))
+    ref_gap_node = lambda s_, r_: float(g['gap_node'][s_, r_])
 
     def margins(u, logp):
         top = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + logp).topk(2, dim=-1).values
@@ -687,9 +693,9 @@ def test_sampler_free_running_1000_steps_matches_reference(name):
         ev = dict(graph=gi, diverged_at=s, resynced_after=resynced_after, rmsd_at=float(rmsd[s + 1, gi]), types_differ=bool(bad_types[s, gi]),
                   kink_margin=float(kink[s, gi]), flips=[])
         bound = FLIP_GAP_MULT * float(max(g['scale_node'][s], g['scale_edge'][s]))
-        for kind, traj, ref, batch, ref_gap, hip_gap in (('node', st.node_traj, ref_n, bn, g['gap_node'], gap_n), ('edge', st.edge_traj, ref_e, be, g['gap_edge'], gap_e)):
+        for kind, traj, ref, batch, ref_gap, hip_gap in (('node', st.node_traj, ref_n, bn, ref_gap_node, gap_n), ('edge', st.edge_traj, ref_e, be, ref_gap_edge, gap_e)):
             for r in ((traj[s + 1].argmax(-1) != ref[s + 1]) & (batch == gi)).nonzero().flatten().tolist():
-                ev['flips'].append(dict(kind=kind, row=r, ref_gap=float(ref_gap[s, r]), hip_gap=float(hip_gap[s, r]), bound=bound))
+                ev['flips'].append(dict(kind=kind, row=r, ref_gap=ref_gap(s, r), hip_gap=float(hip_gap[s, r]), bound=bound))
         ties = bool(ev['flips']) and all(f['ref_gap'] <= f['bound'] and f['hip_gap'] <= f['bound'] for f in ev['flips'])
         on_kink = guid is not None and ev['kink_margin'] <= KINK_EPS
         ev['explained_by'] = 'guidance kink' if on_kink else ('categorical tie' if ties and ev['rmsd_at'] <= 1e-4 else None)
@@ -1144,4 +1150,33 @@ def test_library_side_launch_list_equals_the_python_walk(model, graphs):
             assert eng.lib.pg_program_length(compiled.h) == n_launch + n_order == compiled.n and n_order > 0
         else:
             assert id(eng.prog_fwd) not in eng._compiled
+    model._engine = None
+
+
+@pytest.mark.parametrize('graphs,guided', [(3, False), (3, True), (16, False), (16, True), (40, False), (72, False)])
+def test_pipelined_sampler_loop_equals_the_plain_loop(model, graphs, guided):
+    """`sample_batch(pipeline=True)` (the default with the device RNG): the reverse steps as a software pipeline -- categorical posteriors
+    behind their heads on the side lanes, the next step's feature embedding and layer 0's coordinate-free products behind them -- against
+    the plain loop (everything of a step on the caller's stream after the denoiser's final join).  Same kernels on the same operands:
+    every trajectory frame and the final prediction are the same bits, in every schedule regime (per-chain closing launch, v2, large
+    batches with two triplet launches), with and without guidance, tuning on."""
+    from bench import ligphore_workload
+    w = ligphore_workload(graphs, seed=500 + graphs)
+    args = (w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'], w['num_atoms'], torch.zeros(graphs, 3))
+    guid = GUID if guided else None
+    out = {}
+    for pipe in (False, True):
+        model._engine = None
+        res = model.sample_batch(*args, rng='device', seed=5, num_steps=30, pos_guidance_opt=guid, pipeline=pipe)
+        torch.cuda.synchronize()
+        out[pipe] = [t.clone() for t in res['traj']] + [t.clone() for t in res['pred']]
+    assert model._engine.prog_step is not None                      # the pipelined programs were built and used
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+    # and it refuses what it cannot honour: a step out of sequence
+    st = model.begin_sampling(*args, rng='device', seed=5, num_steps=4, pipeline=True)
+    model.reverse_step(st, 0, 999)
+    with pytest.raises(RuntimeError, match='expects step 998'):
+        model.reverse_step(st, 1, 997)
+    model.finish_sampling(st)
     model._engine = None

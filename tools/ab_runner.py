@@ -25,7 +25,7 @@ def measure(work, gids, fence_free=False, **opt):
     with options.override(**opt):
         model._engine = None
         st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm'], work['batch_phore'], work['num_atoms'],
-                                  torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + 4 * K, graph_ids=gids)
+                                  torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + 4 * K, graph_ids=gids, pipeline=True)
     for i in range(W):
         model.reverse_step(st, i, 999 - i)
     ts, host = [], []

@@ -20,7 +20,7 @@ for G in Gs:
             with options.override(**kw):
                 model._engine = None
                 st = model.begin_sampling(w['h_phore'], w['pos_phore'], w['phore_norm'], w['batch_phore'], w['num_atoms'],
-                                          torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + R * K)
+                                          torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + R * K, pipeline=True)
                 for i in range(W):
                     model.reverse_step(st, i, 999 - i)
                 ts = []

@@ -29,7 +29,7 @@ W, K = 24, 30          # (24 untimed steps: the online choice of the triplet gri
 def ms_per_step(work, gids):
     G = int(work['num_atoms'].numel())
     st = model.begin_sampling(work['h_phore'], work['pos_phore'], work['phore_norm'], work['batch_phore'], work['num_atoms'],
-                              torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + 3 * K, graph_ids=gids)
+                              torch.zeros(G, 3), rng='device', seed=0, return_traj=True, num_steps=W + 3 * K, graph_ids=gids, pipeline=True)
     for i in range(W):
         model.reverse_step(st, i, 999 - i)
     ts = []
