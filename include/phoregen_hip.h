@@ -308,6 +308,16 @@ int pg_posterior_position(const float* x_t, const float* x0, const int* row_grap
                           const int* graph_row0, const int* graph_key, const float* center /*[B,3] per graph, added to traj_out only; or NULL*/,
                           float* x_prev, float* traj_out, void* stream);
 
+/* The same step for a sampler loop that keeps the coordinates in the denoiser's ctx-ordered buffers (phoregen_amd/models/diffusion.py,
+ * pipelined loop): x0 is read as x0_ctx[lig2ctx[row]] (the denoiser's final coordinate buffer: no gather launch in front), the new
+ * position is also written to x_ctx_next[lig2ctx[row]] (the coordinates layer 0 of the NEXT step reads: no embedding launch behind;
+ * may be the buffer x0_ctx points to) and x0 itself to x0_out [n_rows,3] (optional).  Same arithmetic, same noise. */
+int pg_posterior_position_ctx(const float* x_t, const float* x0_ctx, const int* lig2ctx, const int* row_graph,
+                              const int64_t* time_step, const float* coef_x0, const float* coef_xt, const float* std_,
+                              const float* energy_grad, const float* eps, uint64_t seed, uint32_t stream_id, uint32_t step,
+                              int n_rows, const int* graph_row0, const int* graph_key, const float* center, float* x_prev,
+                              float* traj_out, float* x_ctx_next, float* x0_out, void* stream);
+
 /* closed-form guidance gradient (models/diffusion.py:476-502, utils/sample_utils.py:135-165).  phore_center [B,3]: per
  * graph the mean position of its non-EX pharmacophore nodes.  Both energies are means over the graphs of the batch;
  * mean_over_graphs = that divisor (<= 0: this batch's n_graphs; a shard of a larger logical batch passes the full count). */

@@ -107,14 +107,21 @@ __global__ void posterior_pos_kernel(const float* x_t, const float* x0, const in
                                      const float* coef_x0, const float* coef_xt, const float* std_, const float* grad,
                                      const float* eps, uint64_t seed, uint32_t stream_id, uint32_t step, int n_rows,
                                      const int* graph_row0, const int* graph_key,
-                                     const float* center, float* x_prev, float* traj_out) {
+                                     const float* center, float* x_prev, float* traj_out,
+                                     const int* lig2ctx, float* x_ctx_next, float* x0_out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rows * 3) return;
   const int row = idx / 3;
   const int gr = row_graph[row];
   const int tb = (int)time_step[gr];
+  // lig2ctx (pg_posterior_position_ctx): x0 is the denoiser's ctx-ordered coordinate buffer, read through the row map -- and the new
+  // position goes back into the ctx-ordered buffer of the NEXT step as well (x_ctx_next may be the buffer x0 is read from: every thread
+  // reads its own element before it writes it)
+  const int cidx = lig2ctx ? lig2ctx[row] * 3 + (idx - row * 3) : idx;
+  const float x0v = x0[cidx];
+  if (x0_out) x0_out[idx] = x0v;
   // transition.py:57-62
-  float mu = coef_x0[tb] * x0[idx] + coef_xt[tb] * x_t[idx];
+  float mu = coef_x0[tb] * x0v + coef_xt[tb] * x_t[idx];
   if (grad) mu -= grad[idx];
   float e;
   if (eps) e = eps[idx];
@@ -127,6 +134,7 @@ __global__ void posterior_pos_kernel(const float* x_t, const float* x0, const in
   }
   const float v = tb == 0 ? mu : mu + std_[tb] * e;
   x_prev[idx] = v;
+  if (x_ctx_next) x_ctx_next[cidx] = v;
   if (traj_out) traj_out[idx] = v + (center ? center[gr * 3 + idx % 3] : 0.f);
 }
 
@@ -229,8 +237,21 @@ extern "C" int pg_posterior_position(const float* x_t, const float* x0, const in
   if (n_rows == 0) return PG_OK;
   hipLaunchKernelGGL(posterior_pos_kernel, dim3((n_rows * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_t, x0,
                      row_graph, time_step, coef_x0, coef_xt, std_, energy_grad, eps, seed, stream_id, step, n_rows, graph_row0,
-                     graph_key, center, x_prev, traj_out);
+                     graph_key, center, x_prev, traj_out, (const int*)nullptr, (float*)nullptr, (float*)nullptr);
   return check_launch("pg_posterior_position");
+}
+
+extern "C" int pg_posterior_position_ctx(const float* x_t, const float* x0_ctx, const int* lig2ctx, const int* row_graph,
+                                         const int64_t* time_step, const float* coef_x0, const float* coef_xt, const float* std_,
+                                         const float* energy_grad, const float* eps, uint64_t seed, uint32_t stream_id, uint32_t step,
+                                         int n_rows, const int* graph_row0, const int* graph_key, const float* center, float* x_prev,
+                                         float* traj_out, float* x_ctx_next, float* x0_out, void* stream) {
+  if (n_rows == 0) return PG_OK;
+  if (!lig2ctx || !x0_ctx) { set_error("pg_posterior_position_ctx: x0_ctx and lig2ctx are required"); return PG_ERR_ARG; }
+  hipLaunchKernelGGL(posterior_pos_kernel, dim3((n_rows * 3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x_t, x0_ctx,
+                     row_graph, time_step, coef_x0, coef_xt, std_, energy_grad, eps, seed, stream_id, step, n_rows, graph_row0,
+                     graph_key, center, x_prev, traj_out, lig2ctx, x_ctx_next, x0_out);
+  return check_launch("pg_posterior_position_ctx");
 }
 
 extern "C" int pg_guidance_grad(const PgTopo* t, const float* x_lig, const float* h_edge_prev, const int* lig_graph,

@@ -401,17 +401,16 @@ class Engine:
 
     def _build_forward_program(self, step_ahead=False):
         """One denoiser forward.  step_ahead (the pipelined sampler step, `pipelined_programs`): the features of this step were embedded,
-        and layer 0's coordinate-free products launched, by `prog_ahead` at the end of the PREVIOUS step: only the coordinates are embedded
-        here, layer 0 runs like every later layer, and the program ends without joining lanes 2 / 3 (the categorical posteriors and the
-        next step's `prog_ahead` follow on them)."""
+        and layer 0's coordinate-free products launched, by `prog_ahead` at the end of the PREVIOUS step, whose Gaussian posterior wrote the
+        new coordinates straight into x[0] (pg_posterior_position_ctx): nothing is embedded here, layer 0 runs like every later layer, and
+        the program ends without joining lanes 2 / 3 (the categorical posteriors and the next step's `prog_ahead` follow on them)."""
         w, p, pk, prog, lib = self.ws, self.plan, self.pack, [], self.lib
         n, E, t = p.n_ctx, p.n_bond, p.topo_ref
         lig = [(p.lig2ctx, p.n_lig, True)]
         both = [(p.lig2ctx, p.n_lig, True), (p.phore2ctx, p.n_phore, False)]
         h, x, hb = w.h, w.x, w.hb
         if step_ahead:
-            self._lane = 0
-            self._embed_ctx(prog, w.in_t, features=False)
+            self._lane = 0          # (the coordinates are in x[0] already: the Gaussian posterior of the previous step wrote them there)
         else:
             # the bond embedding runs beside the node embedding, the knn search and the edge gate (joined before layer 0 forks)
             self._fork(prog, (2,))
@@ -918,16 +917,15 @@ class Engine:
             self.lane_stream(l).wait_event(ev)
 
     def step_forward(self):
-        """The denoiser forward of a pipelined sampler step (`prog_step`): returns like `forward_inplace`, WITHOUT joining lanes 2 / 3
-        (out_v is complete on lane 2, out_bond on lane 3)."""
+        """The denoiser forward of a pipelined sampler step (`prog_step`): (out_v, the ctx-ordered final coordinates, out_bond) WITHOUT joining
+        lanes 2 / 3 (out_v is complete on lane 2, out_bond on lane 3)."""
         w = self.ws
         tuning = self._tune is not None and self.timers is None and self.trace is None and self.debug is None and \
             not torch.cuda.is_current_stream_capturing()
         if tuning:
             self._tune_begin()
         self._run(self.prog_step)
-        x0 = torch.index_select(w.x[self.final_idx], 0, self.plan.lig2ctx_long)
-        return w.out_v, x0, w.out_bond
+        return w.out_v, w.x[self.final_idx], w.out_bond        # (x0 in ctx rows: the Gaussian posterior reads it through lig2ctx)
 
     def forward_inplace(self):
         w = self.ws

@@ -121,6 +121,8 @@ _PROTOS = {
                                            C.c_uint64, C.c_uint32, C.c_uint32, c_ip, c_ip, c_fp, c_fp, c_fp, C.c_void_p]),
     'pg_posterior_position': (C.c_int, [c_fp, c_fp, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_uint64,
                                         C.c_uint32, C.c_uint32, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, C.c_void_p]),
+    'pg_posterior_position_ctx': (C.c_int, [c_fp, c_fp, c_ip, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_uint64,
+                                            C.c_uint32, C.c_uint32, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_void_p]),
     'pg_gemm_wgrad': (C.c_int, [c_fp, C.c_int, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_void_p]),
     'pg_ln_relu': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, c_fp, C.c_int, C.c_void_p]),
     'pg_ln_relu_bwd': (C.c_int, [c_fp, C.c_int, c_fp, c_fp, c_fp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, c_fp,

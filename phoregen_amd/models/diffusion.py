@@ -398,8 +398,10 @@ class PhoreDiff(nn.Module):
         st.pipelined = bool(pipeline) and rng == 'device' and eng.pipelined_programs() is not None
         st.next_step = None              # (pipelined: the step whose features `prog_ahead` has embedded)
         # (pipelined: the posteriors of step s run on the side lanes, possibly while lane 0 has begun step s - 1: the step number they
-        #  read alternates between two buffers)
-        st.t_buf = [torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(2)] if st.pipelined else None
+        #  read is a row of a table written once)
+        st.t_table = torch.arange(self.num_timesteps, dtype=torch.int64, device=dev).unsqueeze(1).expand(-1, max(B, 1)).contiguous() \
+            if st.pipelined else None
+        st.x0_buf = torch.empty(N, 3, device=dev) if st.pipelined else None
         st.centers = centers.to(dev).float().contiguous()                                # [B,3]
         st.center_rows = st.centers[plan.batch_node]                                     # [N,3]
         st.graph_key = (torch.arange(B) if graph_ids is None else graph_ids.detach().cpu()).to(torch.int32).to(dev)
@@ -540,23 +542,27 @@ class PhoreDiff(nn.Module):
         tp = lambda tr: tr[i + 1].data_ptr() if tr is not None else None
         s2, s3 = eng.lane_stream(2), eng.lane_stream(3)
         if st.next_step is None:                       # first step: nothing was launched ahead yet
+            # the initial coordinates into the denoiser's buffer (from then on the Gaussian posterior writes them there itself)
+            hip.check(lib.pg_embed_ctx(plan.topo_ref, w.in_h_node.data_ptr(), w.in_pos.data_ptr(), w.in_t.data_ptr(),
+                                       pk.W_node_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), w.hp_emb.data_ptr(),
+                                       w.pos_phore.data_ptr(), plan.phore2ctx.data_ptr(), None, w.x[0].data_ptr(), hip.stream_ptr()),
+                      'pg_embed_ctx')
             eng.fork_lanes((2, 3))                     # (the initial state was written on the caller's stream)
             with torch.cuda.stream(s2):
                 w.in_t_next.fill_(step)
             eng._run(eng.prog_ahead)
         elif st.next_step != step:
             raise RuntimeError(f'phoregen_amd: pipelined sampler state expects step {st.next_step}, got {step}')
-        tb = st.t_buf[step & 1]
-        tb.fill_(step)
-        _, st.x0, _ = eng.step_forward()
+        tb = st.t_table.data_ptr() + step * st.t_table.stride(0) * 8        # the [B] row `step` of the table: no fill launch
+        _, x0_ctx, _ = eng.step_forward()
         cur = st.cur
         hip.check(lib.pg_posterior_categorical(
-            w.out_v.data_ptr(), st.log_node[cur].data_ptr(), plan.lig_graph.data_ptr(), tb.data_ptr(),
+            w.out_v.data_ptr(), st.log_node[cur].data_ptr(), plan.lig_graph.data_ptr(), tb,
             pk.node_tab[0].data_ptr(), pk.node_tab[1].data_ptr(), N, 12, None, st.seed, 0, step,
             plan.g_lig_off.data_ptr(), st.graph_key.data_ptr(),
             st.log_node[1 - cur].data_ptr(), w.in_h_node.data_ptr(), tp(st.node_traj), s2.cuda_stream), 'posterior(node)')
         hip.check(lib.pg_posterior_categorical(
-            w.out_bond.data_ptr(), st.log_edge[cur].data_ptr(), plan.bond_graph.data_ptr(), tb.data_ptr(),
+            w.out_bond.data_ptr(), st.log_edge[cur].data_ptr(), plan.bond_graph.data_ptr(), tb,
             pk.edge_tab[0].data_ptr(), pk.edge_tab[1].data_ptr(), E, 6, None, st.seed, 1, step,
             plan.g_bond_off.data_ptr(), st.graph_key.data_ptr(),
             st.log_edge[1 - cur].data_ptr(), w.in_h_edge.data_ptr(), tp(st.edge_traj), s3.cuda_stream), 'posterior(edge)')
@@ -581,12 +587,13 @@ class PhoreDiff(nn.Module):
                     int(not atom), hip.ptr(st.gc), st.guidance_batch, st.cnt_ws.data_ptr(), st.mean_ws.data_ptr(),
                     st.gtmp.data_ptr(), s), 'guidance')
                 grad += st.gtmp
-        hip.check(lib.pg_posterior_position(
-            w.in_pos.data_ptr(), st.x0.data_ptr(), plan.lig_graph.data_ptr(), tb.data_ptr(),
+        hip.check(lib.pg_posterior_position_ctx(
+            w.in_pos.data_ptr(), x0_ctx.data_ptr(), plan.lig2ctx.data_ptr(), plan.lig_graph.data_ptr(), tb,
             pk.pos_tab[0].data_ptr(), pk.pos_tab[1].data_ptr(), pk.pos_tab[2].data_ptr(), hip.ptr(grad), None,
             st.seed, 2, step, N, plan.g_lig_off.data_ptr(), st.graph_key.data_ptr(),
             st.centers.data_ptr() if st.return_traj else None,
-            w.in_pos.data_ptr(), tp(st.pos_traj), s), 'posterior(pos)')
+            w.in_pos.data_ptr(), tp(st.pos_traj), w.x[0].data_ptr(), st.x0_buf.data_ptr(), s), 'posterior(pos)')
+        st.x0 = st.x0_buf
         st.cur = 1 - cur
         st.next_step = step - 1
         if last:
