@@ -106,6 +106,7 @@ class Engine:
         #  lane 3; the replay variant, off by default and measured slower, keeps the previous list)
         self.ahead_v2 = (o['ahead_v2'] == 'always' or (o['ahead_v2'] == 'auto' and self.plan.n_bond < o['ahead_v2_below'])) and not o['graph']
         self.step_ahead = o['step_ahead']
+        self.head_early = o['sa_head_early']
         self.pos_tiled, self.pos_tiled_below = o['pos_tiled'], o['pos_tiled_below']
         self.tri_grid = o['tri_grid']                  # persistent triplet workgroups (-1: by batch size)
         # apply_dx + bond smearing + direction vectors as one launch on lane 0: small batches (measured, same box: 16 graphs 3.52 -> 3.40 ms
@@ -683,6 +684,8 @@ class Engine:
             self._gemm(prog, w.aggE, 128, L.W_lin2[:, :128], w.lin_tmp, n, 128, bias=L.b_lin, add1=hc)
             self._gemm(prog, w.aggB, 128, L.W_lin2[:, 128:], hn, n, 128, add1=w.lin_tmp)
             self._mark(prog, f'A{li}', w.aggE, w.aggB, lane=1)      # (the next layer's bond-node attention may overwrite aggB from here on)
+            if step_ahead and self.head_early and li == n_layers - 1 and heads is not None:
+                hn_done = self._record(prog, 1)        # h' of the last layer: the node head's only input
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
             # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
             # only for ligand atoms
@@ -712,12 +715,22 @@ class Engine:
             # hipGraph capture, PG_GRAPH=1)
             qlane = 2 if last else 3
             # (releasing lanes 2 / 3 in FRONT of lane 0's wait above -- they need nothing of lane 1 -- measured slower: 16 graphs 3.10 vs 3.05 ms)
-            self._fork(prog, (2, 3) if (ahead and li + 1 < n_layers) else (qlane,))
+            early = step_ahead and last and self.head_early
+            if early:
+                # pipelined step: the node head (and behind it the node posterior and the next step's products) needs h' only -- it does not
+                # wait for the triplet kernel (this lane-2-waits-lane-1 edge is what the hipGraph capture of the plain list cannot have)
+                self._wait(prog, 2, hn_done)
+                self._lane = 2
+                heads[1](hn)
+                if not v2:
+                    self._fork(prog, (2,))             # Y2: lane 0 has waited for lane 1 above
+            else:
+                self._fork(prog, (2, 3) if (ahead and li + 1 < n_layers) else (qlane,))
             self._lane = qlane
             if not v2:
                 self._query_gemm(prog, L.PB, w.Y2, 5 * 128, lig, 1)
                 q_done = self._record(prog, qlane)     # (this point of the lane: the node head below is not waited for)
-            if last:
+            if last and not early:
                 heads[1](hn)                           # lane 2 has nothing else left in this step: the node head takes it
             elif ahead and li + 1 < n_layers:
                 # ---- the NEXT layer's products that do not depend on the new coordinates: its first-layer blocks (h' is final:

@@ -28,6 +28,7 @@ DEFAULTS = dict(
     step_ahead=True,      # the sampler loop as a software pipeline over reverse steps: the categorical posteriors behind their heads on the side
                           # lanes, the NEXT step's feature embedding and layer 0's coordinate-free products (first-layer blocks, queries, bond-node
                           # sub-layer) behind them, beside the last layer's position phase / the Gaussian posterior (`Engine.pipelined_programs`)
+    sa_head_early=True,   # ... the node head of a pipelined step right behind the last lin_node (it needs h' only), not behind the triplet kernel
     c_program=True,       # a forward = ONE call into the library (pg_program_run walks the launch list); False: the list is walked from Python
     order_points=True,    # cross-lane order points as device-scope HIP events (pg_order_point_*); False: torch.cuda.Event()
     geom_split='auto',    # ahead_v2: the layer's closing launch (pg_layer_geom) once per chain, on the chain's own lane: 'auto' = batches
