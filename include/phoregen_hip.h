@@ -377,6 +377,11 @@ typedef struct {
                                               MLP path and fits 512 registers without spilling); the value pass leaves d logit (position update: one
                                               scalar per row) and its d feat rows there for the key pass.  Same gradients up to the order of the
                                               weight-gradient atomics. */
+  int tri_form;                            /* PG_SEG_TRIPLET, ligands of up to 64 atoms, Cdst_v == Cdst_k + 128: 0 = one wave per 16-row tile
+                                              (csrc/seg_attn_bwd.hip; the forms above); 1 / 2 = the channels of a tile split over the waves of a
+                                              workgroup (csrc/triplet_bwd2.hip: nothing of the forward is read back -- alpha, S, swn, dlogit, gfeat_v,
+                                              rowbuf unused; same gradients up to summation order): 1 = 4 waves x 32 channels, 2 = ligands of up to
+                                              32 atoms on 8 waves x 16 channels and the larger ones in a second launch of the 4-wave form */
 } PgSegAttnGrad;
 int pg_seg_attn_bwd_waves(int mode);
 int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* g, void* stream);

@@ -420,7 +420,7 @@ int num_cu() {
 using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
-extern "C" int pg_abi_version(void) { return 9; }
+extern "C" int pg_abi_version(void) { return 10; }
 
 // ---- order points between the streams of one step (include/phoregen_hip.h) ----
 // An event here only orders kernels of this device against each other: it needs neither a timestamp nor the system-scope fence (L2

@@ -1078,6 +1078,8 @@ static int launch_bwd_split(const PgTopo* t, const PgSegAttn* p, const PgSegAttn
   return launch_bwd<MODE, 4, OP, 2>(t, p, gr, st);
 }
 
+int triplet_bwd2_launch(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, hipStream_t st);   // triplet_bwd2.hip
+
 }  // namespace pg
 
 using namespace pg;
@@ -1120,6 +1122,7 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
       // the per-source-atom rows (max_nlig x 259 floats) share the LDS with the per-wave tiles: 4 waves up to 64 atoms,
       // 2 waves up to the reference's maximum of 78 (and beyond, to 96)
       const bool op = gr->alpha && gr->S && gr->swn;
+      if (gr->tri_form && t->max_nlig <= 64 && p->Cdst_v == p->Cdst_k + 128) return triplet_bwd2_launch(t, p, gr, st);   // (Cdst k | v: one 1 KB row)
       if (op && gr->dlogit && gr->gfeat_v && t->max_nlig <= 64) return launch_bwd_split<PG_SEG_TRIPLET>(t, p, gr, st);
       if (t->max_nlig <= 64) return op ? launch_bwd<PG_SEG_TRIPLET, 4, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
       return op ? launch_bwd<PG_SEG_TRIPLET, 2, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 2>(t, p, gr, st);

@@ -59,7 +59,7 @@ class PgSegAttnGrad(C.Structure):
                 ('gW2xv_l', c_fp), ('gb2xv', c_fp), ('gx', c_fp), ('gnrm', c_fp), ('gew', c_fp),
                 ('alpha', c_fp), ('alpha_rows', C.c_int), ('S', c_fp), ('swn', c_fp),
                 ('rowbuf', c_fp), ('rowbuf_rows', C.c_int), ('grid', C.c_int), ('atom_order', c_ip),
-                ('dlogit', c_fp), ('gfeat_v', c_fp)]
+                ('dlogit', c_fp), ('gfeat_v', c_fp), ('tri_form', C.c_int)]
 
 
 PG_PROGRAM_LANES, PG_LAUNCH_MAX_ARGS = 4, 12

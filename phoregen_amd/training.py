@@ -451,6 +451,10 @@ class SegCoreFn(torch.autograd.Function):
         rows = (cfg['max_rows'] + 15) // 16 * 16
         rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
         g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
+        if cfg['mode'] == hip.SEG_TRIPLET and options.get('tri_bwd_form') and cfg['max_rows'] <= 64:
+            g.tri_form = int(options.get('tri_bwd_form'))
+            grid = max(1, min(cfg['n_seg'], options.get('tri_bwd_grid')))
+            g.grid = grid
         if cfg['mode'] == hip.SEG_TRIPLET and cfg.get('plan') is not None and options.get('bwd_atom_sort'):
             ao = cfg['plan'].bwd_atom_order(grid)          # cost-sorted source atoms, dealt out in a snake (levels the persistent workgroups)
             g.atom_order = ao.data_ptr()

@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pg_abi_version() == 9
+    assert lib.pg_abi_version() == 10
     assert isinstance(lib.pg_last_error(), bytes)
 
 
