@@ -59,16 +59,17 @@ struct Tb2Layout {
   // floats
   static constexpr int o_op = 0;                                  // operands of a segment, landed by LDS-DMA: U [2048] | dS [2048] | Cdst k|v [256]
                                                                   // (first: the DMA's LDS base register holds 16 bits, the stage must end below 64 KB)
-  static constexpr int o_b = o_op + 4352;                         // b'_k[128] | b'_v[128]
+  static constexpr int o_b = o_op + 2 * 4352;                     // (two stages: a segment's operands are read where they are used)   b'_k[128] | b'_v[128]
   static constexpr int o_stat = o_b + 256;                        // [2 paths][MAXT][16 rows][NW]
   static constexpr int o_y = o_stat + 2 * MAXT * 16 * NW;         // [2][MAXT][NW][YT]
   static constexpr int o_rs = o_y + 2 * MAXT * NW * YT;           // rstd of every row [2][ROWS]
   static constexpr int o_q = o_rs + 2 * ROWS;                     // rstd_k d logit | rstd_v alpha  [2][MAXT][QT]
   static constexpr int o_s1 = o_q + 2 * MAXT * QT;                // [2 parity][2 paths][16][NW]
-  static constexpr int o_df = o_s1 + 2 * 2 * 16 * NW;             // [2 parity][NW][64][4]
-  static constexpr int o_feat = o_df + 2 * NW * 256;              // [2 parity][MAXT][16][17]
-  static constexpr int o_gq = o_feat + 2 * MAXT * 16 * 17;        // d feat tile of the geometry step [16][17]
-  static constexpr int o_x = o_gq + 16 * 17;                      // x_k [ROWS][3]
+  static constexpr int o_df = o_s1 + 2 * 2 * 16 * NW;             // d feat partial sums of a segment's tiles [MAXT][NW][64][4]
+  static constexpr int o_feat = o_df + MAXT * NW * 256;           // [3 segments in flight][MAXT][16][17]
+  static constexpr int o_gq = o_feat + 3 * MAXT * 16 * 17;        // d feat tiles of the geometry steps [MAXT][16][17]
+  static constexpr int o_gij = o_gq + MAXT * 16 * 17;             // d x_j | d x_i of a geometry step [MAXT][8]
+  static constexpr int o_x = o_gij + MAXT * 8;                    // x_k [ROWS][3]
   static constexpr int o_accx = o_x + ROWS * 3;                   // d x [ROWS][3]
   static constexpr int o_wave = o_accx + ROWS * 3;                // per wave: tT [CW][17]
   static constexpr int PW = CW * 17 + 3;                          // (odd tile stride between the waves)
@@ -104,11 +105,6 @@ __device__ __forceinline__ void tb2_dma(unsigned lds_dst, unsigned voff, tb2_i4 
                :: "s"(lds_dst), "v"(voff), "s"(desc), "s"(soff) : "memory");
 }
 
-struct Tb2Pend {      // geometry adjoint of a tile step, run behind the next barrier
-  int valid, t, par, li, buf;
-  float xi[3];
-};
-
 }  // namespace
 
 #ifndef PG_TB2_MINWAVES
@@ -132,16 +128,17 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
   float* const sAccX = lds + Ly::o_accx;
   float* const sRs = lds + Ly::o_rs;
   float* const sQ = lds + Ly::o_q;
-  float* const qT = lds + Ly::o_gq;
+  float* const sGq = lds + Ly::o_gq;
+  float* const sGij = lds + Ly::o_gij;
   float* const tT = lds + Ly::o_wave + wave * Ly::PW;
   float* const sOp = lds + Ly::o_op;
   // the 17 one-KB pieces of a segment's operands (8 of U, 8 of d S, the Cdst row k | v), dealt out over the waves; `lds` is the kernel's
   // only LDS object, so a float offset into it is the LDS address
-  auto stage_operands = [&](int seg_next) {
+  auto stage_operands = [&](int seg_next, int ob) {
     const tb2_i4 dU = tb2_desc(p.U + (size_t)seg_next * 2048, 8192), dM = tb2_desc(gr.gS + (size_t)seg_next * 2048, 8192);
     const tb2_i4 dC = tb2_desc(p.Cdst_k + (size_t)seg_next * p.ld_cdst, 1024);
     for (int pc = __builtin_amdgcn_readfirstlane(wave); pc < 17; pc += NW) {
-      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((Ly::o_op + pc * 256) * 4);
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((Ly::o_op + ob * 4352 + pc * 256) * 4);
       const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((pc & 7) * 1024);
       if (pc < 8) tb2_dma(dst, 16u * lane, dU, so);
       else if (pc < 16) tb2_dma(dst, 16u * lane, dM, so);
@@ -151,7 +148,7 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
   constexpr int YT = Ly::YT, QT = Ly::QT, ROWS = Ly::ROWS;
 
   for (int i = tid; i < 128; i += blockDim.x) { sB[i] = p.ln_bk[i]; sB[128 + i] = p.ln_bv[i]; }
-  for (int i = tid; i < 2 * MAXT * 16 * 17; i += blockDim.x) sFeat[i] = 0.f;      // (columns 12..16 stay zero)
+  for (int i = tid; i < 3 * MAXT * 16 * 17; i += blockDim.x) sFeat[i] = 0.f;      // (columns 12..16 stay zero)
   __syncthreads();
 
   // kernel-long operands of the wave's channels
@@ -203,25 +200,28 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
     }
   };
 
-  // geometry adjoint of a finished tile step: d feat (the waves' partial sums) -> d theta -> d x_k, d x_i, d x_j (all into sAccX)
-  auto geometry = [&](const Tb2Pend& pe, int n, int lj, const float (&xj)[3]) {
+  // geometry adjoint of tile tt of a finished segment j -> i: d feat (the waves' partial sums) -> d theta -> d x_k (sAccX rows, owned by
+  // the tile), d x_j | d x_i (one slot per tile in sGij, added up by one thread behind the next barrier).  The tiles of a segment run side by
+  // side on different waves, next to the waves that compute the next segment's features.
+  auto geometry = [&](int tt, int fb, int n, int li, int lj, const float (&xi)[3], const float (&xj)[3]) {
+    float* const qT = sGq + tt * 16 * 17;
     f4 df = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) df += *reinterpret_cast<const f4*>(sDf + ((pe.buf * NW + w2) * 64 + lane) * 4);
+    for (int w2 = 0; w2 < NW; ++w2) df += *reinterpret_cast<const f4*>(sDf + ((tt * NW + w2) * 64 + lane) * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) qT[(4 * g + r) * 17 + m] = df[r];      // d feat[row 4g + r][f = m]
     wave_lds_sync();
     float gsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int k = 16 * pe.t + m;
-    if (g == 0 && k < n && k != pe.li && k != lj) {
+    const int k = 16 * tt + m;
+    if (g == 0 && k < n && k != li && k != lj) {
       const float* gf = qT + m * 17;
-      const float* ff = sFeat + ((pe.par * MAXT + pe.t) * 16 + m) * 17;
+      const float* ff = sFeat + ((fb * MAXT + tt) * 16 + m) * 17;
       float gth = gf[0];
 #pragma unroll
       for (int f = 1; f < 6; ++f) gth += kAngFreq[f] * (gf[f] * ff[f + 5] - gf[f + 5] * ff[f]);
       float u[3], v[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { u[c] = xj[c] - pe.xi[c]; v[c] = sX[k * 3 + c] - pe.xi[c]; }
+      for (int c = 0; c < 3; ++c) { u[c] = xj[c] - xi[c]; v[c] = sX[k * 3 + c] - xi[c]; }
       const float a = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
       const float cr[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
       const float b = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
@@ -237,18 +237,24 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
           const float gv = ka * u[c] + kb * cxu[c];
           gsum[c] = gu;
           gsum[3 + c] = -(gu + gv);
-          sAccX[k * 3 + c] += gv;                    // (one geometry step at a time per workgroup: plain read-modify-write)
+          sAccX[k * 3 + c] += gv;                    // (row k belongs to this tile, and k != i, j)
         }
       }
     }
-    wave_lds_sync();
 #pragma unroll
     for (int c = 0; c < 6; ++c) gsum[c] = row16_total(gsum[c]);
     if (lane == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { sAccX[lj * 3 + c] += gsum[c]; sAccX[pe.li * 3 + c] += gsum[3 + c]; }
+      for (int c = 0; c < 6; ++c) sGij[tt * 8 + c] = gsum[c];
     }
-    wave_lds_sync();
+  };
+  // ... and the one thread that adds the tiles' d x_j | d x_i slots up (behind the barrier that follows the geometry steps)
+  auto geometry_fold = [&](int nt, int li, int lj) {
+    if (tid == 0) {
+      for (int tt = 0; tt < nt; ++tt)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sAccX[lj * 3 + c] += sGij[tt * 8 + c]; sAccX[li * 3 + c] += sGij[tt * 8 + 3 + c]; }
+    }
   };
 
 #ifdef PG_TB2_PROF
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
         Pv[tt][tb] = have ? lv : z4;
       }
     }
-    if (n > 1) stage_operands(eid_g[lj * n + (lj == 0 ? 1 : 0)]);
+    if (n > 1) stage_operands(eid_g[lj * n + (lj == 0 ? 1 : 0)], 0);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();                              // sX is there
     if (n > 1) {
@@ -300,39 +306,29 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
     }
     __syncthreads();
 
-    Tb2Pend pend;
-    pend.valid = 0; pend.t = 0; pend.par = 0; pend.li = 0; pend.buf = 0;
-    pend.xi[0] = pend.xi[1] = pend.xi[2] = 0.f;
+    int li_prev = 0;                              // the finished segment whose geometry step is still to run
+    float xi_prev[3] = {0.f, 0.f, 0.f};
     TB2_STAMP(0);
     int step = 0;                                 // tile steps of this atom so far (selects the double buffers)
 
     for (int sidx = 0; sidx < n - 1; ++sidx) {
       const int li = sidx < lj ? sidx : sidx + 1;
       const int seg = eid_g[lj * n + li];
-      const int par = sidx & 1;
+      const int par = sidx % 3, ob = sidx & 1;      // feature buffer (three segments in flight), operand stage
       float xi[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) xi[c] = sX[li * 3 + c];
 
-      // per-segment operands of the wave's channels, out of the LDS stage (landed during the previous segment)
-      f4 cdk[NB], cdv[NB], Ub[NB], Mb[NB], Ua[NB], Ma[NB];
-      {
-        const float* Us = sOp;
-        const float* Ms = sOp + 2048;
+      // the next segment's operands start to land in the other stage (its readers, the B steps of the previous segment, are done);
+      // this segment's are read out of its stage where they are used
+      if (sidx + 1 < n - 1) stage_operands(eid_g[lj * n + ((sidx + 1) < lj ? sidx + 1 : sidx + 2)], ob ^ 1);
+      const float* const Us = sOp + ob * 4352;
+      const float* const Ms = Us + 2048;
+      f4 cdk[NB], cdv[NB];
 #pragma unroll
-        for (int tb = 0; tb < NB; ++tb) {
-          const int tq = NB * wave + tb;
-          cdk[tb] = *reinterpret_cast<const f4*>(sOp + 4096 + c0 + 16 * tb + 4 * g);
-          cdv[tb] = *reinterpret_cast<const f4*>(sOp + 4096 + 128 + c0 + 16 * tb + 4 * g);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {           // B layout: [c = 16 tq + 4g + r][h = m]
-            Ub[tb][r] = Us[(tq * 4 + r) * 64 + lane];
-            Mb[tb][r] = Ms[(tq * 4 + r) * 64 + lane];
-          }
-          // A layout: [c = 16 tq + m][h = 4g + ks], ks = 0..3 contiguous in the lane-fixed rows
-          Ua[tb] = *reinterpret_cast<const f4*>(Us + (tq * 4 + (m & 3)) * 64 + (m >> 2) * 16 + 4 * g);
-          Ma[tb] = *reinterpret_cast<const f4*>(Ms + (tq * 4 + (m & 3)) * 64 + (m >> 2) * 16 + 4 * g);
-        }
+      for (int tb = 0; tb < NB; ++tb) {
+        cdk[tb] = *reinterpret_cast<const f4*>(Us + 4096 + c0 + 16 * tb + 4 * g);
+        cdv[tb] = *reinterpret_cast<const f4*>(Us + 4096 + 128 + c0 + 16 * tb + 4 * g);
       }
       const int hh_sm = (16 / NW) * wave + lane / (64 / (16 / NW));
       const float gsw = gr.gswn[(size_t)seg * 16 + hh_sm];       // (the softmax lanes' head; requested early)
@@ -368,10 +364,6 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
       TB2_STAMP(2);
       __syncthreads();                            // barrier 1
       TB2_STAMP(3);
-      if (sidx + 1 < n - 1) stage_operands(eid_g[lj * n + ((sidx + 1) < lj ? sidx + 1 : sidx + 2)]);
-      if (pend.valid && wave == (pend.buf + 1) % NW) geometry(pend, n, lj, xj);      // last tile step of the previous segment
-      pend.valid = 0;
-      TB2_STAMP(4);
 
       // ---------------- A2: statistics, z, partial projections ----------------
       float rsK[MAXT], sgK[MAXT], rsV[MAXT], sgV[MAXT];
@@ -392,9 +384,10 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
 #pragma unroll
           for (int tb = 0; tb < NB; ++tb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              yk = mfma16(fmaxf(fmaf(bC[0][tb][r], sgK[tt], hK[tt][tb][r]), 0.f), Ub[tb][r], yk);
-              yv = mfma16(fmaxf(fmaf(bC[1][tb][r], sgV[tt], hV[tt][tb][r]), 0.f), Mb[tb][r], yv);
+            for (int r = 0; r < 4; ++r) {           // B layout of U / dS: [c = 16 tq + 4g + r][h = m]
+              const int uo = ((NB * wave + tb) * 4 + r) * 64 + lane;
+              yk = mfma16(fmaxf(fmaf(bC[0][tb][r], sgK[tt], hK[tt][tb][r]), 0.f), Us[uo], yk);
+              yv = mfma16(fmaxf(fmaf(bC[1][tb][r], sgV[tt], hV[tt][tb][r]), 0.f), Ms[uo], yv);
             }
           *reinterpret_cast<f4*>(sY + ((0 * MAXT + tt) * NW + wave) * YT + 72 * g + 4 * m) = yk;
           *reinterpret_cast<f4*>(sY + ((1 * MAXT + tt) * NW + wave) * YT + 72 * g + 4 * m) = yv;
@@ -410,9 +403,14 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
         float xi1[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) xi1[c] = sX[li1 * 3 + c];
-        for (int tt = wave; tt < nt; tt += NW) features(par ^ 1, tt, n, li1, lj, xi1, xj);
+        for (int tt = wave; tt < nt; tt += NW) features((sidx + 1) % 3, tt, n, li1, lj, xi1, xj);
       }
       TB2_STAMP(7);
+      // the geometry steps of the previous segment, on the waves behind the feature waves
+      if (sidx > 0)
+        for (int tt = 0; tt < nt; ++tt)
+          if (wave == (nt + tt) % NW) geometry(tt, (sidx + 2) % 3, n, li_prev, lj, xi_prev, xj);
+      TB2_STAMP(4);
 
       // ---------------- softmax over the segment's rows, d logit: wave w takes the heads [HW w, HW w + HW) ----------------
       // lane = (head hs of the wave, row slot): rows slot, slot + RS, ...; the results go to LDS for every wave:
@@ -464,6 +462,7 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
       TB2_STAMP(8);
       __syncthreads();                            // barrier 2b
       TB2_STAMP(14);
+      if (sidx > 0) geometry_fold(nt, li_prev, lj);
 
       f4 gU[NB], gCk[NB], gCv[NB];
 #pragma unroll
@@ -499,8 +498,11 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
 #pragma unroll
           for (int tb = 0; tb < NB; ++tb) {
             f4 zk = {0.f, 0.f, 0.f, 0.f}, zv = {0.f, 0.f, 0.f, 0.f};
+            // A layout of U / dS: [c = 16 tq + m][h = 4g + ks], ks = 0..3 contiguous in the lane-fixed rows
+            const int ao = ((NB * wave + tb) * 4 + (m & 3)) * 64 + (m >> 2) * 16 + 4 * g;
+            const f4 Ua = *reinterpret_cast<const f4*>(Us + ao), Ma = *reinterpret_cast<const f4*>(Ms + ao);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { zk = mfma16(Ua[tb][ks], dlT[ks], zk); zv = mfma16(Ma[tb][ks], alT[ks], zv); }
+            for (int ks = 0; ks < 4; ++ks) { zk = mfma16(Ua[ks], dlT[ks], zk); zv = mfma16(Ma[ks], alT[ks], zv); }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float pk = fmaf(bC[0][tb][r], sgK[tt], hK[tt][tb][r]), pv = fmaf(bC[1][tb][r], sgV[tt], hV[tt][tb][r]);
@@ -523,9 +525,6 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
           TB2_STAMP(9);
           __syncthreads();                        // barrier 3 + tt
           TB2_STAMP(10);
-          if (pend.valid && wave == (pend.buf + 1) % NW) geometry(pend, n, lj, xj);    // the previous tile of this segment
-          pend.valid = 0;
-          TB2_STAMP(4);
           {
             float tk = 0.f, tv = 0.f;
 #pragma unroll
@@ -553,7 +552,7 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
               dfp = mfma16(dV[tb][r], wfB[1][tb][r], dfp);
             }
           }
-          *reinterpret_cast<f4*>(sDf + ((buf * NW + wave) * 64 + lane) * 4) = dfp;
+          *reinterpret_cast<f4*>(sDf + ((tt * NW + wave) * 64 + lane) * 4) = dfp;
           // d Wf[c, f] += sum_row d hidden[c, row] feat[row, f]: d hidden^T through the LDS tile, one path after the other
           const float* fb = sFeat + ((par * MAXT + tt) * 16 + 4 * g) * 17 + m;
           f4 fB;
@@ -573,8 +572,6 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
               for (int tb = 0; tb < NB; ++tb) gWf[a][tb] = mfma16(tT[(16 * tb + m) * 17 + 4 * g + ks], fB[ks], gWf[a][tb]);
           }
           wave_lds_sync();
-          pend.valid = 1; pend.t = tt; pend.par = par; pend.li = li; pend.buf = buf;
-          pend.xi[0] = xi[0]; pend.xi[1] = xi[1]; pend.xi[2] = xi[2];
           ++step;
           TB2_STAMP(11);
         }
@@ -601,11 +598,17 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
           }
         }
       }
+      li_prev = li;
+      xi_prev[0] = xi[0]; xi_prev[1] = xi[1]; xi_prev[2] = xi[2];
       TB2_STAMP(12);
     }  // segments
 
     __syncthreads();
-    if (pend.valid && wave == (pend.buf + 1) % NW) geometry(pend, n, lj, xj);
+    if (n > 1)
+      for (int tt = 0; tt < nt; ++tt)
+        if (wave == tt % NW) geometry(tt, (n - 2) % 3, n, li_prev, lj, xi_prev, xj);
+    __syncthreads();
+    if (n > 1) geometry_fold(nt, li_prev, lj);
     __syncthreads();
     // d P rows of the source atom: every row k -> j is written once
 #pragma unroll

@@ -51,8 +51,9 @@ DEFAULTS = dict(
     bwd_split='all',      # training: the triplet, knn-node and knn-position adjoints as a value pass + a key pass (one MLP path per wave:
                           # no spills at 512 registers; PgSegAttnGrad.dlogit): 'all', 'knn' = the knn adjoints only, 'none' = both paths in one wave
     bwd_grid=256,         # training: persistent workgroups of pg_seg_attn_bwd (one per CU)
-    tri_bwd_form=0,       # training: triplet adjoint 0 = one wave per row tile (csrc/seg_attn_bwd.hip), 1 / 2 = the channels of a tile over the
-                          # 4 / 8 waves of a workgroup (csrc/triplet_bwd2.hip; ligands of up to 64 atoms)
+    tri_bwd_form=2,       # training: triplet adjoint 0 = one wave per row tile (csrc/seg_attn_bwd.hip); the channels of a tile over the waves of
+                          # a workgroup (csrc/triplet_bwd2.hip; ligands of up to 64 atoms): 1 = 4 waves, 2 = 8 waves for ligands of up to
+                          # 32 atoms + the 4-wave form for the larger ones
     tri_bwd_grid=256,     # ... persistent workgroups of the channel-split form
 )
 

@@ -375,7 +375,9 @@ class SegCoreFn(torch.autograd.Function):
             if tf.get('n_tri_iters') and options.get('tri_staged'):
                 # source-atom groups of the plan: the LDS-staged kernel (csrc/triplet2.hip, training form) takes the launch
                 s.tri_iters, s.n_tri_iters, s.tri_counter = tf['tri_iters'].data_ptr(), tf['n_tri_iters'], tf['tri_counter'].data_ptr()
-            if cfg['max_rows'] <= 80 and onepass:   # the tuned kernel runs: it can hand the softmax weights to the adjoint
+            # the tuned kernel runs: it can hand the softmax weights to the one-wave-per-tile adjoint (the channel-split adjoint,
+            # options.tri_bwd_form, recomputes them and reads nothing of the forward back)
+            if cfg['max_rows'] <= 80 and onepass and not (options.get('tri_bwd_form') and cfg['max_rows'] <= 64):
                 arows = (cfg['max_rows'] + 15) // 16 * 16
                 alpha = torch.empty(cfg['n_seg'] * arows * 16, dtype=torch.float32, device=dev)
                 s.alpha, s.alpha_rows = alpha.data_ptr(), arows

@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export PHOREGEN_DEBUG=1
-for args in "1,2 0 4" "1,2 1 16" "1,2 2 8" "2 2 256"; do echo "== $args"; timeout 200 python3 tools/ab_tri_bwd.py $args 2>&1 | grep -v Warning | grep "ligands\|fault\|Error" | cut -c1-200; done > gpurun_out/tb2_ab.txt 2>&1
-cat gpurun_out/tb2_ab.txt
-run() { timeout 300 python3 tools/bench_train.py --steps 6 --warmup 2 $2 > gpurun_out/tb2_x.json 2> gpurun_out/tb2_x.err; python3 -c "
-import json; d=json.loads(open('gpurun_out/tb2_x.json').read().strip().splitlines()[-1]); print('$1', d['value'], d.get('last_loss'), d.get('peak_mem_gb'))"; }
-for f in 0 2 0 2 1; do PG_TRI_BWD_FORM=$f run "form $f config5" ""; done
+timeout 1200 python3 -m pytest tests/test_gpu_training.py -x -q -m gpu 2>&1 | tail -8
+timeout 300 python3 bench.py --train > gpurun_out/tb2_train_line.json 2> gpurun_out/tb2_x.err; python3 -c "
+import json; d=json.loads(open('gpurun_out/tb2_train_line.json').read().strip().splitlines()[-1]); print(d['value'], d.get('peak_mem_gb'), d.get('roofline'))"
