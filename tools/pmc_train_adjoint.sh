@@ -14,18 +14,18 @@ done
 python3 - $out $tag <<'PY'
 import csv, glob, json, subprocess, sys, collections
 root, tag = sys.argv[1], sys.argv[2]
-pat = 'seg_attn_bwd_kernel<4'
+pats = ('seg_attn_bwd_kernel<4', 'triplet_bwd2_kernel')
 # the adjoint is one launch of the C ABI and one (both MLP paths in a wave) or two (value pass + key pass) kernels: per kernel name the
 # mean over its dispatches, then the sum over the names = per adjoint launch
 acc, dur = collections.defaultdict(lambda: collections.defaultdict(list)), collections.defaultdict(list)
 short = lambda n: n.split('(')[0].replace('void ', '')
 for f in glob.glob(root + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if pat in r['Kernel_Name']:
+        if any(q in r['Kernel_Name'] for q in pats):
             acc[r['Counter_Name']][short(r['Kernel_Name'])].append(float(r['Counter_Value']))
 for f in glob.glob(root + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if pat in r['Kernel_Name']:
+        if any(q in r['Kernel_Name'] for q in pats):
             dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 avg = {k: sum(sum(v) / len(v) for v in by.values()) for k, by in acc.items()}
 name = ' + '.join(sorted(dur))
