@@ -27,6 +27,9 @@ extern "C" {
 
 const char* pg_last_error(void);
 int pg_abi_version(void);
+/* sizeof(PgGemm), sizeof(PgTopo), sizeof(PgSegAttn), sizeof(PgSegAttnGrad), sizeof(PgLaunch) of the library's build -> out[0..n); returns 5.
+ * A binding that mirrors the structs (phoregen_amd/hip.py) compares them with its own when it loads the library. */
+int pg_abi_struct_sizes(int* out, int n);
 
 /* ---- order points between the HIP streams one denoiser step is spread over (phoregen_amd/engine.py; the reference has no
  * counterpart: it runs on one torch stream).  An event without timestamp whose record is a DEVICE-scope release

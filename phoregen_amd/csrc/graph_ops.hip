@@ -421,6 +421,12 @@ using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
 extern "C" int pg_abi_version(void) { return 10; }
+// sizeof of the argument structs as THIS build sees them (a binding's mirror is checked against it when the library is loaded)
+extern "C" int pg_abi_struct_sizes(int* out, int n) {
+  const int v[5] = {(int)sizeof(PgGemm), (int)sizeof(PgTopo), (int)sizeof(PgSegAttn), (int)sizeof(PgSegAttnGrad), (int)sizeof(PgLaunch)};
+  for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+  return 5;
+}
 
 // ---- order points between the streams of one step (include/phoregen_hip.h) ----
 // An event here only orders kernels of this device against each other: it needs neither a timestamp nor the system-scope fence (L2

@@ -78,11 +78,13 @@ PROGRAM_OPS = {'pg_gemm': 2, 'pg_seg_attn': 3, 'pg_embed_ctx': 4, 'pg_embed_bond
 SEG_KNN_NODE, SEG_KNN_POS, SEG_BOND_NODE, SEG_BOND_POS, SEG_TRIPLET, SEG_PHORE = range(6)
 ACT_NONE, ACT_SSP, ACT_RELU = 0, 1, 2
 
+ABI_VERSION = 10
 _lib = None
 
 _PROTOS = {
     'pg_last_error': (C.c_char_p, []),
     'pg_abi_version': (C.c_int, []),
+    'pg_abi_struct_sizes': (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     'pg_order_point_create': (C.c_int, [C.POINTER(C.c_void_p)]),
     'pg_order_point_destroy': (C.c_int, [C.c_void_p]),
     'pg_order_point_record': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -153,6 +155,15 @@ def load_library(path=None):
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    # the mirrors above against the build that was loaded: a stale .so (or a header edited without its mirror) fails here, not in a kernel
+    if lib.pg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'phoregen_amd: {path} has ABI version {lib.pg_abi_version()}, this package binds version {ABI_VERSION}: rebuild it')
+    sizes = (C.c_int * 5)()
+    lib.pg_abi_struct_sizes(sizes, 5)
+    mine = [C.sizeof(x) for x in (PgGemm, PgTopo, PgSegAttn, PgSegAttnGrad, PgLaunch)]
+    if list(sizes) != mine:
+        raise RuntimeError(f'phoregen_amd: struct sizes of {path} {list(sizes)} differ from the ctypes mirrors {mine} '
+                           '(PgGemm, PgTopo, PgSegAttn, PgSegAttnGrad, PgLaunch)')
     _lib = lib
     return lib
 
