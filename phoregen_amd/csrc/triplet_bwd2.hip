@@ -373,12 +373,14 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
         if (tt < nt) {
           float qk = 0.f, qv = 0.f;
 #pragma unroll
-          for (int w2 = 0; w2 < NW; ++w2) {
-            qk += sStat[((0 * MAXT + tt) * 16 + m) * NW + w2];
-            qv += sStat[((1 * MAXT + tt) * 16 + m) * NW + w2];
+          for (int w4 = 0; w4 < NW; w4 += 4) {          // the waves' partial sums of a row are contiguous: 16-byte reads
+            const f4 a4 = *reinterpret_cast<const f4*>(sStat + ((0 * MAXT + tt) * 16 + m) * NW + w4);
+            const f4 b4 = *reinterpret_cast<const f4*>(sStat + ((1 * MAXT + tt) * 16 + m) * NW + w4);
+            qk = (((qk + a4[0]) + a4[1]) + a4[2]) + a4[3];
+            qv = (((qv + b4[0]) + b4[1]) + b4[2]) + b4[3];
           }
           const float vk = qk * (1.f / 128.f) + 1e-5f, vv = qv * (1.f / 128.f) + 1e-5f;
-          rsK[tt] = 1.0f / sqrtf(vk); sgK[tt] = vk * rsK[tt];
+          rsK[tt] = 1.0f / sqrtf(vk); sgK[tt] = vk * rsK[tt];      // (the hardware rsq, 1 ulp, moves a bias gradient by 2e-5: kept exact)
           rsV[tt] = 1.0f / sqrtf(vv); sgV[tt] = vv * rsV[tt];
           f4 yk = {0.f, 0.f, 0.f, 0.f}, yv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
         if constexpr (RS == 32) mx = fmaxf(mx, __shfl_xor(mx, 16));
         float e[NQ], l = 0.f;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { e[q] = lg[q] > 0.5f * NEG_BIG ? exp2f(lg[q] - mx) : 0.f; l += e[q]; }
+        for (int q = 0; q < NQ; ++q) { e[q] = lg[q] > 0.5f * NEG_BIG ? __builtin_amdgcn_exp2f(lg[q] - mx) : 0.f; l += e[q]; }
         l = row16_total(l);
         if constexpr (RS == 32) l += __shfl_xor(l, 16);
         const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -528,9 +530,11 @@ __global__ __launch_bounds__(64 * NW, PG_TB2_MINWAVES) void triplet_bwd2_kernel(
           {
             float tk = 0.f, tv = 0.f;
 #pragma unroll
-            for (int w2 = 0; w2 < NW; ++w2) {
-              tk += sS1[((buf * 2 + 0) * 16 + m) * NW + w2];
-              tv += sS1[((buf * 2 + 1) * 16 + m) * NW + w2];
+            for (int w4 = 0; w4 < NW; w4 += 4) {
+              const f4 a4 = *reinterpret_cast<const f4*>(sS1 + ((buf * 2 + 0) * 16 + m) * NW + w4);
+              const f4 b4 = *reinterpret_cast<const f4*>(sS1 + ((buf * 2 + 1) * 16 + m) * NW + w4);
+              tk = (((tk + a4[0]) + a4[1]) + a4[2]) + a4[3];
+              tv = (((tv + b4[0]) + b4[1]) + b4[2]) + b4[3];
             }
             const float gvk = 0.5f * rsK[tt] * tk * (1.f / 64.f), gvv = 0.5f * rsV[tt] * tv * (1.f / 64.f);
 #pragma unroll
