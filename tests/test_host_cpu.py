@@ -65,6 +65,14 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(lib.pg_last_error(), bytes)
 
 
+def test_driver_build_entry_point_runs():
+    """__graft_entry__.build() is what the driver calls on a GPU-less host every round: make (a no-op on an up-to-date tree), load the
+    library, check its ABI version against the binding, import the package.  (It once carried a literal version number and would have
+    failed the round's build check after an ABI bump.)"""
+    import __graft_entry__ as entry
+    entry.build()
+
+
 def test_streaming_gemm_isa_keeps_its_counted_wait_valid(tmp_path):
     """csrc/gemm_stream.hip retires its LDS-DMA with `s_waitcnt vmcnt(32)`: correct only while the 32 result stores of a tile are
     the ONLY younger vector-memory operations of a wave (fewer would let the wait pass before the DMA lands).  Cross-compile
