@@ -9,11 +9,19 @@
 //   * everything that is local to a channel stays in that wave's registers for the whole source atom: the rows P[k -> j] (read ONCE per
 //     atom instead of once per segment), their gradient d P (accumulated over the atom's n - 1 segments in registers, stored once, no
 //     merge), d Cdst, d b', d Wf, d U;
-//   * the two products that contract over the channels (logits / value projection y = z^T . U, d feat = d hidden^T . Wf) and the two
-//     LayerNorm row sums are partial sums per wave, added up through LDS: three workgroup barriers per segment + one per tile;
-//   * nothing of the forward is read back: the softmax weights are recomputed from the logits of ALL tiles of the segment (they sit in
-//     registers), so D[h] = sum_r alpha d alpha needs neither S nor alpha from HBM, and there is no value pass / key pass scratch.
+//   * what contracts over the channels crosses the waves as partial sums through LDS: the two LayerNorm row sums, the logits / value
+//     projection y = z^T . U of ALL tiles of the segment at once, the row sum of the LayerNorm adjoint and d feat = d hidden^T . Wf:
+//     four workgroup barriers per segment + one per tile;
+//   * nothing of the forward is read back: the softmax weights are recomputed from the logits of all tiles of the segment -- wave w takes
+//     16 / waves heads and leaves rstd d logit and rstd alpha in LDS in a layout both MFMA operand forms read -- so D[h] = sum_r alpha d alpha
+//     needs neither S nor alpha from HBM, and there is no value pass / key pass scratch;
+//   * the LayerNorm adjoint needs no row sum of d logit x y: with z = ReLU(pre), d rstd = (1 / rstd) sum_c z d pre, so
+//     d var = (rstd / 2) sum_c d pre (b' - rstd z) is one partial sum per wave;
+//   * the angular features of the next segment and the geometry adjoint of the previous one run on different waves between the same two
+//     barriers; the segment's operands (U, dS, the Cdst row) land in a double LDS stage by LDS-DMA one segment ahead.
 // Per-wave transposes shrink to the wave's own CW x 16 block.  Lane l = (g = l >> 4, m = l & 15); 16x16x4 maps as in seg_attn.hip.
+// Instances: 8 waves x 16 channels for ligands of up to 32 atoms (two waves per SIMD, 249 registers, no spills), 4 waves x 32 channels for
+// up to 64 atoms (up to 512 registers).  Measurements, and what faults on the way: profiles/r05_triplet_adjoint_channel_split.txt.
 #include "seg_common.h"
 
 namespace pg {
@@ -107,6 +115,7 @@ __device__ __forceinline__ void tb2_dma(unsigned lds_dst, unsigned voff, tb2_i4 
 
 }  // namespace
 
+// (-DPG_TB2_MINWAVES=2 / 3: the occupancy experiments of profiles/r05_triplet_adjoint_channel_split.txt; the product build leaves it at 1)
 #ifndef PG_TB2_MINWAVES
 #define PG_TB2_MINWAVES 1
 #endif
