@@ -320,6 +320,17 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
         lg[r] = rv[r].valid ? lg[r] : NEG_BIG;
         tmax = fmaxf(tmax, lg[r]);
       }
+      if constexpr (T::PH) {
+        // training: the rows' logits are left in p.alpha and turned into softmax weights once the segment's maximum and denominator
+        // are known (below); every lane re-reads exactly what it wrote (rows 4g + r, head m)
+        if (p.alpha) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tile * 16 + 4 * g + r;
+            if (row < p.alpha_rows) p.alpha[((size_t)s.seg * p.alpha_rows + row) * 16 + m] = lg[r];
+          }
+        }
+      }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run, tmax);
@@ -410,6 +421,20 @@ __global__ __launch_bounds__(256, 1) void seg_attn_kernel(PgTopo t, PgSegAttn p)
     sw_tot += __shfl_xor(sw_tot, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
 
+    if constexpr (T::PH) {
+      if (p.alpha) {
+        for (int tile = 0; tile < n_tiles; ++tile)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tile * 16 + 4 * g + r;
+            if (row < p.alpha_rows) {
+              float* ap = p.alpha + ((size_t)s.seg * p.alpha_rows + row) * 16 + m;
+              const float lgv = *ap;
+              *ap = lgv > 0.5f * NEG_BIG ? __builtin_amdgcn_exp2f(lgv - m_run) * inv : 0.f;
+            }
+          }
+      }
+    }
     if constexpr (T::POS) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {

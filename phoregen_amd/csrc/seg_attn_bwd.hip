@@ -1127,7 +1127,10 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
       if (t->max_nlig <= 64) return op ? launch_bwd<PG_SEG_TRIPLET, 4, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
       return op ? launch_bwd<PG_SEG_TRIPLET, 2, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 2>(t, p, gr, st);
     }
-    case PG_SEG_PHORE: return launch_bwd<PG_SEG_PHORE, 4>(t, p, gr, st);
+    case PG_SEG_PHORE:
+      // (the pharmacophore encoder, training: with the forward's softmax weights one pass; as a value pass + a key pass it measured
+      //  slower -- 136.6 against 136.2 ms per training step -- and is not built in)
+      return (gr->alpha && gr->S && gr->swn) ? launch_bwd<PG_SEG_PHORE, 4, true>(t, p, gr, st) : launch_bwd<PG_SEG_PHORE, 4>(t, p, gr, st);
   }
   set_error("pg_seg_attn_bwd: unknown mode %d", p->mode);
   return PG_ERR_ARG;

@@ -55,6 +55,8 @@ DEFAULTS = dict(
                           # a workgroup (csrc/triplet_bwd2.hip; ligands of up to 64 atoms): 1 = 4 waves, 2 = 8 waves for ligands of up to
                           # 32 atoms + the 4-wave form for the larger ones
     tri_bwd_grid=256,     # ... persistent workgroups of the channel-split form
+    ph_onepass=True,      # training: the pharmacophore encoder's forward leaves its softmax weights for a one-pass adjoint instead of the generic
+                          # form that recomputes both MLP paths twice
 )
 
 _tri = lambda v: {'0': 'never', '1': 'auto', '2': 'always'}[v]
@@ -65,7 +67,7 @@ _ENV = {
     'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_C_PROGRAM': ('c_program', _flag), 'PG_STEP_AHEAD': ('step_ahead', _flag), 'PG_CHAIN_Q_FROM': ('chain_q_from', int), 'PG_AHEAD_BELOW': ('ahead_below', int), 'PG_TRI_SPLIT': ('tri_split', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
     'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
     'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int), 'PG_BWD_SPLIT': ('bwd_split', lambda v: {'0': 'none', '1': 'knn', '2': 'all'}[v]), 'PG_BWD_ATOM_SORT': ('bwd_atom_sort', _flag),
-    'PG_TRI_BWD_FORM': ('tri_bwd_form', int), 'PG_TRI_BWD_GRID': ('tri_bwd_grid', int),
+    'PG_TRI_BWD_FORM': ('tri_bwd_form', int), 'PG_TRI_BWD_GRID': ('tri_bwd_grid', int), 'PG_PH_ONEPASS': ('ph_onepass', _flag),
 }
 _overrides = {}
 

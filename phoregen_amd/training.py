@@ -361,10 +361,12 @@ class SegCoreFn(torch.autograd.Function):
         tf = cfg.get('tri_fwd')
         alpha = None
         onepass = options.get('tri_onepass')
-        if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_BOND_NODE, hip.SEG_KNN_POS, hip.SEG_BOND_POS) and onepass and \
+        ph_onepass = cfg['mode'] == hip.SEG_PHORE and onepass and options.get('ph_onepass') and 0 < cfg['max_rows'] <= 256
+        if ph_onepass or cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_BOND_NODE, hip.SEG_KNN_POS, hip.SEG_BOND_POS) and onepass and \
                 (cfg['k'] <= 32 if cfg['mode'] in (hip.SEG_KNN_NODE, hip.SEG_KNN_POS) else cfg['max_rows'] <= 80):
             # the two-pass node kernels run (csrc/node_attn.hip): they hand alpha x gate to a one-pass adjoint (node update), or
-            # the logits and value scalars of every row to the adjoint's softmax step (position update: 32 floats per row)
+            # the logits and value scalars of every row to the adjoint's softmax step (position update: 32 floats per row); the
+            # pharmacophore encoder's generic kernel leaves its softmax weights the same way
             arows = (cfg['max_rows'] + 15) // 16 * 16
             alpha = torch.empty(n_rows * arows * (32 if pos else 16), dtype=torch.float32, device=dev)
             s.alpha, s.alpha_rows = alpha.data_ptr(), arows
@@ -469,6 +471,7 @@ class SegCoreFn(torch.autograd.Function):
                 S_, sw_ = ctx.saved_tensors[1:3]
                 g.S, g.swn = S_.data_ptr(), sw_.data_ptr()
                 keep += [S_, sw_]
+            # (the pharmacophore encoder's adjoint stays one pass: as a value pass + a key pass it measured 0.4 ms per step slower)
             split_modes = {'knn': (hip.SEG_KNN_NODE, hip.SEG_KNN_POS), 'all': (hip.SEG_TRIPLET, hip.SEG_KNN_NODE, hip.SEG_KNN_POS)}
             # (the library takes the triplet's two-pass form for ligands of up to 64 atoms only: no scratch for a launch that will not use it)
             if cfg['mode'] in split_modes.get(options.get('bwd_split'), ()) and (cfg['mode'] != hip.SEG_TRIPLET or cfg['max_rows'] <= 64):

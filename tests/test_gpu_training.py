@@ -297,13 +297,14 @@ def test_two_pass_adjoints_equal_the_one_wave_form(model):
 @pytest.mark.parametrize('switch', [dict(dgrad_mm=False), dict(rows_sum=False), dict(tri_onepass=False), dict(wide_gemm=False),
                                     dict(bwd_atom_sort=False), dict(bwd_split='knn'), dict(bwd_grid=64), dict(tri_bwd_form=0),
                                     dict(tri_bwd_form=0, bwd_atom_sort=False), dict(tri_bwd_form=0, tri_onepass=False),
-                                    dict(tri_bwd_form=1), dict(tri_bwd_form=2, tri_bwd_grid=3)])
+                                    dict(tri_bwd_form=1), dict(tri_bwd_form=2, tri_bwd_grid=3), dict(ph_onepass=False)])
 def test_every_training_switch_gives_the_default_paths_gradients(model, switch):
     """options.py keeps a handful of reachable variants of the training path (the in-tree tiled GEMM instead of the library GEMM for the
     input gradients, atomic index_add instead of pg_bond_rows_sum, the generic two-pass triplet / node adjoints instead of the one-pass
     forms fed by the forward's softmax weights, one GEMM per first-layer block instead of the wide one, the triplet adjoint without
     the cost-sorted atom order, the knn-only split, a smaller persistent grid, the triplet adjoint with one wave per row tile instead of
-    the channel-split kernel, its 4-wave form, three persistent workgroups that each walk many source atoms).  Each of them must give the default path's loss and
+    the channel-split kernel, its 4-wave form, three persistent workgroups that each walk many source atoms, the pharmacophore encoder's adjoint in the generic
+    form instead of the one fed by the forward's softmax weights).  Each of them must give the default path's loss and
     gradients on a ragged batch (same sums, other association / atomic order: <= 2e-5 relative per parameter; the loss to 1e-6)."""
     from oracle.make_inputs import synthetic_train_batch
     from phoregen_amd import options
