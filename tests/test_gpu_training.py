@@ -228,11 +228,15 @@ def test_training_step_reduces_the_loss(model):
     assert losses[-1] < losses[0], losses
 
 
-def test_gradients_on_small_and_ragged_graphs(model):
+@pytest.mark.parametrize('tri_grid', [256, 2])
+def test_gradients_on_small_and_ragged_graphs(model, tri_grid):
     """2- and 3-atom ligands (bond / triplet segments with zero or one valid row), a 33-atom ligand (3 row tiles) and
-    pharmacophores of 4..41 nodes (knn degree < 32) against autograd through the oracle on generated draws."""
+    pharmacophores of 4..41 nodes (knn degree < 32) against autograd through the oracle on generated draws.  tri_grid = 2: the
+    channel-split triplet adjoint on two persistent workgroups, each walking ~27 source atoms of different ligands one after the
+    other (registers, LDS stages and the pending geometry step carried from atom to atom)."""
     from oracle import phoregen_oracle as po
     from oracle.make_inputs import synthetic_train_batch
+    from phoregen_amd import options
     from phoregen_amd.data import TrainBatch
     b = synthetic_train_batch(77, [2, 33, 3, 17], [5, 41, 4, 23])
     gen = torch.Generator().manual_seed(5)
@@ -249,8 +253,9 @@ def test_gradients_on_small_and_ragged_graphs(model):
     keys = ('ligand_x', 'ligand_pos', 'ligand_batch', 'ligand_ptr', 'f_edge_index', 'f_edge_attr', 'f_edge_batch',
             'phore_x', 'phore_pos', 'phore_norm', 'phore_batch')
     model.zero_grad()
-    loss, info = model.compute_loss(TrainBatch(*[b[k] for k in keys]), draws=draws)
-    loss.backward()
+    with options.override(tri_bwd_grid=tri_grid):
+        loss, info = model.compute_loss(TrainBatch(*[b[k] for k in keys]), draws=draws)
+        loss.backward()
     assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
     assert info['node_acc'] == info_ref['node_acc'] and info['edge_acc'] == info_ref['edge_acc']
     params = dict(model.named_parameters())
