@@ -263,7 +263,20 @@ def g5_sample(model, name, seed, n_atoms, n_steps, t_total, guidance=None):
 FULL_CK = 50          # g5_sample_full1000*: the carried state is stored after every FULL_CK-th step
 
 
-def g5_sample_full1000(model, name, seed, n_atoms, guidance=None, ck_every=FULL_CK, sparse_edge_gaps=False):
+def synthetic_phore_data(seed, p, frac_ex=0.94, spread=6.0):
+    """A `HeteroData` of the reference's shape (datasets/get_phore_data.py:55-105) holding a synthetic pharmacophore of the headline
+    statistics (p ~ 107 nodes, 94 % exclusion spheres, positions 6 randn, centred): the parsed real file's
+    object with its `phore` store and `center` replaced, so every other field the reference touches is the reference's own."""
+    data = real_phore_data(seed)
+    x, pos, norm = synthetic_phore(torch.Generator().manual_seed(seed), p, frac_ex=frac_ex, spread=spread)
+    st = data['phore']
+    st.x, st.pos, st.norm = x, pos, norm
+    st.center_of_mass = torch.zeros(3)
+    data.center = torch.zeros(3)
+    return data
+
+
+def g5_sample_full1000(model, name, seed, n_atoms, guidance=None, ck_every=FULL_CK, sparse_edge_gaps=False, data=None):
     """The reference's own `sample()` for ALL 1000 steps (diffusion.py:391-525), CPU generator seeded right in front of the
     sampler's first draw (`seed_all(seed + 1)` inside the forced atom-count call: a test re-creates the draws by seeding the same
     generator and drawing in the reference's order, SURVEY.md Appendix B -- 3.3 MB of recorded noise stay out of the fixture).
@@ -272,7 +285,7 @@ def g5_sample_full1000(model, name, seed, n_atoms, guidance=None, ck_every=FULL_
     50th step the carried state the trajectory does not hold (log-posteriors, un-centred positions); float64 sums of every draw
     (a host whose generator stream differs is told apart from a parity failure); per-step max |logit| (scale of the bounds)."""
     import models.diffusion as rd
-    data = real_phore_data(seed)
+    data = real_phore_data(seed) if data is None else data
     T = model.num_timesteps
     rec = dict(gap=[[], []], scale=[[], []], usum=[[], []], post=[[], []], pos_in=[], eps_sum=[])
     orig_lsc, orig_fwd, orig_randn_like = rd.log_sample_categorical, model.forward, torch.randn_like
@@ -499,7 +512,22 @@ def full1000_fixtures(model):
     g5_sample_full1000(model, 'g5_sample_full1000_n34', seed=2042, n_atoms=[34, 21], ck_every=None, sparse_edge_gaps=True)
 
 
+def full1000_headline(model):
+    """The headline shape (BASELINE.json configs[2]; /root/reference/models/diffusion.py:432-517): 4 ligands of 38 / 40 / 43 / 52 atoms
+    (3 / 3 / 3 / 4 row tiles of the triplet kernel; 7 424 bond rows, 316 542 triplets) on ONE synthetic pharmacophore of 107 nodes,
+    unguided, all 1000 steps of the reference's own `sample()` (~2.5 h of CPU at 4 threads)."""
+    g5_sample_full1000(model, 'g5_sample_full1000_headline', seed=2043, n_atoms=[38, 40, 43, 52], ck_every=None, sparse_edge_gaps=True,
+                       data=synthetic_phore_data(2043, 107))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'full1000_headline':
+        model, cfg = build_model(seed=0)
+        if len(sys.argv) > 2:                                  # plumbing check: `full1000_headline 3` runs 3 steps only, writes nothing kept
+            model.num_timesteps = int(sys.argv[2])
+            OUT = '/tmp'
+        full1000_headline(model)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'len':        # only the bond_len_loss fixture (added in round 3)
         model, cfg = build_model(seed=0)
         g6_compute_loss(model, 'g6_loss_len', seed=67, n_atoms=[7, 10, 5], n_phore=[9, 14, 6], bond_len_loss=True)
@@ -536,3 +564,4 @@ if __name__ == '__main__':
     for prof in ('gamma_signed', 'trained_like'):
         profile_fixtures(prof)
     full1000_fixtures(model)
+    full1000_headline(model)

@@ -470,9 +470,11 @@ class Oracle:
         return loss, info
 
     # ---- sampler (diffusion.py:391-525) with an explicit noise source ----
-    def sample(self, h_phore, pos_phore, phore_norm, center, num_atoms, rng, t_total=None, guidance=None, n_steps=None):
+    def sample(self, h_phore, pos_phore, phore_norm, center, num_atoms, rng, t_total=None, guidance=None, n_steps=None,
+               observer=None, keep_steps=True):
         """`rng` provides .randn(shape), .rand64(shape), .rand(shape) in the reference's draw order
-        (SURVEY.md Appendix B 3-5).  Returns the reference's result dict plus per-step records."""
+        (SURVEY.md Appendix B 3-5).  Returns the reference's result dict plus per-step records.
+        `observer(i, kind, log_posterior, uniform, logits)` sees every categorical draw (tools/match_rate.py: top-2 margins)."""
         T = self.T if t_total is None else t_total
         B = len(num_atoms)
         p = h_phore.size(0)
@@ -494,11 +496,17 @@ class Oracle:
         for step in list(range(T)[::-1])[:n_steps]:          # n_steps: only the first steps (tools/match_rate.py)
             t = torch.full((B,), step, dtype=torch.long)
             v, x0, bond, _ = self.forward(h_node, pos, batch_node, h_edge, edge_index, batch_edge, t, hp, pp, pn, bp)
-            steps.append((h_node, pos, h_edge, v, x0, bond))
+            if keep_steps:
+                steps.append((h_node, pos, h_edge, v, x0, bond))
             log_node = q_v_posterior(self.tab_node, F.log_softmax(v, -1), log_node, t, batch_node)
-            h_node_prev = F.one_hot(gumbel_argmax(log_node, rng.rand((N, 12))), 12).float()
+            un = rng.rand((N, 12))
+            h_node_prev = F.one_hot(gumbel_argmax(log_node, un), 12).float()
             log_edge = q_v_posterior(self.tab_edge, F.log_softmax(bond, -1), log_edge, t, batch_edge)
-            h_edge_prev = F.one_hot(gumbel_argmax(log_edge, rng.rand((E, 6))), 6).float()
+            ue = rng.rand((E, 6))
+            h_edge_prev = F.one_hot(gumbel_argmax(log_edge, ue), 6).float()
+            if observer is not None:
+                observer(len(traj[0]) - 1, 'node', log_node, un, v)
+                observer(len(traj[0]) - 1, 'edge', log_edge, ue, bond)
             grad = 0.
             if guidance is not None:
                 grad = guidance_grad(guidance, pos, batch_node, h_edge_prev, edge_index, batch_edge, B,

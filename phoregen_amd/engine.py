@@ -695,6 +695,11 @@ class Engine:
                 self._gemm(prog, hn, 128, L.W_node2[512:], w.Y2[:, 512:], p.n_lig, 768, bias=L.b_node2[512:], rows=p.lig2ctx)
             else:
                 self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
+            if step_ahead and self.head_early and last and v2:
+                # lane 1's last read of h' (= h[0] in the last layer): `prog_ahead` embeds the NEXT step's features into h[0] on lane 2, which in
+                # this schedule is released by `hn_done` alone -- it must not pass these products (advisor, round 5: a write-after-read hazard
+                # that only timing had kept closed)
+                y2_done = self._record(prog, 1)
             if v2:
                 # the bond position update's query right behind Y2 on the node chain's lane (Y2 is out well before the triplet kernel ends):
                 # the one event lane 0 waits for below then covers it, instead of a second cross-lane hop in front of the attention
@@ -722,7 +727,9 @@ class Engine:
                 self._wait(prog, 2, hn_done)
                 self._lane = 2
                 heads[1](hn)
-                if not v2:
+                if v2:
+                    self._wait(prog, 2, y2_done)       # Y2's reads of h' (lane 1) before anything later on this lane overwrites h[0]
+                else:
                     self._fork(prog, (2,))             # Y2: lane 0 has waited for lane 1 above
             else:
                 self._fork(prog, (2, 3) if (ahead and li + 1 < n_layers) else (qlane,))
