@@ -111,41 +111,89 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
     return [torch.tensor(sorted(p), dtype=torch.long) for p in parts]
 
 
-def gather_variable(t, group=None):
-    """all_gather of a [n_r, ...] tensor whose first dimension differs per rank: counts first, then one padded
-    all_gather (two collectives per tensor, ~50 KB per graph)."""
-    world = dist.get_world_size(group)
-    dev = t.device
-    if dist.get_backend(group) == 'gloo' and t.is_cuda:      # gloo moves host memory; RCCL works on device memory
-        t = t.cpu()
-    n = torch.tensor([t.size(0)], device=t.device, dtype=torch.long)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c) for c in counts]
-    nmax = max(counts) if counts else 0
-    pad = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[:t.size(0)] = t
-    out = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return [o[:c].to(dev) for o, c in zip(out, counts)]
+def _comm_device(t, group):
+    """gloo moves host memory; RCCL (backend `nccl` on ROCm) works on device memory."""
+    return torch.device('cpu') if dist.get_backend(group) == 'gloo' else t.device
 
 
-def gather_predictions(pred, num_atoms_local, graph_ids_local, group=None):
-    """Re-assemble `pred` = [logits_node [N,12], pos [N,3], logits_edge [E,6]] of all ranks in global graph order.
-    Returns (pred_global, num_atoms_global) on every rank."""
-    ids = gather_variable(graph_ids_local.to(pred[0].device), group)
-    nat = gather_variable(num_atoms_local.to(pred[0].device), group)
-    parts = [gather_variable(p, group) for p in pred]
-    per_graph = {}
-    for r, (gid, na) in enumerate(zip(ids, nat)):
-        n_off = e_off = 0
-        for g, n in zip(gid.tolist(), na.tolist()):
-            e = n * (n - 1)
-            per_graph[g] = (parts[0][r][n_off:n_off + n], parts[1][r][n_off:n_off + n], parts[2][r][e_off:e_off + e], n)
-            n_off, e_off = n_off + n, e_off + e
-    order = sorted(per_graph)
-    pred_global = [torch.cat([per_graph[g][i] for g in order]) for i in range(3)]
-    return pred_global, torch.tensor([per_graph[g][3] for g in order])
+def gather_predictions(pred, num_atoms_local, graph_ids_local, group=None, dst=0):
+    """The one collective step of the sampling path (sample_all.py:104-116 hands `pred` of every graph to the host-side decode): re-assemble
+    `pred` = [logits_node [N,12], pos [N,3], logits_edge [E,6]] of all ranks in global (ascending graph id) order.
+
+    Three collectives whatever the job size:
+      1. all_gather of the per-rank graph count (one int64),
+      2. all_gather of the per-rank table [graph id | atoms] padded to the largest count (16 B per graph: 1.6 MB for BASELINE config 4),
+      3. ONE flat fp32 buffer per rank -- its node logits, coordinates and bond logits back to back (15 N_r + 6 E_r floats), padded to the
+         longest rank -- gathered to rank `dst` only (`dist.gather`; the north star asks for the final gather on rank 0), or to every rank
+         with dst=None (`all_gather`).
+    Re-assembly is vectorised: per rank and kind one `index_copy_` whose row index comes from two cumulative sums -- O(ranks) Python work,
+    nothing per graph.  Peak memory on the destination: the gathered buffers (world x longest rank) + the result + one kind's row index.
+    Returns (pred_global, num_atoms_global); pred_global is None on the ranks that are not the destination."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out_dev = pred[0].device
+    cdev = _comm_device(pred[0], group)
+    gids = graph_ids_local.to(cdev, torch.long)
+    nat = num_atoms_local.to(cdev, torch.long)
+    assert gids.numel() == nat.numel() and pred[0].size(0) == int(nat.sum()) and pred[2].size(0) == int((nat * (nat - 1)).sum())
+    # 1. graph counts
+    cnt = torch.tensor([gids.numel()], device=cdev, dtype=torch.long)
+    counts = torch.empty(world, device=cdev, dtype=torch.long)
+    dist.all_gather_into_tensor(counts, cnt, group=group)
+    counts = counts.tolist()
+    gmax = max(counts)
+    # 2. the [graph id | atoms] tables
+    meta = torch.zeros(2, gmax, device=cdev, dtype=torch.long)
+    meta[0, :gids.numel()], meta[1, :gids.numel()] = gids, nat
+    metas = torch.empty(world * 2 * gmax, device=cdev, dtype=torch.long)        # (flat: the gloo backend wants the outputs concatenated along dim 0)
+    dist.all_gather_into_tensor(metas, meta.view(-1), group=group)
+    metas = metas.view(world, 2, gmax).cpu()
+    ids_r = [metas[r, 0, :c] for r, c in enumerate(counts)]
+    nat_r = [metas[r, 1, :c] for r, c in enumerate(counts)]
+    n_r = [int(x.sum()) for x in nat_r]
+    e_r = [int((x * (x - 1)).sum()) for x in nat_r]
+    lmax = max(15 * n + 6 * e for n, e in zip(n_r, e_r))
+    # global order = ascending graph id; where every graph's rows start in it
+    ids_all, nat_all = torch.cat(ids_r), torch.cat(nat_r)
+    order = torch.argsort(ids_all, stable=True)
+    nat_sorted = nat_all[order]
+    # 3. the payload
+    flat = torch.zeros(lmax, device=cdev, dtype=torch.float32)
+    o = 0
+    for t in pred:
+        flat[o:o + t.numel()] = t.reshape(-1).to(cdev, torch.float32)
+        o += t.numel()
+    to_all = dst is None
+    if to_all:
+        bufs = torch.empty(world * lmax, device=cdev, dtype=torch.float32)
+        dist.all_gather_into_tensor(bufs, flat, group=group)
+        bufs = bufs.view(world, lmax)
+    else:
+        bufs = [torch.empty(lmax, device=cdev, dtype=torch.float32) for _ in range(world)] if rank == dst else None
+        dist.gather(flat, bufs, dst=dst, group=group)
+    del flat
+    if not (to_all or rank == dst):
+        return None, nat_sorted
+    out = []
+    for kind, (width, rows_of) in enumerate(((12, lambda n: n), (3, lambda n: n), (6, lambda n: n * (n - 1)))):
+        rows_sorted = rows_of(nat_sorted)
+        start_sorted = torch.zeros(order.numel(), dtype=torch.long)           # first row of the k-th graph of the global order
+        start_sorted[1:] = rows_sorted.cumsum(0)[:-1]
+        start_of = torch.empty_like(start_sorted)                               # ... indexed by position in the rank-major list
+        start_of[order] = start_sorted
+        res = torch.empty(int(rows_sorted.sum()), width, device=cdev, dtype=torch.float32)
+        g0 = 0
+        for r in range(world):
+            rows = rows_of(nat_r[r])
+            n_rows = int(rows.sum())
+            if n_rows:
+                src0 = torch.zeros(counts[r], dtype=torch.long)                # first row of each of the rank's graphs in its own block
+                src0[1:] = rows.cumsum(0)[:-1]
+                idx = torch.repeat_interleave(start_of[g0:g0 + counts[r]] - src0, rows) + torch.arange(n_rows)
+                off = (0, 12 * n_r[r], 15 * n_r[r])[kind]
+                res.index_copy_(0, idx.to(cdev), bufs[r][off:off + n_rows * width].view(n_rows, width))
+            g0 += counts[r]
+        out.append(res.to(out_dev))
+    return out, nat_sorted
 
 
 class SamplingJob:

@@ -23,7 +23,7 @@ def _job(n_phores=6, samples=4, seed=5):
 
 
 def _reassemble(parts, job):
-    """What gather_predictions does after the all_gather: per-rank results back into global graph order."""
+    """What gather_predictions does with the gathered buffers: per-rank results back into global graph order."""
     per = {}
     for gids, pred in parts:
         n_off = e_off = 0

@@ -33,12 +33,91 @@ def _worker(rank, world, port, num_atoms, q):
         parts = partition_graphs(num_atoms, world)
         mine = parts[rank]
         pred = _fake_pred(mine, num_atoms[mine])
-        out, nat = gather_predictions(pred, num_atoms[mine], mine)
         ref = _fake_pred(torch.arange(num_atoms.numel()), num_atoms)
-        ok = all(torch.equal(a, b) for a, b in zip(out, ref)) and torch.equal(nat, num_atoms)
+        same = lambda out: all(torch.equal(a, b) for a, b in zip(out, ref))
+        out, nat = gather_predictions(pred, num_atoms[mine], mine)                 # the path's form: to rank 0 only
+        ok = torch.equal(nat, num_atoms) and (same(out) if rank == 0 else out is None)
+        out, nat = gather_predictions(pred, num_atoms[mine], mine, dst=None)       # on request: every rank
+        ok = ok and same(out) and torch.equal(nat, num_atoms)
+        out, nat = gather_predictions(pred, num_atoms[mine], mine, dst=world - 1)
+        ok = ok and (same(out) if rank == world - 1 else out is None)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
+
+
+def _pattern_pred(graph_ids, num_atoms):
+    """Per-graph payload that is cheap to make and to check at job scale: column 0 = graph id, column 1 = row inside the graph."""
+    out = []
+    for width, rows in ((12, num_atoms), (3, num_atoms), (6, num_atoms * (num_atoms - 1))):
+        t = torch.zeros(int(rows.sum()), width)
+        start = rows.cumsum(0) - rows
+        t[:, 0] = torch.repeat_interleave(graph_ids.float(), rows)
+        t[:, 1] = (torch.arange(t.size(0)) - torch.repeat_interleave(start, rows)).float()
+        out.append(t)
+    return out
+
+
+def _job_worker(rank, world, port, n_graphs, q):
+    """BASELINE config 4's gather (sample_all.py:104-116 at job scale): `n_graphs` graphs' worth of rows, partitioned as
+    `run_sampling_job` does, payload without compute."""
+    import resource
+    import time
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(4321)
+        num_atoms = (40 + 6 * torch.randn(n_graphs, generator=g)).round().clamp(20, 60).long()      # bench.config4_job
+        t0 = time.perf_counter()
+        mine = partition_graphs(num_atoms, world)[rank]
+        t_part = time.perf_counter() - t0
+        pred = _pattern_pred(mine, num_atoms[mine])
+        calls = {'n': 0}
+        real = {n: getattr(dist, n) for n in ('all_gather_into_tensor', 'all_gather', 'gather', 'all_reduce', 'broadcast')}
+        for n, f in real.items():
+            setattr(dist, n, (lambda f_: lambda *a, **k: (calls.__setitem__('n', calls['n'] + 1), f_(*a, **k))[1])(f))
+        dist.barrier()
+        t0 = time.perf_counter()
+        out, nat = gather_predictions(pred, num_atoms[mine], mine)
+        t_gather = time.perf_counter() - t0
+        for n, f in real.items():
+            setattr(dist, n, f)
+        ok = torch.equal(nat, num_atoms)
+        if rank == 0:
+            exp = _pattern_pred(torch.arange(n_graphs), num_atoms)
+            ok = ok and all(torch.equal(a, b) for a, b in zip(out, exp))
+            payload = sum(t.numel() for t in out) * 4
+        else:
+            ok, payload = ok and out is None, 0
+        q.put((rank, bool(ok), calls['n'], t_part, t_gather, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024, payload))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_job_gather(n_graphs, world=8):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n_graphs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_gather_world_size_8_gloo_job_scale():
+    """World size 8 over gloo, 12 800 graphs (1 / 8 of BASELINE config 4; the full 102 400 graphs -- 4.1 GB of rows, ~70 s and ~14 GB on
+    rank 0 of this 8-core host -- are run by tools/gather_config4_gloo8.py, record in profiles/r06_gather_config4_gloo8.txt): global order,
+    at most 3 collectives, and the destination's peak host memory bounded by a small multiple of the payload."""
+    res = run_job_gather(12800)
+    assert [r[0] for r in res] == list(range(8)) and all(r[1] for r in res), res
+    assert all(r[2] <= 3 for r in res), [r[2] for r in res]
+    payload = res[0][6]
+    assert payload > 400e6                                         # (12 800 graphs ~ 0.5 GB of fp32 rows)
+    assert res[0][5] <= 4.0 * payload + 1.5e9, (res[0][5], payload)  # gathered buffers + result + one row index (+ the interpreter and torch)
+    assert all(r[5] <= 1.5 * payload / 8 * 4 + 1.5e9 for r in res[1:])
 
 
 def test_partition_is_balanced_and_complete():
