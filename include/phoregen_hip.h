@@ -41,7 +41,7 @@ int pg_order_point_record(void* ev, void* stream);
 int pg_order_point_wait(void* ev, void* stream);          /* `stream` continues after the last record of `ev` */
 /* 0 (default): hipEventDisableTiming | hipEventReleaseToDevice, HIP's documented device-scope release at the record.
  * 1 (measurement only, tools/): hipEventDisableTiming | hipEventDisableSystemFence, the round-4 form whose record carries no release
- * of its own.  Applies to order points created afterwards. */
+ * of its own.  Applies to order points created afterwards.  Refused (PG_ERR_ARG) unless the process runs with PHOREGEN_DEBUG=1. */
 int pg_debug_order_point_fence_free(int on);
 
 /* ---- one denoiser forward as ONE call: a pre-built launch list walked on the host side of the library ---------------------------
@@ -67,6 +67,8 @@ typedef struct {
 } PgLaunch;
 int pg_program_create(const PgLaunch* list, int n, int n_events, void** prog);   /* validates and copies the list, creates the events */
 int pg_program_run(void* prog, void* const* streams /*[PG_PROGRAM_LANES] hipStream_t*/);
+/* (a failing entry leaves the lanes half-enqueued: the call then drains the device, marks the program POISONED and returns the entry's
+ *  error; every later run of a poisoned program is refused -- the owner destroys it and rebuilds its state) */
 int pg_program_length(void* prog);
 int pg_program_destroy(void* prog);
 

@@ -6,6 +6,7 @@
 #include <mutex>
 
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/phoregen_hip.h"
 
 namespace pg {
@@ -436,7 +437,17 @@ extern "C" int pg_abi_struct_sizes(int* out, int n) {
 // form stays reachable for measurement only (pg_debug_order_point_fence_free; tools/micro/stream_packets.py measured a record at
 // 5.1 -> 3.7 us and a cross-stream hop at 29 -> 25 us against a default event).
 static int g_order_point_fence_free = 0;
-extern "C" int pg_debug_order_point_fence_free(int on) { g_order_point_fence_free = on; return 0; }
+// (a process-global switch that weakens every order point created after it: honoured only when the process was started with
+//  PHOREGEN_DEBUG=1 in its environment -- the product path cannot reach the weaker form by accident)
+extern "C" int pg_debug_order_point_fence_free(int on) {
+  const char* dbg = getenv("PHOREGEN_DEBUG");
+  if (on && !(dbg && dbg[0] == '1')) {
+    set_error("pg_debug_order_point_fence_free: measurement switch, needs PHOREGEN_DEBUG=1 in the environment");
+    return PG_ERR_ARG;
+  }
+  g_order_point_fence_free = on;
+  return 0;
+}
 extern "C" int pg_order_point_create(void** ev) {
   hipEvent_t e = nullptr;
   const unsigned flags = hipEventDisableTiming | (g_order_point_fence_free ? hipEventDisableSystemFence : hipEventReleaseToDevice);

@@ -15,7 +15,16 @@ namespace {
 struct Program {
   std::vector<PgLaunch> list;
   std::vector<hipEvent_t> events;
+  bool poisoned = false;        // a run failed half-way: the lanes were drained, the list must not be walked again
 };
+
+// a failing entry: later records / waits of the list were skipped, so the side lanes are no longer ordered against lane 0 -- drain the
+// device (nothing half-ordered stays in flight) and refuse the program from now on
+int fail_run(Program* p, int rc) {
+  p->poisoned = true;
+  (void)hipDeviceSynchronize();
+  return rc;
+}
 
 inline float as_float(uint64_t bits) {
   const uint32_t b = (uint32_t)bits;
@@ -128,17 +137,18 @@ extern "C" int pg_program_length(void* prog) { return prog ? (int)static_cast<Pr
 extern "C" int pg_program_run(void* prog, void* const* streams) {
   Program* p = static_cast<Program*>(prog);
   if (!p || !streams) { pg::set_error("pg_program_run: bad arguments"); return PG_ERR_ARG; }
+  if (p->poisoned) { pg::set_error("pg_program_run: this program failed half-way in an earlier run (poisoned): destroy and rebuild it"); return PG_ERR_ARG; }
   for (const PgLaunch& L : p->list) {
     void* s = streams[L.lane];
     if (L.op == PG_OP_RECORD) {
       const hipError_t rc = hipEventRecord(p->events[L.ev], static_cast<hipStream_t>(s));
-      if (rc != hipSuccess) { pg::set_error("pg_program_run: record: %s", hipGetErrorString(rc)); return PG_ERR_HIP; }
+      if (rc != hipSuccess) { pg::set_error("pg_program_run: record: %s", hipGetErrorString(rc)); return fail_run(p, PG_ERR_HIP); }
     } else if (L.op == PG_OP_WAIT) {
       const hipError_t rc = hipStreamWaitEvent(static_cast<hipStream_t>(s), p->events[L.ev], 0);
-      if (rc != hipSuccess) { pg::set_error("pg_program_run: wait: %s", hipGetErrorString(rc)); return PG_ERR_HIP; }
+      if (rc != hipSuccess) { pg::set_error("pg_program_run: wait: %s", hipGetErrorString(rc)); return fail_run(p, PG_ERR_HIP); }
     } else {
       const int rc = run_one(L, s);
-      if (rc) return rc;
+      if (rc) return fail_run(p, rc);
     }
   }
   return PG_OK;

@@ -1100,8 +1100,14 @@ extern "C" int pg_seg_attn_bwd_waves(int mode) { return mode == PG_SEG_TRIPLET ?
 extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegAttnGrad* gr, void* stream) {
   if (!t || !p || !gr) { set_error("pg_seg_attn_bwd: null argument"); return PG_ERR_ARG; }
   if (p->n_seg == 0) return PG_OK;
-  if (!p->U || !p->Cdst_k || !p->Cdst_v || !gr->rowbuf || gr->grid < 1) {
-    set_error("pg_seg_attn_bwd: U, Cdst_k/v and the row buffer are required");
+  if (!p->U || !p->Cdst_k || !p->Cdst_v || gr->grid < 1) {
+    set_error("pg_seg_attn_bwd: U, Cdst_k/v and a grid are required");
+    return PG_ERR_ARG;
+  }
+  // the row buffer: every form but the triplet's channel-split one (its rows live in LDS) -- a launch that needs it and has none is refused
+  const bool tri_split = p->mode == PG_SEG_TRIPLET && gr->tri_form && t->max_nlig <= 64 && p->Cdst_v == p->Cdst_k + 128;
+  if (!gr->rowbuf && !tri_split) {
+    set_error("pg_seg_attn_bwd: mode %d in this form needs PgSegAttnGrad.rowbuf (grid x pg_seg_attn_bwd_waves x rows x 48 floats)", p->mode);
     return PG_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -1122,7 +1128,7 @@ extern "C" int pg_seg_attn_bwd(const PgTopo* t, const PgSegAttn* p, const PgSegA
       // the per-source-atom rows (max_nlig x 259 floats) share the LDS with the per-wave tiles: 4 waves up to 64 atoms,
       // 2 waves up to the reference's maximum of 78 (and beyond, to 96)
       const bool op = gr->alpha && gr->S && gr->swn;
-      if (gr->tri_form && t->max_nlig <= 64 && p->Cdst_v == p->Cdst_k + 128) return triplet_bwd2_launch(t, p, gr, st);   // (Cdst k | v: one 1 KB row)
+      if (tri_split) return triplet_bwd2_launch(t, p, gr, st);   // (Cdst k | v: one 1 KB row)
       if (op && gr->dlogit && gr->gfeat_v && t->max_nlig <= 64) return launch_bwd_split<PG_SEG_TRIPLET>(t, p, gr, st);
       if (t->max_nlig <= 64) return op ? launch_bwd<PG_SEG_TRIPLET, 4, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 4>(t, p, gr, st);
       return op ? launch_bwd<PG_SEG_TRIPLET, 2, true>(t, p, gr, st) : launch_bwd<PG_SEG_TRIPLET, 2>(t, p, gr, st);

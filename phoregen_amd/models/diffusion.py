@@ -567,6 +567,12 @@ class PhoreDiff(nn.Module):
             plan.g_bond_off.data_ptr(), st.graph_key.data_ptr(),
             st.log_edge[1 - cur].data_ptr(), w.in_h_edge.data_ptr(), tp(st.edge_traj), s3.cuda_stream), 'posterior(edge)')
         last = step == 0 or i + 1 >= st.n_steps
+        if pos_guidance_opt:
+            # the guidance below (lane 0, on the way to the next step's coordinates) reads the bond types just drawn: it waits for THIS point
+            # of lane 3, not for what `prog_ahead` puts behind it (bond embedding, bond-node rows and attention of the next step)
+            if getattr(st, 'bond_drawn', None) is None:
+                st.bond_drawn = torch.cuda.Event()
+            st.bond_drawn.record(s3)
         if not last:
             with torch.cuda.stream(s2):
                 w.in_t_next.fill_(step - 1)
@@ -574,7 +580,7 @@ class PhoreDiff(nn.Module):
         s = hip.stream_ptr()
         grad = None
         if pos_guidance_opt:                                         # diffusion.py:476-502 (reads the bond types just drawn on lane 3)
-            eng.join_lanes((3,))
+            torch.cuda.current_stream().wait_event(st.bond_drawn)
             grad = st.grad
             grad.zero_()
             for o in pos_guidance_opt:

@@ -453,12 +453,15 @@ class SegCoreFn(torch.autograd.Function):
         # left -- training step 179.5 ms with 1 024 workgroups, 171-173 with 512, 168 with 256 (320: 205, 8 192: 206)
         grid = max(1, min((cfg['n_seg'] + 3) // 4, options.get('bwd_grid')))          # (the forms' smallest workgroup has 4 waves)
         rows = (cfg['max_rows'] + 15) // 16 * 16
-        rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
-        g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
         if cfg['mode'] == hip.SEG_TRIPLET and options.get('tri_bwd_form') and cfg['max_rows'] <= 64:
+            # the channel-split form (csrc/triplet_bwd2.hip) keeps its rows in LDS: no row buffer (the library rejects a launch that would need one)
             g.tri_form = int(options.get('tri_bwd_form'))
             grid = max(1, min(cfg['n_seg'], options.get('tri_bwd_grid')))
-            g.grid = grid
+            g.rowbuf, g.rowbuf_rows, g.grid = None, rows, grid
+        else:
+            rowbuf = torch.empty(grid * waves * rows * 48, dtype=torch.float32, device=dev)
+            g.rowbuf, g.rowbuf_rows, g.grid = rowbuf.data_ptr(), rows, grid
+            keep.append(rowbuf)
         if cfg['mode'] == hip.SEG_TRIPLET and cfg.get('plan') is not None and options.get('bwd_atom_sort'):
             ao = cfg['plan'].bwd_atom_order(grid)          # cost-sorted source atoms, dealt out in a snake (levels the persistent workgroups)
             g.atom_order = ao.data_ptr()

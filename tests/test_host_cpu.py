@@ -628,3 +628,24 @@ def test_launch_records_carry_the_arguments_ctypes_would_pass():
     bad.lane, bad.n_arg = 0, 3
     assert lib.pg_program_create((hip.PgLaunch * 1)(bad), 1, 0, C.byref(h)) != 0 and b'takes 1 arguments' in lib.pg_last_error()
     assert set(hip.PROGRAM_OPS) <= set(hip.EXPORTS)
+
+
+def test_failed_program_run_poisons_the_program_and_debug_switch_is_gated(monkeypatch):
+    """pg_program_run: an entry that fails leaves the lanes half-enqueued -- the library drains the device, returns the entry's error and
+    refuses the program from then on (advisor, round 5).  pg_debug_order_point_fence_free weakens every order point created after it: it is
+    refused unless the process runs with PHOREGEN_DEBUG=1.  (Argument errors only: nothing here reaches a GPU.)"""
+    import ctypes as C
+    from phoregen_amd import hip
+    lib = hip.load_library()
+    bad = hip.PgLaunch()
+    bad.op, bad.lane, bad.ev, bad.n_arg = hip.PROGRAM_OPS['pg_gemm'], 0, -1, 1
+    bad.a[0] = 0                                                   # pg_gemm(NULL): refused before any launch
+    h = C.c_void_p()
+    assert lib.pg_program_create((hip.PgLaunch * 1)(bad), 1, 0, C.byref(h)) == 0
+    streams = (C.c_void_p * 4)()
+    assert lib.pg_program_run(h, streams) != 0 and b'poisoned' not in lib.pg_last_error()
+    assert lib.pg_program_run(h, streams) != 0 and b'poisoned' in lib.pg_last_error()
+    assert lib.pg_program_destroy(h) == 0
+    monkeypatch.delenv('PHOREGEN_DEBUG', raising=False)
+    assert lib.pg_debug_order_point_fence_free(1) != 0 and b'PHOREGEN_DEBUG' in lib.pg_last_error()
+    assert lib.pg_debug_order_point_fence_free(0) == 0

@@ -3,6 +3,7 @@
 (device-scope release = product, vs the round-4 fence-free form, measurement only).  Per variant and batch size: ms per step (median of 3
 blocks) and the host time to ENQUEUE a step.  GPU box: python tools/ab_runner.py [graphs ...]"""
 import json, os, sys, time
+os.environ.setdefault('PHOREGEN_DEBUG', '1')      # (the fence-free order points are a measurement switch: the library refuses it otherwise)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -20,7 +21,7 @@ W, K = 30, 30
 
 
 def measure(work, gids, fence_free=False, **opt):
-    hip.lib().pg_debug_order_point_fence_free(int(fence_free))
+    hip.check(hip.lib().pg_debug_order_point_fence_free(int(fence_free)), 'pg_debug_order_point_fence_free')
     G = int(work['num_atoms'].numel())
     with options.override(**opt):
         model._engine = None

@@ -1,6 +1,7 @@
 #!/bin/bash
 # timing-only ablations of pg_seg_attn_bwd (PG_BWD_ABLATE bit mask; results are wrong when non-zero); prints the average
 # launch time of the training kernels matching KERNELS (default: the triplet and knn-node adjoints)
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for a in ${@:-0 1 2 4 8 16 32 64 96}; do
   export PG_BWD_ABLATE=$a

@@ -1,6 +1,7 @@
 #!/bin/bash
 # timing-only ablations (PG_BWD_ABLATE bit mask, -DPG_ABLATE build; results are wrong when non-zero) of the two-pass adjoints:
 # average launch time of the value pass (<mode, 8, true, 1>) and the key pass (<mode, 8, true, 2>).  On the GPU box.
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 cd $GRAFT_REPO_ROOT/phoregen_amd/csrc && make -j8 EXTRA=-DPG_ABLATE OUT=../_lib_ablate > /dev/null 2>&1 < /dev/null || { echo build failed; exit 1; }
 cd $GRAFT_REPO_ROOT
 export PHOREGEN_DEBUG=1 PG_BWD_SPLIT=2 PHOREGEN_HIP_LIB=phoregen_amd/_lib_ablate/libphoregen_hip.so

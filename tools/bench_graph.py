@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 from oracle.make_inputs import synthetic_phore
 from phoregen_amd.config import default_model_config
 from phoregen_amd.models.diffusion import PhoreDiff

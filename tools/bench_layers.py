@@ -1,7 +1,8 @@
 """Where a small-batch step spends its time, without a profiler attached: the sampler step with the denoiser cut to its first k
 layers (k = 0..6).  T(k) - T(k-1) = what layer k costs inside the step, T(0) = embedding + knn + gate + heads + posterior."""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd.config import default_model_config
 from phoregen_amd.models.diffusion import PhoreDiff

@@ -1,7 +1,8 @@
 """ms per sampler step for several batch sizes and engine variants in ONE process (same box, alternating runs).
 usage: bench_variants.py 16,32,128 "base" "fused_geom=False" "tri_grid=224,knn_merge='always'" ...   (options.override keywords)"""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd import options
 from phoregen_amd.config import default_model_config

@@ -2,7 +2,8 @@
 step's first launch), duration, lane, entry point.  No profiler attached: a kernel-trace profiler adds device-side latency to
 every dispatch and stretches exactly the small-batch chains this is for.   usage: event_timeline.py [graphs] [step-count]"""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd.config import default_model_config
 from phoregen_amd.models.diffusion import PhoreDiff

@@ -1,6 +1,7 @@
 """Print the pipelined step's launch list (prog_step) of a G-graph batch: entry, lane, order-point ops -- to see what a launch waits for."""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd.config import default_model_config
 from phoregen_amd.models.diffusion import PhoreDiff

@@ -2,7 +2,8 @@
 stream sets (graphs are independent, the noise is keyed by the global graph id).  Prints ms per step of the whole batch and the
 host enqueue time, for S = 1, 2, 4.   usage: exp_interleave.py [G ...]"""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload, subset_workload
 from phoregen_amd.config import default_model_config
 from phoregen_amd.engine import Engine

@@ -1,7 +1,8 @@
 """The actual rank shares of the headline batch (partition_graphs, by size) timed with several persistent-grid sizes of the triplet kernel:
 where does the best grid flip?  usage: share_tri_grid.py <world> <grid> <grid> ..."""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload, subset_workload
 from phoregen_amd import options
 from phoregen_amd.config import default_model_config

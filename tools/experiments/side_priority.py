@@ -1,7 +1,8 @@
 """Side lanes with HIP stream priorities (one process per variant: streams map onto hardware queues when they are created).
 usage: side_priority.py <graphs> <prio lane 1> <prio lane 2> <prio lane 3>     (0 normal, 1 low, -1 high)"""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd import engine
 from phoregen_amd.config import default_model_config

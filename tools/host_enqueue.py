@@ -1,5 +1,6 @@
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd.config import default_model_config
 from phoregen_amd.models.diffusion import PhoreDiff

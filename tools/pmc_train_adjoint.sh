@@ -2,6 +2,7 @@
 # PMC passes over a short training benchmark for the dominant kernel of config 5, the triplet adjoint (seg_attn_bwd_kernel<4, ...>):
 # MFMA / VALU instruction counts and HBM-side bytes per launch -> gpurun_out/<tag>_train_adjoint_mfma.json (copied to
 # profiles/train_adjoint_mfma.json, which tools/bench_train.py reads for its `roofline` object).   usage: tools/pmc_train_adjoint.sh <tag>
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 tag=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmc_${tag}_trainadj

@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes over the triplet micro-benchmark (run on the GPU box via gpurun). Output: gpurun_out/pmc_<tag>/
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 tag=${1:-tri}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc_${tag}

@@ -2,7 +2,8 @@
 on the fitted step cost), every rank's share is run here one after the other, and the slowest share sets the N-GPU step time (the ranks
 do not communicate inside the loop).  Prints per N: graphs / cost / ms per step of every share, predicted speed-up = T(128 graphs) / max."""
 import json, sys, time, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload, subset_workload
 from phoregen_amd.config import default_model_config
 from phoregen_amd.models.diffusion import PhoreDiff

@@ -1,6 +1,7 @@
 #!/bin/bash
 # builds a profiling copy of the library (section cycle counters in pg_seg_attn_bwd, -DPG_BWD_PROF) into phoregen_amd/_lib_prof
 # and prints the split of one training step (GPU box)
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 set -e
 cd $GRAFT_REPO_ROOT/phoregen_amd/csrc && make -j8 EXTRA=-DPG_BWD_PROF OUT=../_lib_prof > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT && PHOREGEN_DEBUG=1 PHOREGEN_HIP_LIB=phoregen_amd/_lib_prof/libphoregen_hip.so python3 tools/prof_bwd.py

@@ -1,5 +1,5 @@
 import cProfile, pstats, sys, os, io
-sys.path.insert(0, '/root/repo')
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 sys.argv = ['bench_train.py', '--steps', '3', '--warmup', '2']
 import tools.bench_train as bt
 pr = cProfile.Profile()

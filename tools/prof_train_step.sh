@@ -1,6 +1,7 @@
 #!/bin/bash
 # kernel table of a training step (config 5) + PMC record of the triplet adjoint -> gpurun_out/<tag>_train_kernel_stats.md,
 # gpurun_out/<tag>_train_adjoint_mfma.json (copied to profiles/).   usage: tools/prof_train_step.sh <tag>
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/${tag}_train_prof

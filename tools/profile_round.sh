@@ -2,6 +2,7 @@
 # Round profile set (run on the GPU box through gpurun): kernel-trace of the default bench (streams + serial), PMC passes of
 # the dominant kernel with FETCH/WRITE, the summaries land in gpurun_out/<tag>_* and are then copied into profiles/ by
 # tools/save_profile.py.   usage: tools/profile_round.sh <tag> <kernel-pattern>
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 tag=${1:-r03}; pat=${2:-triplet2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for mode in streams serial; do

@@ -2,6 +2,7 @@
 # Matrix-pipe work per sampler step by kernel, measured: one rocprofv3 PMC pass (SQ_INSTS_MFMA, SQ_INSTS_VALU, SQ_VALU_MFMA_BUSY_CYCLES,
 # GRBM_GUI_ACTIVE) over a short one-stream bench + its kernel trace -> gpurun_out/<tag>_step_mfma_by_kernel.md.  Cross-checks the executed-FLOP
 # counts of bench.executed_flops (step_roofline.exec_frac) against the hardware's own instruction counters.
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 set -e
 tag=${1:-r04}
 steps=8

@@ -1,6 +1,7 @@
 #!/bin/bash
 # HBM-side traffic per sampler step by kernel: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate passes as the guide
 # prescribes) over a short serial bench, aggregated by tools/step_traffic.py into gpurun_out/<tag>_step_traffic_by_kernel.md
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 set -e
 tag=${1:-r03}
 steps=8

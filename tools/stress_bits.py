@@ -2,7 +2,8 @@
 the schedule variant the engine picks for it: v2 / per-chain closing launch / merged knn launch / Q rows on the side lane / two triplet
 launches).  Any mismatch of a single bit is a missing order point.   usage: stress_bits.py [repeats]"""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd import options
 from phoregen_amd.config import default_model_config

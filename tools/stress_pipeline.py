@@ -2,7 +2,8 @@
 seed, S steps, several batch sizes (every schedule regime), with and without guidance, R repetitions of the pipelined run.  Any differing bit in
 any trajectory frame is a missing order point.   usage: stress_pipeline.py [steps] [repeats]"""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _ROOT)
 from bench import ligphore_workload
 from phoregen_amd.config import default_model_config
 from phoregen_amd.models.diffusion import PhoreDiff

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Kernel timelines of one sampler step at 16 / 32 / 128 graphs (rocprofv3 --kernel-trace of a short bench, tools/timeline.py) and the
 # strong-scaling estimate from the actual rank shares (tools/predict_scaling.py).   usage: tools/timelines_round.sh <tag>   (GPU box)
+: ${GRAFT_REPO_ROOT:?run through gpurun (or export GRAFT_REPO_ROOT=<repo root>)}
 tag=${1:-r04}
 cd $GRAFT_REPO_ROOT
 for g in 16 32 128; do
