@@ -263,6 +263,91 @@ def measured_mfma_peak(dev):
     return best
 
 
+def secondary_configs(model, dev, budget_s=80.0):
+    """BASELINE.json's other single-GPU configurations, run AFTER the headline's timed region in the same process (rank 0, N = 1) so that
+    the driver's own bench run carries them: configs[1] (one 100-graph `sample`, 1000 steps, sample.sh's guidance), configs[4] (the
+    training step, 256 pairs) and configs[3] as a job on this GPU (2 batches of 128 graphs, 1000 steps each, graphs / hour).  Each entry
+    states its `steps` and the arithmetic that ties its value to the wall time measured here; an entry that would not fit the time
+    budget is listed as skipped.  The headline fields are untouched."""
+    import numpy as np
+    out, t_start = {}, time.perf_counter()
+    left = lambda: budget_s - (time.perf_counter() - t_start)
+    # ---- configs[1]: sample_all.py --num_samples 100 on one pharmacophore (tests/golden/g8_phore_parse.npz = P03211_merge.phore parsed) ----
+    try:
+        from phoregen_amd.data import PhoreGraph
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g8_phore_parse.npz'))
+        tt = lambda a: torch.as_tensor(np.asarray(a))
+        data = PhoreGraph(tt(g['x']), tt(g['pos']), tt(g['norm']), tt(g['center'])).to(dev)
+        guid = [{'type': 'atom_prox', 'min_d': 1.2, 'max_d': 1.9}, {'type': 'center_prox'}]            # sample.sh:21,31
+        na = torch.randint(20, 45, (100,), generator=torch.Generator().manual_seed(2032))
+        model.sample(data, 100, dev, pos_guidance_opt=guid, num_atoms=na, num_steps=3, return_traj=False)   # (plan / engine of this shape)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = model.sample(data, 100, dev, pos_guidance_opt=guid, num_atoms=na, return_traj=True)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out['config2_s'] = {'value': dt, 'unit': 's', 'steps': 1000, 'graphs': 100, 'guidance': 'atom_prox(1.2, 1.9) + center_prox',
+                            'what': 'BASELINE.json configs[1]: wall time of ONE PhoreDiff.sample call (100 graphs on the 44-node pharmacophore, '
+                                    '1000 steps, trajectory written), topology + encoder + result tensors included',
+                            'ms_per_step': dt, 'steps_per_sec': 1000 / dt, 'n_lig': int(na.sum()), 'e_bond': int((na * (na - 1)).sum()),
+                            'finite': bool(torch.isfinite(res['pred'][1]).all())}
+        del res
+    except Exception as ex:                                                  # a secondary figure never takes the headline line down
+        out['config2_s'] = {'error': repr(ex)[:300]}
+    # ---- configs[4]: one training step (compute_loss forward + backward + Adam) on 256 synthetic pairs ----
+    try:
+        if left() < 20:
+            raise TimeoutError(f'skipped: {left():.0f} s of the {budget_s:.0f} s budget left')
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from bench_train import train_workload
+        batch, na_t = train_workload(256, seed=4321)
+        batch.to(dev)
+        model.train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss, info = model.compute_loss(batch)
+            loss.backward()
+            opt.step()
+            return info
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            info = step()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out['train_ms_per_step'] = {'value': dt / 3 * 1e3, 'unit': 'ms/step', 'steps': 3, 'warmup': 2, 'graphs': 256,
+                                    'what': 'BASELINE.json configs[4]: compute_loss forward + backward + Adam on 256 synthetic ligand-pharmacophore '
+                                            'pairs (n ~ N(25, 5) clamp [8, 60]); tools/bench_train.py is the full benchmark',
+                                    'wall_s': dt, 'n_lig': int(na_t.sum()), 'e_bond': int((na_t * (na_t - 1)).sum()), 'last_loss': float(info['loss'])}
+        del opt, batch
+        model.zero_grad(set_to_none=True)
+        model.eval()
+        model.invalidate_pack()            # (Adam moved the weights: the sampler below packs them again)
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        model.eval()
+        out['train_ms_per_step'] = {'error': repr(ex)[:300]}
+    # ---- configs[3] as a job on ONE GPU: 2 batches of 128 graphs of several pharmacophores, 1000 steps each, return_traj=False ----
+    try:
+        if left() < 45:
+            raise TimeoutError(f'skipped: {left():.0f} s of the {budget_s:.0f} s budget left')
+        from phoregen_amd.parallel import run_sampling_job
+        job = config4_job(n_phores=8, samples=32)
+        run_sampling_job(model, config4_job(n_phores=2, samples=4, seed=1), batch_size=8, num_steps=3)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        pred, na4 = run_sampling_job(model, job, batch_size=128)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out['config4_graphs_per_hour'] = {'value': job.n_graphs / dt * 3600, 'unit': 'graphs/hour (one GPU)', 'steps': 1000, 'batches': 2, 'graphs': job.n_graphs,
+                                          'what': 'BASELINE.json configs[3], one GPU\'s slice: 8 synthetic CpxPhore/DockPhore-shaped pharmacophores x 32 samples, '
+                                                  'run_sampling_job in batches of 128, everything between the batches included',
+                                          'wall_s': dt, 'ms_per_step_per_batch': dt / 2, 'graph_steps_per_sec': job.n_graphs * 1000 / dt,
+                                          'finite': bool(torch.isfinite(pred[1]).all())}
+    except Exception as ex:
+        out['config4_graphs_per_hour'] = {'error': repr(ex)[:300]}
+    out['secondary_wall_s'] = time.perf_counter() - t_start
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -306,6 +391,7 @@ def main():
     ap.add_argument('--graphs', type=int, default=128)
     ap.add_argument('--fixed-shape', action='store_true', help='n=40, p=107 for every graph (closed-form counts)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip BASELINE configs[1] / [3] / [4] after the timed region (they run at N = 1 in a full default-style run only)')
     ap.add_argument('--weak', action='store_true',
                     help='weak scaling only: --graphs graphs PER GPU (default: strong scaling, SURVEY.md 8d: ONE batch of '
                          '--graphs graphs partitioned over the ranks by the fitted step cost; a weak-scaling figure is added for N > 1)')
@@ -502,6 +588,12 @@ def main():
             'weak_scaling': weak,
             'final_gather_ms': gather_ms,
         }
+        # the other single-GPU configurations of BASELINE.json, after the timed region (N = 1, full runs only: the quick runs of tools/ pass
+        # --no-cpu-baseline or another --graphs)
+        if world == 1 and not (args.no_secondary or args.no_cpu_baseline or args.weak) and args.graphs == 128:
+            del res
+            torch.cuda.empty_cache()
+            line.update(secondary_configs(model, dev))
         if not args.no_cpu_baseline:           # rank 0, after the timed region, at every world size (the other ranks wait at the
             line['cpu_baseline'] = cpu_baseline(full)      # final barrier below)
         else:
