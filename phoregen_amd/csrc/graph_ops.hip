@@ -421,7 +421,7 @@ int num_cu() {
 using namespace pg;
 
 extern "C" const char* pg_last_error(void) { return pg::g_err; }
-extern "C" int pg_abi_version(void) { return 10; }
+extern "C" int pg_abi_version(void) { return 11; }
 // sizeof of the argument structs as THIS build sees them (a binding's mirror is checked against it when the library is loaded)
 extern "C" int pg_abi_struct_sizes(int* out, int n) {
   const int v[5] = {(int)sizeof(PgGemm), (int)sizeof(PgTopo), (int)sizeof(PgSegAttn), (int)sizeof(PgSegAttnGrad), (int)sizeof(PgLaunch)};

@@ -78,7 +78,7 @@ PROGRAM_OPS = {'pg_gemm': 2, 'pg_seg_attn': 3, 'pg_embed_ctx': 4, 'pg_embed_bond
 SEG_KNN_NODE, SEG_KNN_POS, SEG_BOND_NODE, SEG_BOND_POS, SEG_TRIPLET, SEG_PHORE = range(6)
 ACT_NONE, ACT_SSP, ACT_RELU = 0, 1, 2
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 
 _PROTOS = {

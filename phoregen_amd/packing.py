@@ -11,6 +11,9 @@ import math
 
 import torch
 
+# fixed offsets of every GaussianSmearing on the path (models/common.py:18; fix_offset=True)
+_SMEAR_OFF = (0., 1., 1.25, 1.5, 1.75, 2., 2.25, 2.5, 2.75, 3., 3.5, 4., 4.5, 5., 5.5, 6., 7., 8., 9., 10.)
+
 # queries are pre-scaled by 1/sqrt(head_dim) (np.sqrt(k.shape[-1]) = sqrt(8), uni_denoiser.py:62,158,204) and by
 # log2(e): the kernels' segment softmax runs in base 2 (one v_exp_f32 per weight), which is the same softmax
 HEAD_SCALE = math.log2(math.e) / math.sqrt(8.0)

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from . import hip, options
 from .packing import HEAD_SCALE, NODE1_PARTS, NODE2_PARTS, PHORE_PARTS, ModelPack
 
-_SMEAR_OFF = (0., 1., 1.25, 1.5, 1.75, 2., 2.25, 2.5, 2.75, 3., 3.5, 4., 4.5, 5., 5.5, 6., 7., 8., 9., 10.)
+from .packing import _SMEAR_OFF
 
 
 def _st():

@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pg_abi_version() == 10 == hip.ABI_VERSION
+    assert lib.pg_abi_version() == 11 == hip.ABI_VERSION
     import ctypes as _C
     sizes = (_C.c_int * 5)()
     assert lib.pg_abi_struct_sizes(sizes, 5) == 5      # (load_library has already held the ctypes mirrors against these)
