@@ -1,0 +1,57 @@
+"""The engine's launch lists are ORDERED by construction, not by timing (tools/check_schedule.py): every two launches that touch the same
+buffer region, one of them writing, are connected through lane order and the record / wait points -- in the plain forward list and across
+three consecutive steps of the pipelined sampler loop, for batch sizes that cover every schedule regime (phoregen_amd/options.py).
+(The lists hold device pointers, so an engine must be built on the GPU; nothing is launched.)"""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def model():
+    from phoregen_amd.config import default_model_config
+    from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.weights import init_deterministic_
+    return init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to('cuda')
+
+
+@pytest.mark.parametrize('graphs', [2, 8, 16, 48, 72, 128])
+@pytest.mark.parametrize('guided', [False, True])
+def test_launch_lists_are_ordered(model, graphs, guided):
+    from bench import ligphore_workload
+    import check_schedule as cs
+    fwd, pipe, info = cs.check_engine(model, ligphore_workload(graphs), guided)
+    model._engine = None
+    assert info['pipelined'] and pipe is not None
+    assert not fwd, [cs.fmt(h) for h in fwd]
+    assert not pipe, [cs.fmt(h) for h in pipe]
+
+
+def test_checker_notices_a_missing_order_point(model):
+    """Round 5's advisor finding, replayed: in the pipelined v2 schedule lane 2 (node head -> node posterior -> `prog_ahead`, which embeds the
+    NEXT step's features into h[0]) must wait for lane 1's last reads of h' = h[0] (the position phase's first-layer products).  With that one
+    wait removed the check reports the write-after-read pair on ws.h[0]; with every wait of `prog_step` removed in turn, some hazard appears for
+    most of them (the list carries few redundant waits)."""
+    from bench import ligphore_workload
+    import check_schedule as cs
+    work = ligphore_workload(16)
+    _, pipe, info = cs.check_engine(model, work)
+    eng = info['eng']
+    assert info['v2'] and not pipe
+    waits = [(k, pt, ln) for k, (fn, a, lane) in enumerate(eng.prog_step) if lane < 0 and fn.kind == 'order'
+             for what, pt, ln in fn.ops if what == 'wait']
+    found_h0, n_sensitive = False, 0
+    for k0, pt0, ln0 in waits:
+        _, pipe, _ = cs.check_engine(model, work, drop_step=lambda k, what, pt, ln: what == 'wait' and (k, pt, ln) == (k0, pt0, ln0))
+        n_sensitive += bool(pipe)
+        if ln0 == 2 and any(h[6] == 'ws.h[0]' and 'pg_gemm' in h[0] and 'pg_embed_ctx' in h[3] for h in pipe):
+            found_h0 = True
+    model._engine = None
+    assert found_h0, 'the dropped lane-2 wait behind the node head must surface as a hazard on ws.h[0]'
+    assert n_sensitive >= len(waits) // 2, (n_sensitive, len(waits))
