@@ -452,12 +452,9 @@ def main():
                                   return_traj=True, num_steps=n_total, graph_ids=gids, pipeline=True)
         for i in range(W):
             model.reverse_step(st, i, T - 1 - i)
-        # small batches time neighbouring triplet grids during their first ~20 steps (Engine._tune_*): those steps stay outside the timed
-        # region -- the warm-up is extended until the choice is made and the line reports the number of untimed steps actually run
+        # (small batches choose their persistent triplet grid inside begin_sampling since round 6 -- Engine.calibrate_tri_grid -- so the loop
+        #  below runs a fixed launch list; nothing of the choice falls into the timed region)
         extra = 0
-        while getattr(st.eng, '_tune', None) is not None and extra < n_total - W - R * K:
-            model.reverse_step(st, W + extra, T - 1 - W - extra)
-            extra += 1
         if time_triplet:                       # (the headline run; the weak-scaling figure below reports its own)
             run.warmup_steps = W + extra
         times, tri, knn = [], [], []

@@ -23,6 +23,9 @@ from .packing import HEAD_SCALE, ModelPack
 _SIDE_STREAMS = {}
 
 
+_TRI_GRID_CACHE = {}       # batch shape -> (persistent triplet grid chosen by Engine.calibrate_tri_grid, its timings)
+
+
 def side_streams(device_index, stream_set=0):
     """The three side lanes of a device, shared by every Engine of the process: the runtime maps HIP streams onto a handful of
     hardware queues (4 by default), and streams that share a queue serialise -- an Engine that created its own streams made the
@@ -84,7 +87,6 @@ class Engine:
         # switch them with options.override(...), the ambient environment only counts under PHOREGEN_DEBUG=1)
         o = options.snapshot()
         self.multi_stream = o['streams']
-        self.row_subsets = o['row_subsets']
         self.staged_triplet = o['tri_staged']          # csrc/triplet2.hip (False: the gather kernel)
         self.fused_node = o['node_fused']              # node attention folds / unfolds in-kernel
         self.group_knn = o['knn_group']                # neighbour slots partitioned by source kind
@@ -100,8 +102,6 @@ class Engine:
         self.tune_grid = o['tune_grid']
         self.tuned_tri_grid = None
         self.geom_split = o['geom_split'] == 'always' or (o['geom_split'] == 'auto' and self.plan.n_bond < o['geom_split_below'])
-        self.small_below = o['small_below']
-        self.ahead_below = o['ahead_below']
         # (hipGraph capture of the v2 launch list segfaults inside the runtime -- lanes 2 / 3 wait on lane 1 there while lane 1 waits on
         #  lane 3; the replay variant, off by default and measured slower, keeps the previous list)
         self.ahead_v2 = (o['ahead_v2'] == 'always' or (o['ahead_v2'] == 'auto' and self.plan.n_bond < o['ahead_v2_below'])) and not o['graph']
@@ -111,7 +111,7 @@ class Engine:
         self.tri_grid = o['tri_grid']                  # persistent triplet workgroups (-1: by batch size)
         # apply_dx + bond smearing + direction vectors as one launch on lane 0: small batches (measured, same box: 16 graphs 3.52 -> 3.40 ms
         # per step, 32 graphs 5.69 -> 5.43; 128 graphs 20.20 -> 20.28: there the three launches hide beside the first-layer GEMM)
-        self.fused_geom = o['fused_geom'] == 'always' or (o['fused_geom'] == 'auto' and self.plan.n_bond < o['small_below'])
+        self.fused_geom = o['fused_geom'] in ('always', 'auto')
         # hipGraph replay of the forward launch list.  Off by default: measured on MI355X it buys nothing, a step
         # is bound by the ~225 dependent kernels themselves, not by their launches (tools/bench_graph.py: B=1 3.19 -> 2.95,
         # B=10 3.89 -> 4.07, B=30 5.33 -> 5.92 ms/step; identical results)
@@ -298,11 +298,7 @@ class Engine:
         """q = W2q . ReLU(LN(q_hid)) + b2q, scaled by 1/sqrt(head_dim); q_hid = block 4 of the sub-layer's first-layer columns."""
         n, wq = self.plan.n_ctx, self.ws.q[buf]
         qh = Y[:, col0 + 4 * 128: col0 + 5 * 128]
-        if len(h_dst_lists) == 1 and self.row_subsets:      # queries are only needed at the target rows
-            ids, cnt, _ = h_dst_lists[0]
-            self._gemm(prog, qh, 128, a.W2q, wq, cnt, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE, rows=ids)
-        else:
-            self._gemm(prog, qh, 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
+        self._gemm(prog, qh, 128, a.W2q, wq, n, 128, bias=a.b2q, ln=(a.q_ln_g, a.q_ln_b), scale=HEAD_SCALE)
 
     def _node_attention(self, prog, mode, a, Y, col0, x, h_dst_lists, out=None, dx=None, csrc=None, buf=0, extra=None,
                         query_done=False, qbuf=None):
@@ -467,7 +463,7 @@ class Engine:
     def pipelined_programs(self):
         """(prog_step, prog_ahead) of the pipelined sampler step, or None when this engine's schedule has no layer-ahead form."""
         if not (self.step_ahead and self.multi_stream and self.layer_ahead and self.fused_geom and self.staged_triplet and self.plan.n_tri_iters
-                and self.order_points and self.plan.n_bond < min(self.small_below, self.ahead_below)):
+                and self.order_points):
             return None
         if self.prog_step is None:
             tri_calls, self.tri_calls = self.tri_calls, []
@@ -480,11 +476,7 @@ class Engine:
         # first-layer blocks: knn-node blocks for every ctx node, bond-node / triplet blocks only where they are read
         # (ligand atoms: targets and sources of bond edges)
         p, n = self.plan, self.plan.n_ctx
-        if self.row_subsets:
-            self._gemm(prog, h_in, 128, L.W_node1[:640], Y1[:, :640], n, 640, bias=L.b_node1[:640])
-            self._gemm(prog, h_in, 128, L.W_node1[640:], Y1[:, 640:], p.n_lig, 1280, bias=L.b_node1[640:], rows=p.lig2ctx)
-        else:
-            self._gemm(prog, h_in, 128, L.W_node1, Y1, n, 1920, bias=L.b_node1)
+        self._gemm(prog, h_in, 128, L.W_node1, Y1, n, 1920, bias=L.b_node1)
 
     def _triplet_queries(self, prog, L, hb_in, Y1):
         w, p, E = self.ws, self.plan, self.plan.n_bond
@@ -518,7 +510,7 @@ class Engine:
         # next layer's x-independent products inside this layer's position phase: measured (same box, alternating runs) 16 graphs
         # 3.93 -> 3.83 ms, 32 graphs 5.94 -> 5.67, 64 graphs 10.55 -> 10.36, 128 graphs 20.12 -> 20.17 (the triplet kernel then
         # shares the chip with more side work: 2.03 -> 2.19 ms per launch) -- so it is used below ~100 graphs of the headline shape
-        ahead = self.layer_ahead and self.multi_stream and E < min(self.small_below, self.ahead_below)
+        ahead = self.layer_ahead and self.multi_stream
         v2 = self.ahead_v2 and ahead        # Y1 of the next layer on lane 1 behind Y2, bond-node of layer 0 on lane 3, finer waits (round 4)
         # the Q rows (a K = 20 product, bound by its 256-wide output) behind P on the bond chain's own lane, or beside P on lane 2: lane 0 in
         # the v2 schedule (there lane 2 would need its own release after the layer's closing launch: measured equal or slower, 8 graphs
@@ -531,11 +523,11 @@ class Engine:
         # ... and which multiple of 32 is best flips from batch to batch of the SAME size (whole 12-segment rounds per workgroup against
         # the CUs left to the node chain: rank shares of the headline batch with 25.7 k bond edges each: 3.48 / 3.31 ms with 192 / 224
         # workgroups for one, 3.27 / 3.48 for the next; profiles/r04_share_tri_grid.txt), so small batches TIME the neighbours of this
-        # default during their first steps and keep the fastest (`_tune_*`; the result does not depend on the grid: the queue hands out the
-        # same segments)
+        # default once, before the sampler loop, and keep the fastest (`calibrate_tri_grid`; the result does not depend on the grid: the queue
+        # hands out the same segments)
         self._tune = None
         if (self.tune_grid and self.tri_grid < 0 and self.multi_stream and staged and 0 < tri_grid <= 224 and not self.graph_mode == '1'):
-            self._tune = dict(cands=[g for g in (tri_grid, tri_grid + 32, tri_grid - 32) if 128 <= g <= 256], marks=[], skip=3)
+            self._tune = dict(cands=[g for g in (tri_grid, tri_grid + 32, tri_grid - 32) if 128 <= g <= 256])
 
         if v2 and w.Y1b is None:
             w.Y1b = torch.empty_like(w.Y1)
@@ -689,12 +681,7 @@ class Engine:
             # ---- position updates from h', h_bond' and the OLD geometry (:291-296)
             # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
             # only for ligand atoms
-            if self.row_subsets:
-                self._gemm(prog, hn, 128, L.W_node2[256:512], w.Y2[:, 256:512], n, 256, bias=L.b_node2[256:512])
-                self._gemm(prog, hn, 128, L.W_node2[:256], w.Y2[:, :256], p.n_lig, 256, bias=L.b_node2[:256], rows=p.lig2ctx)
-                self._gemm(prog, hn, 128, L.W_node2[512:], w.Y2[:, 512:], p.n_lig, 768, bias=L.b_node2[512:], rows=p.lig2ctx)
-            else:
-                self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
+            self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
             if step_ahead and self.head_early and last and v2:
                 # lane 1's last read of h' (= h[0] in the last layer): `prog_ahead` embeds the NEXT step's features into h[0] on lane 2, which in
                 # this schedule is released by `hn_done` alone -- it must not pass these products (advisor, round 5: a write-after-read hazard
@@ -873,7 +860,7 @@ class Engine:
             self._run(self.prog_fwd)
         self._graph = g
 
-    TUNE_REPS = 6          # steps per candidate grid: the first settles, five are timed
+    TUNE_REPS = 6          # timing marks per candidate grid (five timed steps between them, behind one settling step)
 
     def _set_tri_grid(self, grid):
         for i in self.tri_calls:
@@ -882,37 +869,50 @@ class Engine:
             for i in self.step_tri_calls:
                 self.prog_step[i][1][-1]._obj.tri_grid = grid
 
-    def _tune_begin(self):
-        """One timing event at the START of every forward of the tuning phase: the period between two of them is a whole sampler step
-        (denoiser, posterior kernels, whatever overlaps), which is what the choice is about.  The decision (after ~20 forwards of a new
-        Engine) waits ONCE on the host for the last mark; results do not depend on the grid (the queue hands out the same segments)."""
-        t = self._tune
-        if t['skip'] > 0:                            # the first forwards of an engine pay one-time costs (kernel attributes, allocator)
-            t['skip'] -= 1
+    def calibrate_tri_grid(self, run_step):
+        """Small batches: which persistent grid of the triplet kernel (the default by size or its neighbours, multiples of 32 workgroups) makes a
+        whole sampler step fastest -- the kernel shares the chip with the node chain's launches, and which multiple wins flips between batches of
+        the SAME size (profiles/r04_share_tri_grid.txt).  Decided ONCE, in `PhoreDiff.begin_sampling`, before the caller's loop: `run_step(k)` runs
+        one real sampler step (denoiser, posteriors, whatever overlaps) on scratch state; per candidate one settling step and TUNE_REPS - 1 timed
+        ones, HIP events between the steps, one host wait at the end.  The loop itself then has no host synchronisation and a fixed launch
+        configuration; the choice is remembered per batch shape for the life of the process (`_TRI_GRID_CACHE`).  Results do not depend on
+        the grid (the queue hands out the same segments)."""
+        t, self._tune = self._tune, None
+        if t is None:
             return
-        cur = torch.cuda.current_stream().cuda_stream
-        if t.setdefault('stream', cur) != cur:       # the caller changed streams between forwards: the marks cannot be compared -> keep the default
-            self._set_tri_grid(t['cands'][0])
-            self._tune = None
+        key = (self.plan.n_bond, self.plan.n_ctx, self.plan.n_graphs, self.plan.topo.max_nlig)
+        if key in _TRI_GRID_CACHE:
+            self.tuned_tri_grid, self.tuned_tri_grid_ms = _TRI_GRID_CACHE[key]
+            self._set_tri_grid(self.tuned_tri_grid)
             return
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        t['marks'].append(ev)
-        k = len(t['marks']) - 1                      # this forward's index within the phase
-        if k == self.TUNE_REPS * len(t['cands']):    # one past the last candidate's steps: decide
-            ev.synchronize()                         # the one host wait of the tuning phase
-            ms = {}
-            for ci, g in enumerate(t['cands']):
-                per = sorted(t['marks'][j].elapsed_time(t['marks'][j + 1]) for j in range(ci * self.TUNE_REPS + 1, (ci + 1) * self.TUNE_REPS))
-                ms[g] = 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]) if len(per) % 2 == 0 else per[len(per) // 2]
-            best = min(ms, key=ms.get)
-            if ms[best] > 0.99 * ms[t['cands'][0]]:  # the default stays unless a neighbour is clearly faster
-                best = t['cands'][0]
-            self._set_tri_grid(best)
-            self.tuned_tri_grid, self.tuned_tri_grid_ms = best, ms
-            self._tune = None
-        elif k % self.TUNE_REPS == 0:
-            self._set_tri_grid(t['cands'][k // self.TUNE_REPS])
+        k = 0
+        for _ in range(3):                            # the first steps of an engine pay one-time costs (kernel attributes, allocator)
+            run_step(k)
+            k += 1
+        marks = {}
+        for g in t['cands']:
+            self._set_tri_grid(g)
+            run_step(k)                               # settles
+            k += 1
+            marks[g] = []
+            for _ in range(self.TUNE_REPS):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks[g].append(ev)
+                if len(marks[g]) < self.TUNE_REPS:
+                    run_step(k)
+                    k += 1
+        torch.cuda.current_stream().synchronize()    # the one host wait (inside begin_sampling)
+        ms = {}
+        for g, evs in marks.items():
+            per = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+            ms[g] = 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]) if len(per) % 2 == 0 else per[len(per) // 2]
+        best = min(ms, key=ms.get)
+        if ms[best] > 0.99 * ms[t['cands'][0]]:      # the default stays unless a neighbour is clearly faster
+            best = t['cands'][0]
+        self._set_tri_grid(best)
+        self.tuned_tri_grid, self.tuned_tri_grid_ms = best, ms
+        _TRI_GRID_CACHE[key] = (best, ms)
 
     def lane_stream(self, lane):
         """hipStream_t of a lane for launches the caller adds beside a program (lane 0 = torch's current stream)."""
@@ -940,20 +940,11 @@ class Engine:
         """The denoiser forward of a pipelined sampler step (`prog_step`): (out_v, the ctx-ordered final coordinates, out_bond) WITHOUT joining
         lanes 2 / 3 (out_v is complete on lane 2, out_bond on lane 3)."""
         w = self.ws
-        tuning = self._tune is not None and self.timers is None and self.trace is None and self.debug is None and \
-            not torch.cuda.is_current_stream_capturing()
-        if tuning:
-            self._tune_begin()
         self._run(self.prog_step)
         return w.out_v, w.x[self.final_idx], w.out_bond        # (x0 in ctx rows: the Gaussian posterior reads it through lig2ctx)
 
     def forward_inplace(self):
         w = self.ws
-        tuning = self._tune is not None and self.timers is None and self.trace is None and self.debug is None
-        if tuning and torch.cuda.is_current_stream_capturing():      # (the decision takes one host wait: never inside a caller's capture)
-            tuning = False
-        if tuning:
-            self._tune_begin()
         if self._graph_wanted():
             if self._graph is None:
                 self._capture()

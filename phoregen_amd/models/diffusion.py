@@ -470,7 +470,29 @@ class PhoreDiff(nn.Module):
             cnt = torch.zeros(B, 1).index_add_(0, bp, keep)
             st.gc = (sums / cnt).to(dev).contiguous()      # (0/0 = nan for a pharmacophore of exclusion spheres only, as in the reference)
         st.x0 = None
+        if getattr(eng, '_tune', None) is not None and not st.cpu:
+            self._calibrate_launch_configuration(st)
         return st
+
+    def _calibrate_launch_configuration(self, st):
+        """Small batches: `Engine.calibrate_tri_grid` times a few REAL sampler steps per candidate grid -- here, before the caller's loop, on the
+        state just initialised, which is put back afterwards (the device noise is counter-based: nothing is consumed; no trajectory frame is
+        written).  The loop then runs a fixed launch list with no host synchronisation in it (round-5 review, item 8)."""
+        eng, w = st.eng, st.eng.ws
+        saved = [t.clone() for t in (w.in_h_node, w.in_pos, w.in_h_edge, st.log_node[0], st.log_edge[0])]
+        keep = (st.node_traj, st.pos_traj, st.edge_traj, st.return_traj, st.n_steps)
+        st.node_traj = st.pos_traj = st.edge_traj = None
+        st.return_traj, st.n_steps = False, self.num_timesteps
+        T = self.num_timesteps
+        try:
+            eng.calibrate_tri_grid(lambda k: self.reverse_step(st, k, T - 1 - k))
+        finally:
+            if st.pipelined:
+                eng.join_lanes((2, 3))
+            st.node_traj, st.pos_traj, st.edge_traj, st.return_traj, st.n_steps = keep
+            for dst, src in zip((w.in_h_node, w.in_pos, w.in_h_edge, st.log_node[0], st.log_edge[0]), saved):
+                dst.copy_(src)
+            st.cur, st.next_step, st.x0 = 0, None, None
 
     @torch.no_grad()
     @_on_model_device

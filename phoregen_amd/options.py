@@ -10,7 +10,6 @@ import os
 
 DEFAULTS = dict(
     streams=True,         # four lanes (HIP streams) per layer; False: one stream
-    row_subsets=False,    # first-layer blocks only on the rows that read them
     tri_staged=True,      # csrc/triplet2.hip (False: the gather kernel, triplet.hip)
     node_fused=True,      # node attention folds the query / unfolds the value in-kernel
     knn_group=True,       # neighbour slots partitioned by source kind
@@ -19,10 +18,6 @@ DEFAULTS = dict(
     ahead_v2='auto',      # next layer's Y1 on the node chain's lane behind Y2, P waits for it alone, layer 0's bond-node attention on lane 3:
                           # 'auto' = small batches (8 / 16 / 32 graphs - 3 % / - 3.5 % / - 1 %; 64 / 128 graphs + 0.4 % / + 1.7 %), 'never', 'always'
     ahead_v2_below=82000, # ... 'auto': fewer bond edges than this (~55 graphs of the headline shape: 48 graphs 7.75 -> 7.63 ms, 64 graphs 9.97 -> 10.04)
-    ahead_below=10**9,    # ... up to this many bond edges.  (With the triplet sub-layer in two launches the 128-graph step is 0.4 % faster WITHOUT
-                          # them -- 19.64 -> 19.55 ms, 175000 here -- but the triplet kernel then shares the chip with more side work, 2.03 -> 2.14 ms per
-                          # sub-layer: kept on; 96 graphs need them, 14.85 -> 14.5.)
-    small_below=10**9,    # ... 'small' = fewer bond edges than this (round 4: the schedule pays at every size, 128 graphs 20.10 -> 19.81 ms)
     pos_tiled='auto',     # position-update attention with a node's row tiles over several waves: 'auto' = launches of few nodes, 'never', 'always'
     pos_tiled_below=1500, # ... 'auto': up to this many target nodes (32 graphs 5.29 -> 5.21 ms; at 64 graphs = 2 560 nodes it loses)
     step_ahead=True,      # the sampler loop as a software pipeline over reverse steps: the categorical posteriors behind their heads on the side
@@ -42,7 +37,7 @@ DEFAULTS = dict(
     tri_grid=-1,          # persistent workgroups of the staged triplet kernel (-1: by batch size)
     graph=False,          # hipGraph replay of the forward launch list
     fused_geom='auto',    # coordinate update + bond smearing + direction vectors as one launch on the bond chain's lane (pg_layer_geom):
-                          # 'auto' = small batches (below ~100 graphs of the headline shape), 'never', 'always'
+                          # 'auto' = 'always' (round 4: it pays at every batch size), 'never' = three launches on three lanes
     dgrad_mm=True,        # training: input gradients through the library GEMM
     rows_sum=True,        # training: pg_bond_rows_sum instead of atomic index_add_
     tri_onepass=True,     # training: one-pass triplet / node adjoints fed by the forward's softmax weights
@@ -62,9 +57,9 @@ DEFAULTS = dict(
 _tri = lambda v: {'0': 'never', '1': 'auto', '2': 'always'}[v]
 _flag = lambda v: v != '0'
 _ENV = {
-    'PG_STREAMS': ('streams', _flag), 'PG_ROW_SUBSETS': ('row_subsets', _flag), 'PG_TRI_STAGED': ('tri_staged', _flag),
+    'PG_STREAMS': ('streams', _flag), 'PG_TRI_STAGED': ('tri_staged', _flag),
     'PG_NODE_FUSED': ('node_fused', _flag), 'PG_KNN_GROUP': ('knn_group', _flag), 'PG_KNN_MERGE': ('knn_merge', _tri),
-    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_SMALL_BELOW': ('small_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_C_PROGRAM': ('c_program', _flag), 'PG_STEP_AHEAD': ('step_ahead', _flag), 'PG_CHAIN_Q_FROM': ('chain_q_from', int), 'PG_AHEAD_BELOW': ('ahead_below', int), 'PG_TRI_SPLIT': ('tri_split', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
+    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_C_PROGRAM': ('c_program', _flag), 'PG_STEP_AHEAD': ('step_ahead', _flag), 'PG_CHAIN_Q_FROM': ('chain_q_from', int), 'PG_TRI_SPLIT': ('tri_split', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
     'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
     'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int), 'PG_BWD_SPLIT': ('bwd_split', lambda v: {'0': 'none', '1': 'knn', '2': 'all'}[v]), 'PG_BWD_ATOM_SORT': ('bwd_atom_sort', _flag),
     'PG_TRI_BWD_FORM': ('tri_bwd_form', int), 'PG_TRI_BWD_GRID': ('tri_bwd_grid', int), 'PG_PH_ONEPASS': ('ph_onepass', _flag),

@@ -55,3 +55,20 @@ def test_checker_notices_a_missing_order_point(model):
     model._engine = None
     assert found_h0, 'the dropped lane-2 wait behind the node head must surface as a hazard on ws.h[0]'
     assert n_sensitive >= len(waits) // 2, (n_sensitive, len(waits))
+
+
+@pytest.mark.parametrize('shape,graphs', [('headline', 16), ('config2', 100), ('config4', 128)])
+def test_default_schedule_is_near_the_best_variant(model, shape, graphs):
+    """The size thresholds of phoregen_amd/options.py were fitted on the headline shape; here every size-dependent switch is forced both ways on
+    three shapes (tools/fit_schedule.py; BASELINE configs[2], [1], [3]) and the DEFAULT choice must stay within 4 % of the fastest variant
+    (best of two alternating runs each; the committed table profiles/r06_schedule_fit.md has it within 2 % at every size measured)."""
+    import fit_schedule as fs
+    w = next(w for s, g, w in fs.workloads(quick=True) if s == shape and g == graphs)
+    labels = [('default', {})] + [(f'{k}={list(v.values())[0]}', v) for k, vs in fs.VARIANTS.items() for v in vs]
+    best = {l: 1e9 for l, _ in labels}
+    for _ in range(2):
+        for l, kw in labels:
+            ms, _ = fs.ms_per_step(model, w, W=4, K=16, R=3, **kw)
+            best[l] = min(best[l], ms)
+    fastest = min(best, key=best.get)
+    assert best['default'] <= 1.04 * best[fastest], (shape, graphs, fastest, best)
