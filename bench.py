@@ -300,6 +300,8 @@ def secondary_configs(model, dev, budget_s=80.0):
         from bench_train import train_workload
         batch, na_t = train_workload(256, seed=4321)
         batch.to(dev)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
         model.train()
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-5)
 
@@ -315,7 +317,16 @@ def secondary_configs(model, dev, budget_s=80.0):
         for _ in range(3):
             info = step()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        from phoregen_amd import training as _tr
+        _tr.lib_timers = []                       # one more step with HIP events around the library GEMM calls (the input gradients)
+        step()
+        torch.cuda.synchronize()
+        lib_ms = [a.elapsed_time(b) for a, b in _tr.lib_timers]
+        _tr.lib_timers = None
         out['train_ms_per_step'] = {'value': dt / 3 * 1e3, 'unit': 'ms/step', 'steps': 3, 'warmup': 2, 'graphs': 256,
+                                    'library_ms': sum(lib_ms), 'library_calls': len(lib_ms),
+                                    'library_note': 'input-gradient GEMMs on rocBLAS / hipBLASLt through torch.mm (training.py _dgrad), part of `value`',
+                                    'peak_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
                                     'what': 'BASELINE.json configs[4]: compute_loss forward + backward + Adam on 256 synthetic ligand-pharmacophore '
                                             'pairs (n ~ N(25, 5) clamp [8, 60]); tools/bench_train.py is the full benchmark',
                                     'wall_s': dt, 'n_lig': int(na_t.sum()), 'e_bond': int((na_t * (na_t - 1)).sum()), 'last_loss': float(info['loss'])}

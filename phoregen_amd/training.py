@@ -74,7 +74,14 @@ def _dgrad(gY, W, gX):
     pass at about twice the rate of the tiled pg_gemm fallback (the streaming pg_gemm kernel covers K = 128 only; training
     step 195 -> 188 ms).  `PG_DGRAD_MM=0`: pg_gemm on W^T, as before."""
     if options.get('dgrad_mm'):
-        torch.mm(gY, W, out=gX)
+        if lib_timers is not None:      # measurement (tools/bench_train.py, bench.py): HIP events around the library call, on its stream
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            torch.mm(gY, W, out=gX)
+            ev[1].record()
+            lib_timers.append(ev)
+        else:
+            torch.mm(gY, W, out=gX)
     else:
         _gemm_raw(gY, W.t().contiguous(), gX)
 
@@ -498,6 +505,8 @@ class SegCoreFn(torch.autograd.Function):
 
 
 bwd_timers = None       # dict mode -> [(start, end) events] when a benchmark wants the adjoint launches timed
+lib_timers = None       # list of (start, end) events around every LIBRARY GEMM of the step (the input gradients, `_dgrad`): the one place
+                        # where the training path leaves the in-tree kernels -- benchmarks report it as `library_ms`
 
 
 def seg_core(cfg, Ydst, Ysrc, U, x, nrm=None, ew=None, Wf_k=None, Wf_v=None, bk=None, bv=None, W2xv_l=None, b2xv=None):

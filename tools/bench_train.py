@@ -83,13 +83,14 @@ def main(argv=None):
     # events around its launches during two more steps; executed FLOPs = its MFMA count per launch from the committed PMC pass
     # (profiles/train_adjoint_mfma.json: SQ_INSTS_MFMA x 2 048, every MFMA of the kernel is a 16x16x4) scaled by the triplet rows
     from phoregen_amd import training as _tr
-    _tr.bwd_timers = {}
+    _tr.bwd_timers, _tr.lib_timers = {}, []
     for _ in range(2):
         step()
     torch.cuda.synchronize()
     tri_ms = [e0.elapsed_time(e1) for e0, e1 in _tr.bwd_timers.get(4, [])]
     knn_ms = [e0.elapsed_time(e1) for e0, e1 in _tr.bwd_timers.get(0, [])]
-    _tr.bwd_timers = None
+    lib_ms = [e0.elapsed_time(e1) for e0, e1 in _tr.lib_timers]
+    _tr.bwd_timers = _tr.lib_timers = None
     roof = None
     try:
         rec = json.load(open(os.path.join(ROOT, 'profiles', 'train_adjoint_mfma.json')))
@@ -134,6 +135,10 @@ def main(argv=None):
                                                       'graphs': a.graphs, 'n_lig': int(na.sum()), 'e_bond': e_bond, 'e3': e3},
                       **({'ms_without_buckets': ms_plain, 'buckets': len(buckets.buckets), 'buckets_launched_from_hooks': hooked,
                           'note': 'value = with GradientBuckets on a 1-rank nccl group'} if ms_plain is not None else {}),
+                      'library_ms': sum(lib_ms) / 2, 'library_calls_per_step': len(lib_ms) // 2,
+                      'library_note': 'the input-gradient GEMMs of the adjoint pass (gX = gY W, K = 256 ... 1 920) run on the library GEMM through torch.mm '
+                                      '(rocBLAS / hipBLASLt; phoregen_amd/training.py _dgrad) -- the one place where the training path leaves the in-tree '
+                                      'kernels; HIP events around every call, mean of two steps',
                       'roofline': roof, 'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30, 'last_loss': info['loss']}))
 
 
