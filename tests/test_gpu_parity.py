@@ -622,7 +622,7 @@ FLIP_GAP_MULT = 2 * 5 * TOL      # x max |logit| of the step: a categorical draw
 KINK_EPS = 2e-5                  # [A] a bond this close to min_d / max_d of the atom_prox guidance sits ON the kink of its relu at fp32 precision
 
 
-@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid', 'g5_sample_full1000_n34'])
+@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid', 'g5_sample_full1000_n34', 'g5_sample_full1000_headline'])
 def test_sampler_free_running_1000_steps_matches_reference(name):
     """ALL 1000 reverse steps, free-running, against the reference's own `sample()` on the same seed (models/diffusion.py:391-525;
     fixture: oracle/make_golden.py g5_sample_full1000): the CPU generator is seeded like the reference run and the draws are taken in
@@ -675,7 +675,8 @@ def test_sampler_free_running_1000_steps_matches_reference(name):
     rmsd = torch.zeros(T + 1, B, device=DEV)
     kink = torch.full((T, B), 9.0, device=DEV)
     gap_n, gap_e = torch.zeros(T, N, device=DEV), torch.zeros(T, E, device=DEV)
-    ck = {int(i): k for k, i in enumerate(g['ck_steps'])}          # (`n34`: ligands of 34 / 21 atoms = 3 / 2 row tiles; no checkpoints stored)
+    ck = {int(i): k for k, i in enumerate(g['ck_steps'])}          # (`n34`: ligands of 34 / 21 atoms = 3 / 2 row tiles; `headline` (round 6): 38 / 40 / 43 / 52
+                                                                   #  atoms on a synthetic 107-node pharmacophore = the bench's shape; no checkpoints stored)
     events, seg_end_rmsd = [], []
     if 'gap_edge' in g.files:
         ref_gap_edge = lambda s_, r_: float(g['gap_edge'][s_, r_])

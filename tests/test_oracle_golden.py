@@ -175,7 +175,7 @@ def test_g5_sampler(name):
         assert np.array_equal(res['lig_info'][2].numpy(), g['lig_edge_index'])
 
 
-@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid', 'g5_sample_full1000_n34'])
+@pytest.mark.parametrize('name', ['g5_sample_full1000_a', 'g5_sample_full1000_guid', 'g5_sample_full1000_n34', 'g5_sample_full1000_headline'])
 def test_g5_full_length_fixture_windows(name):
     """The 1000-step fixtures of the reference's own `sample()` (oracle/make_golden.py g5_sample_full1000): the draws are re-created by
     seeding torch's CPU generator like the reference run (their float64 sums are in the fixture), the initial state must come out bit
@@ -214,7 +214,8 @@ def test_g5_full_length_fixture_windows(name):
     ck = list(g['ck_steps'])
     worst = 0.0
     with torch.no_grad():
-        # (`n34` -- ligands of 34 / 21 atoms -- stores no checkpoints: its window is the first 6 steps from the initial state)
+        # (`n34` -- ligands of 34 / 21 atoms -- stores no checkpoints: its window is the first 6 steps from the initial state; `headline` -- 38 / 40 /
+        #  43 / 52 atoms on a 107-node pharmacophore, round 6 -- the first 3: ~10 s of CPU per step)
         for after in ((49, 499, 949) if ck else (-1,)):
             if after < 0:
                 pos = pos0
@@ -226,7 +227,7 @@ def test_g5_full_length_fixture_windows(name):
                 pos, log_node, log_edge = t(g['ck_pos'][k]), t(g['ck_log_node'][k]), t(g['ck_log_edge'][k])
                 h_node = F.one_hot(t(g['traj_node'][after + 1]).long(), 12).float()
                 h_edge = F.one_hot(t(g['traj_edge'][after + 1]).long(), 6).float()
-            for i in range(after + 1, after + (11 if ck else 7)):
+            for i in range(after + 1, after + (11 if ck else (4 if 'headline' in name else 7))):
                 tt = torch.full((B,), T - 1 - i)
                 v, x0, bond, _ = o.forward(h_node, pos, bn, h_edge, ei, be, tt, hp, pp, pn, bp)
                 un, ue, eps = draws[i]

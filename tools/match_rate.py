@@ -16,6 +16,9 @@ GPU box with the snapshot):
                                                              their slice of the draws (bit-identical to `ref`, checked) + margins
   python tools/match_rate.py hip S B          (GPU box)   -> one JSON line + gpurun_out/match_rate_hip_S_B.npz (margins of its departures)
   python tools/match_rate.py report S B       (any host)  -> one JSON line: hip-vs-oracle and control side by side, every departure labelled
+  python tools/match_rate.py hipperm S B [headline]  (GPU box) -> one JSON line: the HIP sampler against ITSELF with every ligand's atoms permuted (same
+                                                             draws per atom / bond): the same control on the device, affordable at the HEADLINE shape
+                                                             (`headline`: the first B graphs of bench.ligphore_workload(128): n ~ 40, p ~ 107 per graph)
   python tools/match_rate.py S B              ref + hip in one process (small S x B)
 """
 import json, os, sys, time
@@ -25,7 +28,9 @@ import numpy as np
 import torch
 
 args = sys.argv[1:]
-phase = args.pop(0) if args and args[0] in ('ref', 'hip', 'perm', 'sub', 'report') else 'both'
+phase = args.pop(0) if args and args[0] in ('ref', 'hip', 'perm', 'sub', 'report', 'hipperm') else 'both'
+HEADLINE = 'headline' in args
+args = [a for a in args if a != 'headline']
 S = int(args[0]) if len(args) > 0 else 40
 B = int(args[1]) if len(args) > 1 else 12
 SUBSET = [int(v) for v in args[2].split(',')] if len(args) > 2 else []
@@ -40,6 +45,11 @@ t = lambda a: torch.as_tensor(np.asarray(a))
 x, pos, nrm, center = t(g['x']), t(g['pos']), t(g['norm']), t(g['center'])
 gen = torch.Generator().manual_seed(4)
 na = torch.randint(12, 28, (B,), generator=gen)
+WORK = None
+if HEADLINE:                                  # the bench's workload (BASELINE configs[2]): its first B graphs, each with its own pharmacophore
+    from bench import ligphore_workload, subset_workload
+    WORK = subset_workload(ligphore_workload(128), torch.arange(B))
+    na = WORK['num_atoms']
 N, E = int(na.sum()), int((na * (na - 1)).sum())
 MARKS = sorted({0, 1, 2, 5, 10, 20, 30, 50, 100, 200, 300, 400, 500, 600, 700, 800, 900, 950, 990, S} & set(range(S + 1)))
 
@@ -304,6 +314,73 @@ def run_hip(ref):
             'randn_checksum_max_dev_between_hosts': randn_dev}
 
 
+def run_hipperm():
+    """HIP vs HIP with the atoms of every ligand permuted (the control of `perm`, on the device): both runs take the same CPU-generator draws,
+    row-permuted for the second one; its trajectory is put back into the caller's order and compared like `hip` vs `ref`."""
+    from phoregen_amd.config import default_model_config
+    from phoregen_amd.models.diffusion import PhoreDiff
+    from phoregen_amd.weights import init_deterministic_
+    import torch.nn.functional as F
+    DEV = 'cuda'
+    model = init_deterministic_(PhoreDiff(default_model_config(), 'zinc_300'), 0).eval().to(DEV)
+    perm_atom, perm_edge = graph_permutations()
+    if WORK is not None:
+        hp, pp, pn, bp = WORK['h_phore'], WORK['pos_phore'], WORK['phore_norm'], WORK['batch_phore']
+        centers = torch.zeros(B, 3)
+    else:
+        p = x.shape[0]
+        hp, pp, pn, bp = x.repeat(B, 1), pos.repeat(B, 1), nrm.repeat(B, 1), torch.repeat_interleave(torch.arange(B), p)
+        centers = center.unsqueeze(0).expand(B, 3)
+    def margins(u, logp):
+        top = (-torch.log(-torch.log(u + 1e-30) + 1e-30) + logp).topk(2, dim=-1).values
+        return top[:, 0] - top[:, 1]
+
+    def run(pa, pe):
+        """One HIP run whose row r holds the caller's atom pa[r] / bond pe[r] (None: the caller's order); everything returned in the caller's order."""
+        st = model.begin_sampling(hp, pp, pn, bp, na, centers, rng='cpu', seed=0)           # (its own init draws are overwritten below)
+        w = st.eng.ws
+        torch.manual_seed(SEED)                        # both runs take the same stream, in the reference's order (SURVEY.md Appendix B)
+        pos0 = torch.randn(N, 3)
+        un0, ue0 = torch.rand(N, 12, dtype=torch.float64), torch.rand(E, 6, dtype=torch.float64)
+        ia = torch.arange(N) if pa is None else pa
+        ie = torch.arange(E) if pe is None else pe
+        lp_n = torch.log(torch.from_numpy(model.node_transition.init_prob) + model.node_transition.eps).clamp_min(-32.)
+        lp_e = torch.log(torch.from_numpy(model.edge_transition.init_prob) + model.edge_transition.eps).clamp_min(-32.)
+        gum = lambda u: -torch.log(-torch.log(u + 1e-30) + 1e-30)
+        h_node = F.one_hot((gum(un0[ia]) + lp_n.unsqueeze(0)).argmax(-1), 12).float().to(DEV)
+        h_edge = F.one_hot((gum(ue0[ie]) + lp_e.unsqueeze(0)).argmax(-1), 6).float().to(DEV)
+        p0 = (pos0[ia]).to(DEV) - st.center_rows
+        w.in_h_node.copy_(h_node), w.in_pos.copy_(p0), w.in_h_edge.copy_(h_edge)
+        st.log_node[0].copy_(torch.log(h_node.clamp(min=1e-30))), st.log_edge[0].copy_(torch.log(h_edge.clamp(min=1e-30)))
+        st.node_traj[0], st.pos_traj[0], st.edge_traj[0] = h_node, p0, h_edge
+        gn, ge, sc = torch.zeros(S, N, device=DEV), torch.zeros(S, E, device=DEV), torch.zeros(S, 2, device=DEV)
+        for i in range(S):
+            un, ue, eps = torch.rand(N, 12), torch.rand(E, 6), torch.randn(N, 3)
+            un, ue = un[ia].to(DEV), ue[ie].to(DEV)
+            model.reverse_step(st, i, 999 - i, None, draws=(un, ue, eps[ia]))
+            gn[i], ge[i] = margins(un, st.log_node[st.cur]), margins(ue, st.log_edge[st.cur])
+            sc[i, 0], sc[i, 1] = w.out_v.abs().max(), w.out_bond.abs().max()
+        torch.cuda.synchronize()
+
+        def back(v, perm):
+            if perm is None:
+                return v
+            out = torch.empty_like(v)
+            out[:, perm.to(v.device)] = v
+            return out
+        return dict(node=back(st.node_traj[:S + 1].argmax(-1), pa).cpu().numpy(), edge=back(st.edge_traj[:S + 1].argmax(-1), pe).cpu().numpy(),
+                    pos=back(st.pos_traj[:S + 1], pa).cpu().numpy(), gap_node=back(gn, pa).cpu().numpy(), gap_edge=back(ge, pe).cpu().numpy(), scale=sc.cpu().numpy())
+    t0 = time.time()
+    a = run(None, None)
+    b = run(perm_atom, perm_edge)
+    secs = time.time() - t0
+    cmp_ = compare(b, a)
+    label(cmp_['departures'], margins_from(b), margins_from(a), 'hip_permuted', 'hip')
+    return dict(what='the HIP sampler against itself with the atoms (hence bond rows and triplet order) of every ligand permuted, same draws per atom / bond',
+                workload='headline shape: first %d graphs of bench.ligphore_workload(128)' % B if HEADLINE else 'P03211 pharmacophore x %d ligands of 12-27 atoms' % B,
+                graphs=B, steps=S, atoms=N, bond_rows=E, both_runs_s=round(secs, 1), **cmp_)
+
+
 def run_report():
     ref = np.load(CACHE('ref'))
     out = {'graphs': B, 'steps': S, 'atoms': N, 'bond_rows': E, 'tie_rule': f'every flipped row: top-2 margin <= {FLIP_GAP_MULT:g} x max |logit| of the step in both runs'}
@@ -340,5 +417,7 @@ elif phase == 'hip':
     print(json.dumps(run_hip(np.load(CACHE('ref')))))
 elif phase == 'report':
     print(json.dumps(run_report()))
+elif phase == 'hipperm':
+    print(json.dumps(run_hipperm()))
 else:
     print(json.dumps(run_hip(run_ref())))
