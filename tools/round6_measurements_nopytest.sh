@@ -1,6 +1,5 @@
 # Round 6: the whole measurement job at HEAD (suite, bench lines, kernel traces, PMC of the dominant kernel, step traffic / MFMA, timelines, scaling prediction, parity ratios).
 rm -f gpurun_out/parity_ratios.jsonl gpurun_out/free_running_1000.jsonl
-python -m pytest tests -m gpu -q > gpurun_out/r06_pytest_full.log 2>&1; grep -E "passed|failed" gpurun_out/r06_pytest_full.log | tail -2
 bash tools/measure_round.sh r06 > gpurun_out/r06_measure.log 2>&1; tail -6 gpurun_out/r06_measure.log | cut -c1-300
 bash tools/profile_round.sh r06 triplet2 > gpurun_out/r06_profile.log 2>&1
 python3 tools/save_profile.py stats gpurun_out/r06_prof_streams gpurun_out/r06_bench_kernel_stats.md "r06: kernel trace of the default bench (four lanes)" "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --steps 20 --repeats 1" 25
