@@ -153,6 +153,10 @@ class Engine:
         w.s_all, w.s_l = _f(p.n_phore, device=d), _f(p.n_phore, device=d)
         w.count_l, w.count_u = _f(p.n_graphs, device=d), _f(p.n_graphs, device=d)
         w.h = [_f(n, 128, device=d), _f(n, 128, device=d)]
+        # the embedded features = layer 0's input, in a buffer of their own: the layers ping-pong h[1] / h[0] behind it, so the NEXT step's embedding
+        # (`prog_ahead`, lane 2 of the pipelined loop) never overwrites what the current step's last layer still reads (round 5's advisor finding:
+        # with the embedding in h[0] the position phase's first-layer products on lane 1 raced it; no order point is needed this way)
+        w.h_in = _f(n, 128, device=d)
         w.x = [_f(n, 3, device=d), _f(n, 3, device=d)]
         w.hb = [_f(E, 128, device=d), _f(E, 128, device=d)]
         w.nbr = torch.zeros(n, k, dtype=torch.int32, device=d)
@@ -393,7 +397,7 @@ class Engine:
         w, p, pk = self.ws, self.plan, self.pack
         self._call(prog, self.lib.pg_embed_ctx, p.topo_ref, w.in_h_node.data_ptr(), w.in_pos.data_ptr(), in_t.data_ptr(),
                    pk.W_node_emb.data_ptr(), pk.t_off.data_ptr(), pk.t_coeff.data_ptr(), w.hp_emb.data_ptr(),
-                   w.pos_phore.data_ptr(), p.phore2ctx.data_ptr(), w.h[0].data_ptr() if features else None,
+                   w.pos_phore.data_ptr(), p.phore2ctx.data_ptr(), w.h_in.data_ptr() if features else None,
                    w.x[0].data_ptr() if coords else None)
 
     def _build_forward_program(self, step_ahead=False):
@@ -448,7 +452,7 @@ class Engine:
         hb_done = self._record(prog, 3)
         self._lane = 2
         self._embed_ctx(prog, w.in_t_next, coords=False)
-        self._first_layer_gemm(prog, L0, w.h[0], w.Y1)
+        self._first_layer_gemm(prog, L0, w.h_in, w.Y1)
         y1_done = self._record(prog, 2)
         self._query_gemm(prog, L0.NE, w.Y1, 0, both, 3)
         self._wait(prog, 2, hb_done)
@@ -547,7 +551,7 @@ class Engine:
 
         for li, L in enumerate(pk.layers):
             nxt = 1 - cur
-            hc, xc, hbc, hn, xn, hbn = h[cur], x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
+            hc, xc, hbc, hn, xn, hbn = (w.h_in if li == 0 else h[cur]), x[cur], hb[cur], h[nxt], x[nxt], hb[nxt]
             # v2 writes the next layer's first-layer blocks while this layer's are still being read: two buffers, alternating (the
             # other schedules overwrite in place, behind the last reader)
             Y1c, Y1n = (w.Y1, w.Y1) if not v2 else ((w.Y1, w.Y1b) if li % 2 == 0 else (w.Y1b, w.Y1))
@@ -682,11 +686,6 @@ class Engine:
             # knn-pos k/v source halves for every node (cols 256:512); target halves, queries and the bond-pos blocks
             # only for ligand atoms
             self._gemm(prog, hn, 128, L.W_node2, w.Y2, n, 1280, bias=L.b_node2)
-            if step_ahead and self.head_early and last and v2:
-                # lane 1's last read of h' (= h[0] in the last layer): `prog_ahead` embeds the NEXT step's features into h[0] on lane 2, which in
-                # this schedule is released by `hn_done` alone -- it must not pass these products (advisor, round 5: a write-after-read hazard
-                # that only timing had kept closed)
-                y2_done = self._record(prog, 1)
             if v2:
                 # the bond position update's query right behind Y2 on the node chain's lane (Y2 is out well before the triplet kernel ends):
                 # the one event lane 0 waits for below then covers it, instead of a second cross-lane hop in front of the attention
@@ -714,10 +713,10 @@ class Engine:
                 self._wait(prog, 2, hn_done)
                 self._lane = 2
                 heads[1](hn)
-                if v2:
-                    self._wait(prog, 2, y2_done)       # Y2's reads of h' (lane 1) before anything later on this lane overwrites h[0]
-                else:
+                if not v2:
                     self._fork(prog, (2,))             # Y2: lane 0 has waited for lane 1 above
+                # (v2: lane 2 goes on behind `hn_done` alone -- what follows on it, `prog_ahead`, embeds the next step's features into `h_in`,
+                #  which nothing of this step reads any more, and never touches h[0])
             else:
                 self._fork(prog, (2, 3) if (ahead and li + 1 < n_layers) else (qlane,))
             self._lane = qlane
@@ -986,7 +985,7 @@ def denoiser_forward_standalone(module, h, x, bond_index, h_bond, mask_ligand, b
     sd = {'denoiser.' + k: v for k, v in module.state_dict().items()}
     eng = Engine(_DenoiserOnlyPack(sd, module.num_layers), plan, knn_k=module.k, full=False)
     w = eng.ws
-    w.h[0].copy_(h)
+    w.h_in.copy_(h)
     w.x[0].copy_(x)
     w.hb[0].copy_(h_bond if plan.edge_identity else h_bond.index_select(0, plan.edge_ref_long))   # internal bond order
     w.phore_norm.copy_(phore_norm)

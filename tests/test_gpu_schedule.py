@@ -34,10 +34,11 @@ def test_launch_lists_are_ordered(model, graphs, guided):
 
 
 def test_checker_notices_a_missing_order_point(model):
-    """Round 5's advisor finding, replayed: in the pipelined v2 schedule lane 2 (node head -> node posterior -> `prog_ahead`, which embeds the
-    NEXT step's features into h[0]) must wait for lane 1's last reads of h' = h[0] (the position phase's first-layer products).  With that one
-    wait removed the check reports the write-after-read pair on ws.h[0]; with every wait of `prog_step` removed in turn, some hazard appears for
-    most of them (the list carries few redundant waits)."""
+    """The check is sensitive to the order points it verifies: with any single wait of `prog_step` removed a hazard appears for most of them (the
+    list carries few redundant waits) -- among them the class round 5's advisor found by reading the code (a side lane released too early
+    overwriting / reading h' of the last layer): lane 2's wait for `hn_done` in front of the node head, without which the head reads h[0] while
+    `lin_node` on lane 1 is still writing it.  (Round 5's own hazard -- the next step's embedding into h[0] racing the position phase's reads --
+    is gone by construction since round 6: the embedded features live in `ws.h_in`.)"""
     from bench import ligphore_workload
     import check_schedule as cs
     work = ligphore_workload(16)
@@ -50,10 +51,9 @@ def test_checker_notices_a_missing_order_point(model):
     for k0, pt0, ln0 in waits:
         _, pipe, _ = cs.check_engine(model, work, drop_step=lambda k, what, pt, ln: what == 'wait' and (k, pt, ln) == (k0, pt0, ln0))
         n_sensitive += bool(pipe)
-        if ln0 == 2 and any(h[6] == 'ws.h[0]' and 'pg_gemm' in h[0] and 'pg_embed_ctx' in h[3] for h in pipe):
-            found_h0 = True
+        found_h0 = found_h0 or (ln0 == 2 and any(h[6] == 'ws.h[0]' and h[1] == 1 and h[4] == 2 for h in pipe))
     model._engine = None
-    assert found_h0, 'the dropped lane-2 wait behind the node head must surface as a hazard on ws.h[0]'
+    assert found_h0, 'a lane-2 wait on lane 1 (hn_done) must surface as a hazard on ws.h[0] when removed'
     assert n_sensitive >= len(waits) // 2, (n_sensitive, len(waits))
 
 
