@@ -622,12 +622,15 @@ FLIP_GAP_MULT = 2 * 5 * TOL      # x max |logit| of the step: a categorical draw
 # The fixture at the HEADLINE shape (4 ligands of 38 ... 52 atoms on a 107-node pharmacophore, round 6).  At this size the reverse dynamics of the
 # (randomly initialised) network amplify fp32 rounding faster than fp32 resolves it late in the run: the CONTROL -- the HIP sampler against ITSELF
 # with the atoms of every ligand permuted, same draws (tools/match_rate.py hipperm; profiles/r06_control_hip_permuted_1000_128_headline.json) --
-# keeps 128 / 128 graphs of the bench's batch bit-identical through step 676 and within 1e-4 A through step ~ 700, then loses 38 of them by step
-# 1000 (half through exact ties, half through drift first), and the fp32 CPU oracle against its own permuted run does the same on 32 smaller
-# graphs (profiles/r06_free_running_match_rate.json).  No fp32 implementation -- the reference on another BLAS included -- reproduces such a
-# trajectory to the end.  So this fixture is held STRICTLY (types bit-exact, RMSD <= 1e-4, no departure at all) through its first
-# AT_SCALE_STRICT steps, and over the whole run at least AT_SCALE_ON_TRAJECTORY of all graph-steps must lie on the reference's trajectory.
-AT_SCALE_STRICT = 500
+# keeps 128 / 128 graphs of the bench's batch bit-identical through step 676 and loses 38 of them by step 1000 (half through exact ties, half
+# through coordinate drift first), and the fp32 CPU oracle against its own permuted run does the same on 32 smaller graphs (final-frame RMSD up to
+# 3.6e-3 on graphs whose types never differ; profiles/r06_free_running_match_rate.json).  No fp32 implementation -- the reference on another BLAS
+# or thread count included -- reproduces such a trajectory to the end.  So this fixture is held to the STRICT rule of the small fixtures (types
+# bit-exact, RMSD <= 1e-4; a graph may leave only through an evidenced tie) through its first AT_SCALE_STRICT steps; after that a graph may also
+# leave by drift, and at least AT_SCALE_ON_TRAJECTORY of all graph-steps must lie on the reference's trajectory.  (Measured at HEAD: 4 / 4 graphs
+# bit-identical and within 8.2e-5 A through step 738; then one drifts past 1e-4, two leave through evidenced ties at steps 826 / 906, one stays
+# for all 1000 steps, 3.0e-5 A at the end; 86.8 % of the graph-steps on the trajectory.)
+AT_SCALE_STRICT = 700
 AT_SCALE_ON_TRAJECTORY = 0.75
 KINK_EPS = 2e-5                  # [A] a bond this close to min_d / max_d of the atom_prox guidance sits ON the kink of its relu at fp32 precision
 
@@ -779,7 +782,7 @@ def test_sampler_free_running_1000_steps_matches_reference(name):
     print(json.dumps(rec))
     if at_scale:
         # the headline shape: strict through AT_SCALE_STRICT steps, then a graph may leave through the dynamics' own conditioning (see the docstring)
-        assert all(ev['diverged_at'] >= AT_SCALE_STRICT for ev in events), rec
+        assert all(ev['diverged_at'] >= AT_SCALE_STRICT or ev['explained_by'] == 'categorical tie' for ev in events), rec
         assert int(valid[1:].sum()) >= AT_SCALE_ON_TRAJECTORY * T * B, rec
     else:
         for ev in events:                                 # every departure is one of the reference algorithm's own discontinuities

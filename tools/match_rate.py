@@ -162,11 +162,21 @@ def run_sub(graphs):
     rng, obs = SummingRng(rows_n, rows_e), Margins(len(rows_n), len(rows_e))
     res, secs = oracle_run(na[sel], rng, obs)
     assert np.allclose(np.array(rng.sums), ref['sums'], rtol=1e-12, atol=1e-9), 'generator stream differs from the host the `ref` phase ran on'   # (the float64 checksum's own summation order depends on the thread count)
-    same = dict(node=bool(np.array_equal(res['traj'][0].argmax(-1).numpy(), ref['node'][:, rows_n.numpy()])),
-                edge=bool(np.array_equal(res['traj'][2].argmax(-1).numpy(), ref['edge'][:, rows_e.numpy()])),
-                pos_max_abs=float(np.abs(res['traj'][1].numpy() - ref['pos'][:, rows_n.numpy()]).max()))
+    tn, te, tp = res['traj'][0].argmax(-1).numpy(), res['traj'][2].argmax(-1).numpy(), res['traj'][1].numpy()
+    same = dict(node=bool(np.array_equal(tn, ref['node'][:, rows_n.numpy()])), edge=bool(np.array_equal(te, ref['edge'][:, rows_e.numpy()])),
+                pos_max_abs=float(np.abs(tp - ref['pos'][:, rows_n.numpy()]).max()))
+    # per graph: the first frame whose types or coordinates are not the full run's bit for bit (S + 1: none) -- a graph alone is NOT always the
+    # graph inside its batch: the library GEMM blocks its rows by the batch's size, and the late dynamics amplify that last-bit difference too
+    first_diff = {}
+    for gi in sel.tolist():
+        mn, me = (bn[rows_n] == gi).numpy(), (be[rows_e] == gi).numpy()
+        bad = (tn[:, mn] != ref['node'][:, rows_n.numpy()][:, mn]).any(1) | (te[:, me] != ref['edge'][:, rows_e.numpy()][:, me]).any(1) | \
+              (tp[:, mn] != ref['pos'][:, rows_n.numpy()][:, mn]).any((1, 2))
+        first_diff[gi] = int(np.argmax(bad)) if bad.any() else S + 1
+    same['first_differing_frame_by_graph'] = first_diff
     out = dict(graphs=sel.numpy(), rows_node=rows_n.numpy(), rows_edge=rows_e.numpy(), gap_node=obs.gap['node'].numpy(), gap_edge=obs.gap['edge'].numpy(),
-               scale=obs.scale.numpy(), identical_to_ref=np.array([same['node'], same['edge']]), pos_max_abs=np.array(same['pos_max_abs']), oracle_s=np.array(secs))
+               scale=obs.scale.numpy(), identical_to_ref=np.array([same['node'], same['edge']]), pos_max_abs=np.array(same['pos_max_abs']), oracle_s=np.array(secs),
+               first_diff=np.array([first_diff[gi] for gi in sel.tolist()]))
     if os.path.exists(CACHE('sub')):         # keep the graphs of earlier calls
         old = dict(np.load(CACHE('sub')))
         keep = ~np.isin(old['graphs'], out['graphs'])
@@ -175,7 +185,8 @@ def run_sub(graphs):
             out.update(graphs=np.concatenate([old['graphs'][keep], out['graphs']]), rows_node=np.concatenate([old['rows_node'][kn], out['rows_node']]),
                        rows_edge=np.concatenate([old['rows_edge'][ke], out['rows_edge']]), gap_node=np.concatenate([old['gap_node'][:, kn], out['gap_node']], 1),
                        gap_edge=np.concatenate([old['gap_edge'][:, ke], out['gap_edge']], 1), scale=np.maximum(old['scale'], out['scale']),
-                       identical_to_ref=old['identical_to_ref'] & out['identical_to_ref'], pos_max_abs=np.maximum(old['pos_max_abs'], out['pos_max_abs']))
+                       identical_to_ref=old['identical_to_ref'] & out['identical_to_ref'], pos_max_abs=np.maximum(old['pos_max_abs'], out['pos_max_abs']),
+                       first_diff=np.concatenate([old['first_diff'][keep], out['first_diff']]))
     np.savez_compressed(CACHE('sub'), **out)
     return same, secs
 
@@ -240,16 +251,22 @@ def margins_from(npz, rows_key=None):
     """Accessor (kind, step, caller's row) -> margin, over a cache that holds all rows (`perm`) or the rows of some graphs (`sub`, hip departures)."""
     if npz is None:
         return lambda kind, s, r: None
-    idx = {}
+    idx, valid_before = {}, {}
     if rows_key:
         idx = {'node': {int(r): k for k, r in enumerate(npz['rows_node'])}, 'edge': {int(r): k for k, r in enumerate(npz['rows_edge'])}}
+        if 'first_diff' in getattr(npz, 'files', npz):           # (`sub`: a margin counts only while the graph alone still IS the graph of the full run)
+            bn, ei, be = topology()
+            fd = {int(g_): int(f_) for g_, f_ in zip(npz['graphs'], npz['first_diff'])}
+            valid_before = {'node': lambda r: fd[int(bn[r])], 'edge': lambda r: fd[int(be[r])]}
 
     def f(kind, s, r):
         if kind == 'scale':
             return float(npz['scale'][s].max())
         if rows_key:
             k = idx[kind].get(r)
-            return None if k is None else float(npz['gap_' + kind][s, k])
+            if k is None or (valid_before and s + 1 >= valid_before[kind](r)):
+                return None
+            return float(npz['gap_' + kind][s, k])
         return float(npz['gap_' + kind][s, r])
     return f
 
@@ -386,7 +403,8 @@ def run_report():
     out = {'graphs': B, 'steps': S, 'atoms': N, 'bond_rows': E, 'tie_rule': f'every flipped row: top-2 margin <= {FLIP_GAP_MULT:g} x max |logit| of the step in both runs'}
     sub = np.load(CACHE('sub')) if os.path.exists(CACHE('sub')) else None
     if sub is not None:
-        out['oracle_subset_rerun'] = dict(graphs=sub['graphs'].tolist(), types_identical_to_full_run=bool(sub['identical_to_ref'].all()), pos_max_abs_vs_full_run=float(sub['pos_max_abs']))
+        out['oracle_subset_rerun'] = dict(graphs=sub['graphs'].tolist(), first_frame_not_bit_identical_to_the_full_run=dict(zip(map(int, sub['graphs']), map(int, sub['first_diff']))),
+                                          note=f'{S + 1} = identical through the whole run; margins of a graph are used only before that frame')
     if os.path.exists(HIP_OUT):
         hip = np.load(HIP_OUT)
         cmp_ = compare(hip, ref)
