@@ -117,7 +117,7 @@ def test_gather_world_size_8_gloo_job_scale():
     payload = res[0][6]
     assert payload > 400e6                                         # (12 800 graphs ~ 0.5 GB of fp32 rows)
     assert res[0][5] <= 4.0 * payload + 1.5e9, (res[0][5], payload)  # gathered buffers + result + one row index (+ the interpreter and torch)
-    assert all(r[5] <= 1.5 * payload / 8 * 4 + 1.5e9 for r in res[1:])
+    assert all(r[5] <= 0.5 * payload + 2.5e9 for r in res[1:]), [r[5] for r in res]       # (the other ranks hold their own share + the interpreter; the job-size run records 1.7 GB each)
 
 
 def test_partition_is_balanced_and_complete():
