@@ -243,7 +243,9 @@ def label(departures, margins_a, margins_b, name_a, name_b):
         d.update(flips=flips, tie_bound=bound)
         known = bound is not None and all(f[f'gap_{name_a}'] is not None and f[f'gap_{name_b}'] is not None for f in flips)
         tie = known and all(f[f'gap_{name_a}'] <= bound and f[f'gap_{name_b}'] <= bound for f in flips)
-        d['label'] = ('tie' if tie and d['rmsd_frame_before'] <= 1e-4 else 'tie, graph already > 1e-4 off' if tie else 'NOT A TIE') if known else 'margin not recorded'
+        one_sided = bound is not None and any(v is not None and v > bound for f in flips for k_, v in f.items() if k_.startswith('gap_'))
+        d['label'] = ('tie' if tie and d['rmsd_frame_before'] <= 1e-4 else 'tie, graph already > 1e-4 off' if tie else 'NOT A TIE') if known else \
+            ('NOT A TIE (the one recorded margin is above the bound)' if one_sided else 'margin not recorded')
     return departures
 
 
