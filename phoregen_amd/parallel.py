@@ -26,6 +26,46 @@ def graph_cost(num_atoms, n_phore=None):
     return COST_US['tile'] * tiles * n * (n - 1) + COST_US['bond'] * n * (n - 1) + COST_US['node'] * ctx + COST_US['graph']
 
 
+def _level(parts, cl, caps, ok, rounds=256):
+    """Level a partition in place: moves and swaps between the fullest rank (load / capacity) and any other, emptiest partner first, while that
+    lowers the larger of the two; `ok(graph, destination rank)` vetoes a placement."""
+    world_size = len(parts)
+    tot = [sum(cl[g] for g in parts[i]) for i in range(world_size)]
+    rel = lambda i: tot[i] / caps[i]
+    for _ in range(rounds):
+        hi = max(range(world_size), key=rel)
+        applied = False
+        for lo in sorted((i for i in range(world_size) if i != hi), key=rel):      # emptiest partner first
+            pair_max = max(rel(hi), rel(lo))
+            best = None
+            for g in parts[hi]:                            # a move (h = None) or a swap g <-> h
+                for h in [None] + parts[lo]:
+                    if not ok(g, lo) or (h is not None and not ok(h, hi)):
+                        continue
+                    c = cl[g] - (cl[h] if h is not None else 0.0)
+                    if c <= 0:
+                        continue
+                    new_max = max(rel(hi) - c / caps[hi], rel(lo) + c / caps[lo])
+                    if new_max < pair_max - 1e-9 and (best is None or new_max < best[0]):
+                        best = (new_max, g, h)
+            if best is None:
+                continue
+            parts[hi].remove(best[1])
+            parts[lo].append(best[1])
+            tot[hi] -= cl[best[1]]
+            tot[lo] += cl[best[1]]
+            if best[2] is not None:
+                parts[lo].remove(best[2])
+                parts[hi].append(best[2])
+                tot[lo] -= cl[best[2]]
+                tot[hi] += cl[best[2]]
+            applied = True
+            break
+        if not applied:
+            break
+    return parts
+
+
 def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.0, big_discount=None):
     """Greedy (longest-processing-time) balanced partition of independent graphs over the ranks by `graph_cost`: the triplet
     term ~ n^3 dominates a large graph, but at the 16 graphs a rank gets of the headline batch 45 % of a step scales with n^2 and
@@ -71,43 +111,7 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
         parts[r].append(g)
         load[r] += float(cost[g])
     if by_size and world_size > 1 and len(num_atoms) <= 2048:      # (a large job is level to a fraction of a per cent already)
-        # level what first-fit left: moves and swaps between the fullest rank (relative to its capacity) and any other, emptiest partner first,
-        # while that lowers the larger of the two; a 50+-atom ligand never moves to a rank that has none
-        cl = cost.tolist()
-        tot = [sum(cl[g] for g in parts[i]) for i in range(world_size)]
-        rel = lambda i: tot[i] / caps[i]
-        ok = lambda g, dst: not (big[g] and dst >= max(n_big_bins, 1))
-        for _ in range(256):
-            hi = max(range(world_size), key=rel)
-            applied = False
-            for lo in sorted((i for i in range(world_size) if i != hi), key=rel):      # emptiest partner first
-                pair_max = max(rel(hi), rel(lo))
-                best = None
-                for g in parts[hi]:                            # a move (h = None) or a swap g <-> h
-                    for h in [None] + parts[lo]:
-                        if not ok(g, lo) or (h is not None and not ok(h, hi)):
-                            continue
-                        c = cl[g] - (cl[h] if h is not None else 0.0)
-                        if c <= 0:
-                            continue
-                        new_max = max(rel(hi) - c / caps[hi], rel(lo) + c / caps[lo])
-                        if new_max < pair_max - 1e-9 and (best is None or new_max < best[0]):
-                            best = (new_max, g, h)
-                if best is None:
-                    continue
-                parts[hi].remove(best[1])
-                parts[lo].append(best[1])
-                tot[hi] -= cl[best[1]]
-                tot[lo] += cl[best[1]]
-                if best[2] is not None:
-                    parts[lo].remove(best[2])
-                    parts[hi].append(best[2])
-                    tot[lo] -= cl[best[2]]
-                    tot[hi] += cl[best[2]]
-                applied = True
-                break
-            if not applied:
-                break
+        _level(parts, cost.tolist(), caps, lambda g, dst: not (big[g] and dst >= max(n_big_bins, 1)))
     return [torch.tensor(sorted(p), dtype=torch.long) for p in parts]
 
 
