@@ -879,7 +879,10 @@ class Engine:
         t, self._tune = self._tune, None
         if t is None:
             return
-        key = (self.plan.n_bond, self.plan.n_ctx, self.plan.n_graphs, self.plan.topo.max_nlig)
+        # remembered per batch SHAPE, coarsely (bond rows in steps of 2 048, context nodes in steps of 512, graphs, row tiles of the largest ligand): the
+        # repeated `sample()` calls of a sample_all.py-style loop (same batch size, atom counts drawn anew: sample_all.py:79-94) calibrate once, not
+        # 21 extra steps per call
+        key = (self.plan.n_bond // 2048, self.plan.n_ctx // 512, self.plan.n_graphs, (max(self.plan.topo.max_nlig, 2) + 14) // 16)
         if key in _TRI_GRID_CACHE:
             self.tuned_tri_grid, self.tuned_tri_grid_ms = _TRI_GRID_CACHE[key]
             self._set_tri_grid(self.tuned_tri_grid)
