@@ -1058,9 +1058,9 @@ def test_full_size_e3_equivariance(model):
 
 
 def test_online_grid_tuning_does_not_change_the_trajectory(model):
-    """Small batches time the neighbouring persistent-grid sizes of the triplet kernel during their first sampler steps and keep the fastest
-    (Engine._tune_*): the queue hands out the same segments whatever the grid, so 30 steps with the tuning phase inside equal 30 steps
-    without it bit for bit, and the phase ends with one of the candidates selected."""
+    """Small batches time the neighbouring persistent-grid sizes of the triplet kernel on real sampler steps inside `begin_sampling` and keep
+    the fastest (Engine.calibrate_tri_grid; the state is put back afterwards): the queue hands out the same segments whatever the grid and the
+    device noise is counter-based, so 30 steps behind the calibration equal 30 steps without it bit for bit, and one of the candidates is selected."""
     from bench import ligphore_workload
     from phoregen_amd import options
     w = ligphore_workload(10, seed=3)
