@@ -262,7 +262,7 @@ typedef struct {
   int pos_tiled;
   /* PG_SEG_TRIPLET with tri_iters, optional: the largest ligand (atoms) among the queue's entries when that is smaller than
    * PgTopo.max_nlig.  The staged kernel is instantiated for the row tiles of the largest ligand it may meet, and the 4-tile
-   * instance costs EVERY segment ~4 % (44 instead of 31 spilled registers): a batch with a few 50+-atom ligands runs them as a
+   * instance costs EVERY segment ~4 % (44 instead of 31 spilled registers): a batch with a few 51+-atom ligands (a segment visits n - 2 rows) runs them as a
    * second launch with its own queue and the rest on the 3-tile instance.  0 = PgTopo.max_nlig. */
   int tri_max_nlig;
 } PgSegAttn;

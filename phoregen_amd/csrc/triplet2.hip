@@ -177,7 +177,10 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
     // 12-wave rounds so that the queue can level the workgroups)
     const int s_begin = __builtin_amdgcn_readfirstlane(d.w & 0xffff);
     const int n_seg = __builtin_amdgcn_readfirstlane((d.w >> 16) ? (d.w >> 16) : A * nm1);
-    const int n_tiles = (nm1 + 15) >> 4;
+    // a segment j->i visits the nm1 - 1 rows k != j, k != i of its source atom's block (round 6: the target's own row, which used to be computed
+    // and masked, is skipped in the row index instead -- ligands of 34 / 50 atoms need a row tile less, 2.7 % of the headline batch's tiles)
+    const int nr = nm1 - 1;
+    const int n_tiles = (nr + 15) >> 4;
 
     // per-segment global inputs (the Q row of Cdst, the query, the residual row) are fetched ONE SEGMENT AHEAD: their HBM
     // round trip overlaps the previous segment's arithmetic instead of opening every segment with a wait
@@ -233,12 +236,13 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
 
       // angle at i between j and k (uni_denoiser.py:131-135) for row m of tile g (+4 for a fifth tile): one atan2 per lane and
       // segment instead of one per tile, the tiles then fetch theta of (tile, m) from lane 16 tile + m.  Rows past the ligand
-      // take row 0's angle (finite; such rows are masked by selects on the logits), the row k = i gives atan2(0, 0) = 0.
+      // take the first row's angle (finite; such rows are masked by selects on the logits).
       float th_own[(MAXT + 3) / 4];
 #pragma unroll
       for (int rep = 0; rep < (MAXT + 3) / 4; ++rep) {
         const int kp = (4 * rep + g) * 16 + m;
-        const int kc = kp < nm1 ? kp : 0;
+        const int kq = kp < nr ? kp : 0;
+        const int kc = kq + (kq >= ip ? 1 : 0);                            // staged row: the block holds every k != j, row ip is the target's own
         const int k = kc + (kc >= j ? 1 : 0);
         const float v0 = xs[k * 3] - xi0, v1 = xs[k * 3 + 1] - xi1, v2 = xs[k * 3 + 2] - xi2;
         const float dt = u0 * v0 + u1 * v1 + u2 * v2;
@@ -268,8 +272,9 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
           lg[tile] = (f4){T2_NEG, T2_NEG, T2_NEG, T2_NEG};
           feat[tile][0] = feat[tile][1] = feat[tile][2] = 0.f;
           if (tile < n_tiles) {
-            const int kp = tile * 16 + m;                                  // row = k-th OTHER atom of j
-            const int kc = kp < nm1 ? kp : 0;                              // rows past the ligand read row 0 (finite, masked below)
+            const int kp = tile * 16 + m;                                  // row = k-th atom that is neither j nor i
+            const int kq = kp < nr ? kp : 0;                               // rows past the ligand read the first row (finite, masked below)
+            const int kc = kq + (kq >= ip ? 1 : 0);
             const float theta = t2_from_lane(th_own[tile >> 2], 16 * (tile & 3) + m);
             // angular features of row kp for f = 4 step + g  (common.py:85); f = 11 carries the per-segment constant Q
             // the four lanes of a row share the work: lane g evaluates sin / cos of theta, theta/2, theta/3 (one range reduction
@@ -283,8 +288,8 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
             feat[tile][0] = g == 0 ? theta : (g == 1 ? s1 : (g == 2 ? 2.0f * s1 * c1 : s1 * fmaf(-4.0f * s1, s1, 3.0f)));
             feat[tile][1] = g < 2 ? sx : (g == 2 ? c1 : fmaf(-2.0f * s1, s1, 1.0f));
             feat[tile][2] = g == 0 ? c1 * fmaf(4.0f * c1, c1, -3.0f) : (g == 3 ? 1.0f : cg);
-            // hidden^T[c, row] = P_k[row][c] + Q_k[c] + Wf_k . feat   (the masked rows k = i and past-the-end rows are computed
-            // like any other: their logits are replaced below, so no per-element selects are needed)
+            // hidden^T[c, row] = P_k[row][c] + Q_k[c] + Wf_k . feat   (past-the-end rows are computed like any other: their logits are
+            // replaced below, so no per-element selects are needed)
             f4 hid[8];
             const float* pk = prow + kc * T2_ROW + 4 * g;
 #pragma unroll
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int kr = tile * 16 + 4 * g + r;
-              lg[tile][r] = (kr < nm1 && kr != ip) ? acc[r] : T2_NEG;
+              lg[tile][r] = kr < nr ? acc[r] : T2_NEG;
             }
           }
         }
@@ -362,10 +367,11 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
           for (int tile = 0; tile < MAXT; ++tile)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int kr = tile * 16 + 4 * g + r;                 // row among the other atoms of j -> atom kr (+1 past j)
-              if (kr < nm1) ap[(kr + (kr >= j ? 1 : 0)) * 16] = lg[tile][r] * inv;
+              const int kr = tile * 16 + 4 * g + r;                 // row among the atoms that are neither j nor i -> its atom
+              const int kc = kr + (kr >= ip ? 1 : 0);
+              if (kr < nr) ap[(kc + (kc >= j ? 1 : 0)) * 16] = lg[tile][r] * inv;
             }
-          if (g == 0) ap[j * 16] = 0.f;
+          if (g == 0) { ap[j * 16] = 0.f; ap[i * 16] = 0.f; }      // the rows this kernel never visits: the source atom and the target
         }
       }
       T2_STAMP(4);                                // softmax
@@ -380,7 +386,8 @@ __global__ __launch_bounds__(THREADS) void triplet2_kernel(PgTopo t, PgSegAttn p
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int kr = tile * 16 + 4 * g + r;
-            const float* pv = prow + (kr < nm1 ? kr : 0) * T2_ROW + 128 + m;     // masked rows carry alpha = 0 below
+            const int kq = kr < nr ? kr : 0;
+            const float* pv = prow + (kq + (kq >= ip ? 1 : 0)) * T2_ROW + 128 + m;     // past-the-end rows carry alpha = 0 below
 #pragma unroll
             for (int tq = 0; tq < 8; ++tq) hv[tq][r] = pv[16 * tq];
           }
@@ -495,7 +502,7 @@ int launch_triplet_staged(const PgTopo* t, const PgSegAttn* p, hipStream_t st) {
   if (p->Csrc_v != p->Csrc_k + 128 || p->ld_csrc != 256 || ((size_t)p->Csrc_k & 15) || !p->Cdst_k || !p->Cdst_v) return -1;
   if (t->max_nlig - 1 > T2_ROWS || t->max_nlig > T2_XS) return -1;
   const int maxn = (p->tri_max_nlig > 0 && p->tri_max_nlig < t->max_nlig) ? p->tri_max_nlig : t->max_nlig;     // largest ligand among this queue's entries
-  const int tiles = (maxn - 1 + 15) / 16;
+  const int tiles = (maxn - 2 + 15) / 16;          // rows a segment visits: every atom but its source and its target
   if (train) {
     if (tiles <= 3) return launch_t2<768, 3, true>(t, p, st);
     if (tiles == 4) return launch_t2<768, 4, true>(t, p, st);

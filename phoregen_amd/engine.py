@@ -630,7 +630,7 @@ class Engine:
                 self._sync(prog, 0, (2,))          # this layer's triplet queries (lane 2, launched one layer ahead)
             a = L.TB
             self._event(prog, 'triplet', True)
-            # one launch, or two when a few ligands need more row tiles than the rest (BatchPlan.tri_split): the ligands of up to 49 atoms on
+            # one launch, or two when a few ligands need more row tiles than the rest (BatchPlan.tri_split): the ligands of up to 50 atoms on
             # the 3-tile instance of the kernel, the larger ones behind them with their own queue (the 4-tile instance costs every segment
             # ~4 %: tools/experiments/triplet_maxt_penalty.py).  Large batches only: 128 graphs 19.78 -> 19.64 ms per step; at 64 graphs the
             # second grid's tail costs more than the instance saves (9.92 -> 10.04), at 16 graphs per rank much more (3.33 -> 3.60)

@@ -21,7 +21,7 @@ COST_US = dict(tile=11.7e3 / 618440, bond=6.2e3 / 203720, node=3.0e3 / 18816, gr
 def graph_cost(num_atoms, n_phore=None):
     """Per-graph cost model of a sampler step (see COST_US).  Without pharmacophore sizes the node term counts the atoms only."""
     n = num_atoms.double()
-    tiles = torch.div(num_atoms.clamp(min=1) - 1 + 15, 16, rounding_mode='floor').double()       # 16-row tiles per triplet segment
+    tiles = torch.div(num_atoms.clamp(min=2) - 2 + 15, 16, rounding_mode='floor').double()       # 16-row tiles per triplet segment (n - 2 rows)
     ctx = n + (n_phore.double() if n_phore is not None else 0.0)
     return COST_US['tile'] * tiles * n * (n - 1) + COST_US['bond'] * n * (n - 1) + COST_US['node'] * ctx + COST_US['graph']
 
@@ -79,8 +79,8 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
     parts = [[] for _ in range(world_size)]
     if by_size and world_size > 1:
         # first-fit decreasing into bins of the mean load: the largest ligands end up TOGETHER on the first ranks.  The attention kernels
-        # are instantiated for the row tiles of the largest ligand of a batch (n >= 50 atoms: 4 tiles of 16 rows, n <= 49: 3): spread by
-        # LPT, the nine 50+-atom graphs of the headline batch put all eight ranks on the 4-tile kernels (+ 5 % per step)
+        # are instantiated for the row tiles of the largest ligand of a batch (n >= 51 atoms: 4 tiles of 16 rows, n <= 50: 3): spread by
+        # LPT, the 51+-atom graphs of the headline batch (five; nine of 50+ before the target's own row left the segments, round 6) put all eight ranks on the 4-tile kernels (+ 5 % per step)
         # ... and a rank on the 4-tile kernels gets `big_discount` less than its share (measured on the headline batch: equal cost, + 5 % time)
         cap_mean = float(cost.sum()) / world_size
         if big_discount is None:
@@ -89,8 +89,8 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
             # (a finer fit -- 3.5 % at 16 graphs per rank, 6 % at 32 -- was tried and lost: the shares scatter by +- 3 % around ANY smooth model,
             #  grid choice and whole rounds of the node kernels on the CUs that are left: profiles/r04_share_tri_grid.txt)
             big_discount = 0.05 if cap_mean < 4000.0 else (0.08 if cap_mean < 8000.0 else 0.0075)      # 16 / 32 / 64+ graphs per rank
-        big = (num_atoms >= 50).tolist()
-        n_big_cost = float(cost[num_atoms >= 50].sum())
+        big = (num_atoms >= 51).tolist()
+        n_big_cost = float(cost[num_atoms >= 51].sum())
         cap0 = float(cost.sum()) / world_size
         n_big_bins = max(1, -(-int(n_big_cost * 1000) // int(cap0 * (1.0 - big_discount) * 1000))) if n_big_cost > 0 else 0
         # a rank on the 4-tile kernels holds (1 - big_discount) of what the others hold

@@ -122,7 +122,7 @@ class BatchPlan:
         def queue(grps):
             its = []
             for gi, n, j0, a in grps:
-                tiles = (n - 1 + 15) // 16
+                tiles = (n - 2 + 15) // 16              # rows of a segment: every atom but its source and its target
                 n_seg = a * (n - 1)
                 rounds = (n_seg + waves - 1) // waves
                 parts = max(1, min(want_parts, rounds // 2))
@@ -139,12 +139,12 @@ class BatchPlan:
         self.tri_iters, n_its = queue(groups)
         self.n_tri_iters = n_its if usable else 0
         # the same entries as two queues, by the row tiles of the ligand: the kernel is instantiated for the largest ligand a queue holds,
-        # and the instance for 4 (5) tiles costs every segment ~4 % (8 %) -- a few 50+-atom ligands in a batch of smaller ones get their own
+        # and the instance for 4 (5) tiles costs every segment ~4 % (8 %) -- a few 51+-atom ligands in a batch of smaller ones get their own
         # launch (engine: options.tri_split) and the rest run on the 3-tile instance
-        small = [g_ for g_ in groups if g_[1] - 1 <= 48]
+        small = [g_ for g_ in groups if g_[1] - 2 <= 48]
         self.tri_split = None
         if usable and small and len(small) < len(groups):
-            big = [g_ for g_ in groups if g_[1] - 1 > 48]
+            big = [g_ for g_ in groups if g_[1] - 2 > 48]
             it_s, n_s = queue(small)
             it_b, n_b = queue(big)
             self.tri_split = dict(small=(it_s, n_s, max(g_[1] for g_ in small), torch.zeros(2, dtype=torch.int32, device=device)),

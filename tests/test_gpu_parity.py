@@ -1084,7 +1084,7 @@ def test_online_grid_tuning_does_not_change_the_trajectory(model):
 
 
 def test_triplet_launch_split_by_row_tiles_is_bit_identical(model):
-    """A batch with a few 50+-atom ligands among smaller ones runs the staged triplet kernel as two launches -- the ligands of up to 49 atoms
+    """A batch with a few 51+-atom ligands among smaller ones runs the staged triplet kernel as two launches -- the ligands of up to 50 atoms
     on the 3-tile instance, the larger ones with their own queue (BatchPlan.tri_split, PgSegAttn.tri_max_nlig): every segment sees the same
     arithmetic, so three sampler steps equal the single launch on the 4-tile instance bit for bit.  A 66-atom ligand (5 tiles) likewise."""
     from bench import ligphore_workload

@@ -496,7 +496,7 @@ def test_plan_matches_is_safe_for_inference_tensors_and_recycled_storage():
 def test_partition_balances_the_fitted_step_cost():
     """parallel.partition_graphs on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p) + d.  Every graph lands on exactly one rank; plain LPT
     (by_size=False) keeps the heaviest rank within one graph of the mean; the default groups the largest ligands on the first ranks (the
-    attention kernels are instantiated for the row tiles of a batch's largest ligand: ligands of 50+ atoms then do not put EVERY rank on the
+    attention kernels are instantiated for the row tiles of a batch's largest ligand: ligands of 51+ atoms then do not put EVERY rank on the
     4-tile kernels) and gives the ranks that hold them 5 % less than the others hold; on a batch whose
     pharmacophore sizes are skewed against the atom counts the fitted cost balances better than n^3 alone does."""
     from phoregen_amd.parallel import COST_US, graph_cost, partition_graphs
@@ -513,9 +513,9 @@ def test_partition_balances_the_fitted_step_cost():
             assert float(loads.max()) <= mean * (1.06 if by_size else 1.0) + float(cost.max()) + 1e-9
         if B == 128 and world == 8:
             parts = partition_graphs(na, world, nph)                       # default: by size
-            with_big = [r for r, p in enumerate(parts) if int(na[p].max()) >= 50]
-            assert with_big and with_big == list(range(len(with_big))) and len(with_big) <= 3       # the 50+-atom ligands sit together on the first ranks
-            lpt_big = [r for r, p in enumerate(partition_graphs(na, world, nph, by_size=False)) if int(na[p].max()) >= 50]
+            with_big = [r for r, p in enumerate(parts) if int(na[p].max()) >= 51]
+            assert with_big and with_big == list(range(len(with_big))) and len(with_big) <= 3       # the 51+-atom ligands sit together on the first ranks
+            lpt_big = [r for r, p in enumerate(partition_graphs(na, world, nph, by_size=False)) if int(na[p].max()) >= 51]
             assert len(lpt_big) > len(with_big)
             loads = torch.stack([cost[p].sum() for p in parts])
             assert float(loads[with_big].max()) <= mean * 0.975 and float(loads.max()) <= mean * 1.03        # (5 % less than the others hold)
@@ -556,8 +556,8 @@ def test_triplet_adjoint_atom_order_is_a_balanced_permutation():
 
 
 def test_triplet_queues_by_row_tiles_cover_the_single_queue():
-    """BatchPlan.tri_split: the entries of the staged triplet kernel's queue as two queues, ligands of up to 49 atoms (3 row tiles of 16) and
-    larger ones.  Together they hold exactly the entries of the single queue; the first holds no ligand above 49 atoms and names its largest
+    """BatchPlan.tri_split: the entries of the staged triplet kernel's queue as two queues, ligands of up to 50 atoms (a segment visits n - 2 <= 48 rows = 3 row tiles of 16) and
+    larger ones.  Together they hold exactly the entries of the single queue; the first holds no ligand above 50 atoms and names its largest
     (PgSegAttn.tri_max_nlig: the kernel instance is picked from it); a batch of one class has no split."""
     from phoregen_amd.plan import BatchPlan, make_edge_data
 
@@ -565,16 +565,16 @@ def test_triplet_queues_by_row_tiles_cover_the_single_queue():
         na = torch.tensor(sizes)
         ei, be = make_edge_data(na)
         return BatchPlan(torch.repeat_interleave(torch.arange(len(sizes)), na), torch.zeros(0, dtype=torch.long), ei, be, len(sizes), 'cpu')
-    p = plan_of([20, 50, 33, 49, 56, 8, 2, 41])
+    p = plan_of([20, 50, 33, 51, 56, 8, 2, 41])
     assert p.tri_split is not None
     (it_s, n_s, max_s, ctr_s), (it_b, n_b, max_b, ctr_b) = p.tri_split['small'], p.tri_split['big']
     rows = lambda t, n: sorted(map(tuple, t[:n].tolist()))
     assert n_s > 0 and n_b > 0
     assert sorted(rows(it_s, n_s) + rows(it_b, n_b)) == rows(p.tri_iters, p.n_tri_iters)
     atoms = lambda t, n: {int(v) & 0xff for v in t[:n, 1].tolist()}            # entry word 1 = n | j0 << 8 | a << 16
-    assert max(atoms(it_s, n_s)) == max_s == 49 and min(atoms(it_b, n_b)) == 50 and max_b == 0
+    assert max(atoms(it_s, n_s)) == max_s == 50 and min(atoms(it_b, n_b)) == 51 and max_b == 0
     assert ctr_s.numel() == 2 and ctr_b.numel() == 2 and ctr_s.data_ptr() != ctr_b.data_ptr() != p.tri_counter.data_ptr()
-    assert plan_of([20, 33, 49]).tri_split is None and plan_of([50, 60]).tri_split is None
+    assert plan_of([20, 33, 50]).tri_split is None and plan_of([51, 60]).tri_split is None
 
 
 def test_option_switches_are_consistent(monkeypatch):
