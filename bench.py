@@ -263,7 +263,7 @@ def measured_mfma_peak(dev):
     return best
 
 
-def secondary_configs(model, dev, budget_s=80.0):
+def secondary_configs(model, dev, budget_s=150.0):
     """BASELINE.json's other single-GPU configurations, run AFTER the headline's timed region in the same process (rank 0, N = 1) so that
     the driver's own bench run carries them: configs[1] (one 100-graph `sample`, 1000 steps, sample.sh's guidance), configs[4] (the
     training step, 256 pairs) and configs[3] as a job on this GPU (2 batches of 128 graphs, 1000 steps each, graphs / hour).  Each entry

@@ -88,7 +88,10 @@ def partition_graphs(num_atoms, world_size, n_phore=None, by_size=True, slack=0.
             # slower at 16 / 32 graphs per rank, 0.7 % at 64 (the kernels are throughput-bound there)
             # (a finer fit -- 3.5 % at 16 graphs per rank, 6 % at 32 -- was tried and lost: the shares scatter by +- 3 % around ANY smooth model,
             #  grid choice and whole rounds of the node kernels on the CUs that are left: profiles/r04_share_tri_grid.txt)
-            big_discount = 0.05 if cap_mean < 4000.0 else (0.08 if cap_mean < 8000.0 else 0.0075)      # 16 / 32 / 64+ graphs per rank
+            # round 6: with the target's own row out of the triplet segments only ligands of 51+ atoms take the 4-tile kernels (five of the headline
+            # batch, nine before) and the rank that holds them was 7 % light at 16 graphs per rank: 2.5 % there (two workload seeds, 8 ranks: 6.10 /
+            # 6.10 x with 5 %, 6.18 / 6.15 with 2.5 %, 6.21 / 6.14 with none; 4 ranks: 8 % stays -- none loses 1.5 - 3 %; profiles/r06_partition_big_discount.txt)
+            big_discount = 0.025 if cap_mean < 4000.0 else (0.08 if cap_mean < 8000.0 else 0.0075)      # 16 / 32 / 64+ graphs per rank
         big = (num_atoms >= 51).tolist()
         n_big_cost = float(cost[num_atoms >= 51].sum())
         cap0 = float(cost.sum()) / world_size

@@ -497,7 +497,7 @@ def test_partition_balances_the_fitted_step_cost():
     """parallel.partition_graphs on graph_cost = a tiles n (n-1) + b n (n-1) + c (n + p) + d.  Every graph lands on exactly one rank; plain LPT
     (by_size=False) keeps the heaviest rank within one graph of the mean; the default groups the largest ligands on the first ranks (the
     attention kernels are instantiated for the row tiles of a batch's largest ligand: ligands of 51+ atoms then do not put EVERY rank on the
-    4-tile kernels) and gives the ranks that hold them 5 % less than the others hold; on a batch whose
+    4-tile kernels) and gives the ranks that hold them 2.5 % less than the others hold (16 graphs per rank; 8 % at 32); on a batch whose
     pharmacophore sizes are skewed against the atom counts the fitted cost balances better than n^3 alone does."""
     from phoregen_amd.parallel import COST_US, graph_cost, partition_graphs
     g = torch.Generator().manual_seed(5)
@@ -518,7 +518,7 @@ def test_partition_balances_the_fitted_step_cost():
             lpt_big = [r for r, p in enumerate(partition_graphs(na, world, nph, by_size=False)) if int(na[p].max()) >= 51]
             assert len(lpt_big) > len(with_big)
             loads = torch.stack([cost[p].sum() for p in parts])
-            assert float(loads[with_big].max()) <= mean * 0.975 and float(loads.max()) <= mean * 1.03        # (5 % less than the others hold)
+            assert float(loads[with_big].max()) <= mean * 0.99 and float(loads.max()) <= mean * 1.03         # (2.5 % less than the others hold at 16 graphs per rank)
     # an empty job (a shard of a finished sampling job): empty shards for every rank, at any world size
     for world in (1, 2, 8):
         parts = partition_graphs(torch.tensor([], dtype=torch.long), world)
