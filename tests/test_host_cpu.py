@@ -568,9 +568,18 @@ def test_triplet_queues_by_row_tiles_cover_the_single_queue():
     p = plan_of([20, 50, 33, 51, 56, 8, 2, 41])
     assert p.tri_split is not None
     (it_s, n_s, max_s, ctr_s), (it_b, n_b, max_b, ctr_b) = p.tri_split['small'], p.tri_split['big']
-    rows = lambda t, n: sorted(map(tuple, t[:n].tolist()))
+    def segments(t, n):
+        """Every (ligand, group, segment) an entry list hands out (entry = {ligand, n | j0 << 8 | A << 16, bond row 0, s0 | s1 << 16}; 0 = the
+        whole group).  The tail of a queue is cut into half-groups, so the two queues hold other ENTRIES than the single one, the same segments."""
+        out = []
+        for lig0, w1, boff, w3 in t[:n].tolist():
+            n_, a_ = w1 & 0xff, w1 >> 16
+            s0, s1 = (w3 & 0xffff, w3 >> 16) if w3 else (0, a_ * (n_ - 1))
+            out += [(lig0, w1, boff, s_) for s_ in range(s0, s1)]
+        return sorted(out)
     assert n_s > 0 and n_b > 0
-    assert sorted(rows(it_s, n_s) + rows(it_b, n_b)) == rows(p.tri_iters, p.n_tri_iters)
+    both, single = segments(it_s, n_s) + segments(it_b, n_b), segments(p.tri_iters, p.n_tri_iters)
+    assert sorted(both) == single and len(set(single)) == len(single)            # every segment exactly once, either way
     atoms = lambda t, n: {int(v) & 0xff for v in t[:n, 1].tolist()}            # entry word 1 = n | j0 << 8 | a << 16
     assert max(atoms(it_s, n_s)) == max_s == 50 and min(atoms(it_b, n_b)) == 51 and max_b == 0
     assert ctr_s.numel() == 2 and ctr_b.numel() == 2 and ctr_s.data_ptr() != ctr_b.data_ptr() != p.tri_counter.data_ptr()
