@@ -627,9 +627,9 @@ FLIP_GAP_MULT = 2 * 5 * TOL      # x max |logit| of the step: a categorical draw
 # 3.6e-3 on graphs whose types never differ; profiles/r06_free_running_match_rate.json).  No fp32 implementation -- the reference on another BLAS
 # or thread count included -- reproduces such a trajectory to the end.  So this fixture is held to the STRICT rule of the small fixtures (types
 # bit-exact, RMSD <= 1e-4; a graph may leave only through an evidenced tie) through its first AT_SCALE_STRICT steps; after that a graph may also
-# leave by drift, and at least AT_SCALE_ON_TRAJECTORY of all graph-steps must lie on the reference's trajectory.  (Measured at HEAD: 4 / 4 graphs
-# bit-identical and within 8.2e-5 A through step 738; then one drifts past 1e-4, two leave through evidenced ties at steps 826 / 906, one stays
-# for all 1000 steps, 3.0e-5 A at the end; 86.8 % of the graph-steps on the trajectory.)
+# leave by drift, and at least AT_SCALE_ON_TRAJECTORY of all graph-steps must lie on the reference's trajectory.  (Measured at HEAD: 3 / 4 graphs
+# bit-identical for all 1000 steps, worst RMSD 3.5e-5 A; one leaves at step 826 through an evidenced tie; 95.7 % of the graph-steps on the
+# trajectory.  With the same arithmetic in another row order, earlier in round 6: 4 / 4 through step 738, then one drift and two ties.)
 AT_SCALE_STRICT = 700
 AT_SCALE_ON_TRAJECTORY = 0.75
 KINK_EPS = 2e-5                  # [A] a bond this close to min_d / max_d of the atom_prox guidance sits ON the kink of its relu at fp32 precision
