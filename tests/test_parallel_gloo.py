@@ -61,7 +61,6 @@ def _pattern_pred(graph_ids, num_atoms):
 def _job_worker(rank, world, port, n_graphs, q):
     """BASELINE config 4's gather (sample_all.py:104-116 at job scale): `n_graphs` graphs' worth of rows, partitioned as
     `run_sampling_job` does, payload without compute."""
-    import resource
     import time
     os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -89,7 +88,10 @@ def _job_worker(rank, world, port, n_graphs, q):
             payload = sum(t.numel() for t in out) * 4
         else:
             ok, payload = ok and out is None, 0
-        q.put((rank, bool(ok), calls['n'], t_part, t_gather, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024, payload))
+        # peak resident set of THIS process (VmHWM: per address space, reset by exec; getrusage's ru_maxrss starts from the parent's value -- in a
+        # full pytest run the 3 GB of the test process itself)
+        hwm = next(int(l.split()[1]) * 1024 for l in open('/proc/self/status') if l.startswith('VmHWM'))
+        q.put((rank, bool(ok), calls['n'], t_part, t_gather, hwm, payload))
     finally:
         dist.destroy_process_group()
 
