@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6, GPU job 10 (experiment): the tail of the triplet queue in half / quarter groups.
+# Round 6, GPU job 10 (experiment): the tail of the triplet queue in half / quarter groups.  (A record: the knob PG_TRI_TAIL_PARTS existed in plan.py
+# only for this experiment; the product rule -- the last 256 entries halved -- came out of it: profiles/r06_triplet_queue_tail.txt.)
 export PHOREGEN_DEBUG=1
 for k in 0 256 384 256,256 512,256 512,512 1024,512; do
   echo "PG_TRI_TAIL_PARTS=$k: $(PG_TRI_TAIL_PARTS=$k python3 tools/bench_triplet.py 40 2>&1 | tail -1)"
