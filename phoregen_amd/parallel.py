@@ -147,7 +147,7 @@ def gather_predictions(pred, num_atoms_local, graph_ids_local, group=None, dst=0
     counts = torch.empty(world, device=cdev, dtype=torch.long)
     dist.all_gather_into_tensor(counts, cnt, group=group)
     counts = counts.tolist()
-    gmax = max(counts)
+    gmax = max(max(counts), 1)                        # (a rank, or the whole job, may be empty)
     # 2. the [graph id | atoms] tables
     meta = torch.zeros(2, gmax, device=cdev, dtype=torch.long)
     meta[0, :gids.numel()], meta[1, :gids.numel()] = gids, nat
@@ -158,7 +158,7 @@ def gather_predictions(pred, num_atoms_local, graph_ids_local, group=None, dst=0
     nat_r = [metas[r, 1, :c] for r, c in enumerate(counts)]
     n_r = [int(x.sum()) for x in nat_r]
     e_r = [int((x * (x - 1)).sum()) for x in nat_r]
-    lmax = max(15 * n + 6 * e for n, e in zip(n_r, e_r))
+    lmax = max(max(15 * n + 6 * e for n, e in zip(n_r, e_r)), 1)
     # global order = ascending graph id; where every graph's rows start in it
     ids_all, nat_all = torch.cat(ids_r), torch.cat(nat_r)
     order = torch.argsort(ids_all, stable=True)

@@ -23,6 +23,8 @@ def _fake_pred(graph_ids, num_atoms):
         node.append(torch.randn(n, 12, generator=gen))
         pos.append(torch.randn(n, 3, generator=gen))
         edge.append(torch.randn(n * (n - 1), 6, generator=gen))
+    if not node:                               # a rank without graphs
+        return [torch.zeros(0, 12), torch.zeros(0, 3), torch.zeros(0, 6)]
     return [torch.cat(node), torch.cat(pos), torch.cat(edge)]
 
 
@@ -130,6 +132,20 @@ def test_partition_is_balanced_and_complete():
         loads = [float((na[p].double() ** 3).sum()) for p in parts]
         if world <= 4:
             assert max(loads) <= 1.6 * (sum(loads) / world)
+
+
+def test_gather_world_size_2_gloo_with_an_empty_rank():
+    """One graph for two ranks (the tail of a job): the rank without graphs takes part in the three collectives with empty payloads."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, torch.tensor([6]), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
 
 
 def test_gather_world_size_2_gloo():
