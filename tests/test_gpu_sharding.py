@@ -181,3 +181,34 @@ def test_guidance_normalisation_of_a_tail_batch(model):
     assert float((by_size[1][n4:] - actual[1][n4:]).abs().max()) > 1e-6
     with pytest.raises(ValueError):
         sample_job_shard(model, job, ids, batch_size=4, guidance_norm='mean')
+
+
+def test_gather_predictions_over_rccl_one_rank():
+    """The path's one collective on the device: a 1-rank `nccl` (= RCCL) group on cuda:0, `gather_predictions` on device tensors (the counts /
+    tables / payload collectives run through RCCL on device memory, the re-assembly on the device), graph ids NOT in order and with gaps: the
+    result is `pred` in ascending graph id, for the rank-0 form and the every-rank form.  (World size > 1 over gloo: tests/test_parallel_gloo.py.)"""
+    import socket
+    import torch.distributed as dist
+    from phoregen_amd.parallel import gather_predictions
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        gids = torch.tensor([7, 2, 11, 3])
+        na = torch.tensor([5, 9, 3, 6])
+        gen = torch.Generator().manual_seed(0)
+        N, E = int(na.sum()), int((na * (na - 1)).sum())
+        pred = [torch.randn(N, 12, generator=gen).cuda(), torch.randn(N, 3, generator=gen).cuda(), torch.randn(E, 6, generator=gen).cuda()]
+        order = torch.argsort(gids)
+        n_off = torch.cat([torch.zeros(1, dtype=torch.long), na.cumsum(0)])
+        e_off = torch.cat([torch.zeros(1, dtype=torch.long), (na * (na - 1)).cumsum(0)])
+        exp = [torch.cat([pred[k][(n_off if k < 2 else e_off)[g]:(n_off if k < 2 else e_off)[g + 1]] for g in order.tolist()]) for k in range(3)]
+        for dst in (0, None):
+            out, nat = gather_predictions(pred, na, gids, dst=dst)
+            torch.cuda.synchronize()
+            assert torch.equal(nat, na[order]) and all(o.is_cuda and torch.equal(o, e) for o, e in zip(out, exp))
+    finally:
+        dist.destroy_process_group()
