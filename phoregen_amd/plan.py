@@ -114,10 +114,10 @@ class BatchPlan:
             A = max(1, min(rows_cap // (n - 1), n))
             for j0 in range(0, n, A):
                 groups.append((gi, n, j0, min(A, n - j0)))
-        # small batches (fewer than ~4 groups per workgroup): a group's segments are handed out in up to 4 parts of whole
-        # 12-wave rounds, so that the queue can level the workgroups (16 graphs: 320 groups of 7 rounds on 256 workgroups meant
-        # 14 rounds for the slowest; in parts of 3 + 2 + 2 rounds about 10)
-        want_parts = 1 if len(groups) >= 4 * 256 or not groups else min(4, -(-4 * 256 // len(groups)))
+        # small batches (fewer than 2 groups per workgroup): a group's segments are handed out in 2 parts of whole 12-wave rounds, so that
+        # the queue can level the workgroups.  (Rounds 2 - 5: up to 4 parts below 4 groups per workgroup; with the queue's tail in half-groups
+        # -- below -- coarser is better: 8 / 16 / 32 graphs 1.93 / 2.87 / 4.98 -> 1.90 / 2.82 / 4.90 ms per step, profiles/r06_triplet_queue_tail.txt)
+        want_parts = 1 if len(groups) >= 2 * 256 or not groups else 2
 
         def queue(grps):
             its = []
@@ -134,12 +134,12 @@ class BatchPlan:
                                 0 if parts == 1 else (s0 | (s1 << 16))))
                     r0 = r1
             its.sort(key=lambda r: -r[0])
-            # the TAIL of the queue in half-groups (round 6): the last 256 entries -- the cheapest groups, handed out when the persistent
+            # the TAIL of the queue in half-groups (round 6): the last 128 entries -- the cheapest groups, handed out when the persistent
             # workgroups run dry -- cover half of their whole 12-wave rounds each, so the launch ends within half a group of its last workgroup
             # instead of a whole one (a group of a 40-atom ligand is 6.5 rounds = ~180 us).  Measured on the headline batch: the sub-layer alone
-            # 1.957 -> 1.859 ms, the step 19.53 -> 19.25 ms; 16 graphs 2.92 -> 2.87; halving more of the queue, or the tail twice, loses to the
-            # repeated staging of the groups' rows (profiles/r06_triplet_queue_tail.txt)
-            head, last = its[:max(len(its) - 256, 0)], its[max(len(its) - 256, 0):]
+            # 1.957 -> 1.859 ms, the step 19.53 -> 19.25 ms; 16 graphs 2.92 -> 2.87 (the last 256: 128 is equal at 128 graphs and better below);
+            # halving more of the queue, or the tail twice, loses to the repeated staging of the groups' rows (profiles/r06_triplet_queue_tail.txt)
+            head, last = its[:max(len(its) - 128, 0)], its[max(len(its) - 128, 0):]
             halves = []
             for c, lig0, w1, boff, w3 in last:
                 n_, a_ = w1 & 0xff, w1 >> 16
