@@ -520,10 +520,13 @@ class Engine:
         # the v2 schedule (there lane 2 would need its own release after the layer's closing launch: measured equal or slower, 8 graphs
         # 2.05 vs 2.03 ms) and for the largest batches (128 graphs + 0.3 % on the side lane), lane 2 in between (64 graphs 9.98 -> 9.94 ms)
         chain_q = self.multi_stream and (v2 or E >= self.chain_q_from)
+        # (round 6, with the queue's tail in half-groups: the best grid moved up by 32 -- 8 graphs 2.01 / 1.90 / 1.92 ms with 160 / 192 / 224
+        #  workgroups, 16 graphs 3.31 / 2.99 / 2.81 / 2.93 with 160 / 192 / 224 / 256, 32 graphs 5.33 / 4.88 / 5.10 with 192 / 224 / 256; the defaults
+        #  below follow, the calibration in begin_sampling still tries the neighbours)
         # small batches leave some CUs to the side lanes while the persistent triplet kernel runs (measured on the headline shape:
         # 16 graphs = 25 k bond edges 3.76 -> 3.57 ms per step with 192 workgroups, 24 / 32 graphs 4.9 -> 4.7 / 5.87 -> 5.61 with
         # 224 and the merged knn launch; 48 graphs equal either way, from 64 graphs up the full grid is fastest)
-        tri_grid = self.tri_grid if self.tri_grid >= 0 else ((160 if E < 15000 else 192 if E < 26000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
+        tri_grid = self.tri_grid if self.tri_grid >= 0 else ((192 if E < 15000 else 224 if E < 80000 else 0) if self.multi_stream else 0)
         # ... and which multiple of 32 is best flips from batch to batch of the SAME size (whole 12-segment rounds per workgroup against
         # the CUs left to the node chain: rank shares of the headline batch with 25.7 k bond edges each: 3.48 / 3.31 ms with 192 / 224
         # workgroups for one, 3.27 / 3.48 for the next; profiles/r04_share_tri_grid.txt), so small batches TIME the neighbours of this
