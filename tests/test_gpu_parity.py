@@ -1078,7 +1078,7 @@ def test_online_grid_tuning_does_not_change_the_trajectory(model):
         return [t.cpu().clone() for t in out['pred']] + [torch.as_tensor(t).cpu().clone() for t in out['traj'] if t is not None], eng
     tuned, eng = run()
     plain, eng0 = run(tune_grid=False)
-    assert eng._tune is None and eng.tuned_tri_grid in (128, 160, 192, 224) and set(eng.tuned_tri_grid_ms) >= {eng.tuned_tri_grid}
+    assert eng._tune is None and eng.tuned_tri_grid in (128, 160, 192, 224, 256) and set(eng.tuned_tri_grid_ms) >= {eng.tuned_tri_grid}
     assert eng0.tuned_tri_grid is None
     assert len(tuned) == len(plain) and all(torch.equal(a, b) for a, b in zip(tuned, plain))
 
