@@ -5,7 +5,8 @@ TEST INFRASTRUCTURE, build container only.  The reference is imported unmodified
 oracle/ref_import.py + oracle/standins/README.md for the absent third-party wheels), loaded with
 the deterministic synthetic weights of phoregen_amd/weights.py (there are no checkpoints offline)
 and driven on small seeded inputs.  Only *data* is written: inputs, recorded RNG draws, expected
-outputs.  Re-run with:  python oracle/make_golden.py
+outputs.  Re-run with:  python oracle/make_golden.py            (everything; the full-length fixtures alone: `full1000`, `full1000_n34`,
+`full1000_headline` -- the last one is ~3 h of CPU at the script's 4 threads: the reference's own 1000-step run at the bench's shape)
 """
 import os
 import random
