@@ -24,7 +24,7 @@ else:
     full = ligphore_workload(128, seed=_seed)
     print(f'workload: headline shape, seed {_seed}')
 sys.argv = [a for a in sys.argv if not a.startswith('seed=') and a != 'config4']
-W, K = 24, 30          # (24 untimed steps: the online choice of the triplet grid of a small share is made inside them)
+W, K = 24, 30          # (untimed steps first; since round 6 a small share chooses its triplet grid inside begin_sampling, before the loop)
 
 
 def ms_per_step(work, gids):
