@@ -551,7 +551,7 @@ def main():
             'repeats': R, 'repeats_ms_per_step': [t / K * 1e3 for t in times], 'statistic': 'median block of `repeats` blocks of `steps` steps',
             'graph_steps_per_sec': K * total_graphs / dt,
             'ranks': world, 'distinct_devices': min(world, n_dev), 'dist_backend': backend,
-            'roofline': {'kernel': 'triplet kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 sub-layers/step' + (': each as two launches, ligands of up to 50 atoms on the 3-tile instance and the larger ones behind them' if getattr(run, 'tri_launches', 6) > 6 else '') + '), rank 0',
+            'roofline': {'kernel': 'triplet kernel (pg_seg_attn PG_SEG_TRIPLET = BondUpdateLayer, 6 sub-layers/step' + (': each as two launches, ligands of up to 50 atoms on the 3-tile instance and the larger ones beside them on another lane; a launch = the pair' if getattr(run, 'tri_launches', 6) > 6 else '') + '), rank 0',
                          'bound': 'mfma', 'achieved': exec_tf, 'peak': peak_tf, 'unit': 'TFLOP/s',
                          'frac': (exec_tf / peak_tf) if exec_tf else None, 'traffic': traffic, 'traffic_source': traffic_src,
                          'frac_mfma_only': (mfma_only_tf / peak_tf) if mfma_only_tf else None,

@@ -98,6 +98,7 @@ class Engine:
         # cross-lane order points without the host-visibility fence of a default event (hip.OrderPoint; tools/micro/stream_packets.py)
         self.order_points = o['order_points'] and not o['graph']
         self.tri_split, self.tri_split_from = o['tri_split'], o['tri_split_from']
+        self.tri_overlap = o['tri_overlap']
         self.chain_q_from = o['chain_q_from']
         self.tune_grid = o['tune_grid']
         self.tuned_tri_grid = None
@@ -634,19 +635,32 @@ class Engine:
             a = L.TB
             self._event(prog, 'triplet', True)
             # one launch, or two when a few ligands need more row tiles than the rest (BatchPlan.tri_split): the ligands of up to 50 atoms on
-            # the 3-tile instance of the kernel, the larger ones behind them with their own queue (the 4-tile instance costs every segment
-            # ~4 %: tools/experiments/triplet_maxt_penalty.py).  Large batches only: 128 graphs 19.78 -> 19.64 ms per step; at 64 graphs the
-            # second grid's tail costs more than the instance saves (9.92 -> 10.04), at 16 graphs per rank much more (3.33 -> 3.60)
+            # the 3-tile instance of the kernel, the larger ones with their own queue (the 4-tile instance costs every segment ~4 %:
+            # tools/experiments/triplet_maxt_penalty.py) on lane 3 BESIDE it -- the two launches cover disjoint ligands, a workgroup slot that
+            # one queue no longer fills goes to the other, and the sub-layer ends with one tail instead of two (one kernel that picks its
+            # unrolling per group was 12 % slower: tools/experiments/README.md).  Per step, one launch / two in a row / two side by side:
+            # 128 graphs 19.21 / 19.00 / 18.89 ms, 64 graphs 9.60 / 9.59 / 9.44, 32 and 16 graphs equal (profiles/r06_triplet_side_by_side.txt)
             queues = [(p.tri_iters, p.n_tri_iters, 0, p.tri_counter)]
             if staged and self.tri_split and p.tri_split is not None and (E >= self.tri_split_from or self.tri_split == 'always'):
                 queues = [p.tri_split['small'], p.tri_split['big']]
-            for q_iters, q_n, q_maxn, q_ctr in queues:
+            side = abs(self.tri_overlap) if len(queues) == 2 else 0
+            big_first = self.tri_overlap > 0
+            if side:                               # the larger ligands' queue on a side lane, beside (not behind) the other launch
+                if big_first:
+                    queues = queues[::-1]
+                self._fork(prog, (side,))
+            for qi, (q_iters, q_n, q_maxn, q_ctr) in enumerate(queues):
+                if side:
+                    self._lane = side if (qi == 0) == big_first else 0
                 self.tri_calls.append(len(prog))
                 self._seg(prog, hip.SEG_TRIPLET, E, p.tri_order, a, x=xc, Csrc_k=w.P[:, 0:128], Csrc_v=w.P[:, 128:256],
                           ld_csrc=w.P.stride(0), Wf_k=a.Wf_k, Wf_v=a.Wf_v, Wg2_k=a.Wg2_k, Wg2_v=a.Wg2_v, G=w.G, q=w.qT,
                           W2k_l=a.W2k_l, W2v_l=a.W2v_l, b2v=a.b2v, resid=hbc, out=hbn, seg_chunks=p.tri_chunks,
                           **(dict(tri_iters=q_iters, n_tri_iters=q_n, tri_counter=q_ctr, tri_grid=tri_grid, tri_max_nlig=q_maxn,
                                   Cdst_k=w.Qd[:, 0:128], Cdst_v=w.Qd[:, 128:256], ld_cdst=256) if staged else {}))
+            if side:
+                self._lane = 0
+                self._join(prog, (side,))
             self._event(prog, 'triplet', False)
             if last:                               # lane 3 (the triplet queries) has been joined: the bond head takes it
                 self._fork(prog, (3,))

@@ -33,7 +33,9 @@ DEFAULTS = dict(
     chain_q_from=150000,  # the Q rows of the triplet MLPs behind P on lane 0 from this many bond edges up (below: beside P on lane 2)
     tri_split=True,       # the triplet kernel as two launches when a few ligands need more row tiles than the rest (BatchPlan.tri_split):
                           # True = from `tri_split_from` bond edges up, 'always', False
-    tri_split_from=120000,
+    tri_split_from=82000,
+    tri_overlap=3,        # the side lane the larger ligands' launch runs on, BESIDE the other one (disjoint ligands; both queues drain into the
+                          # same workgroup slots, one tail instead of two); 0 = behind it on lane 0; < 0: that lane, launched second
     tri_grid=-1,          # persistent workgroups of the staged triplet kernel (-1: by batch size)
     graph=False,          # hipGraph replay of the forward launch list
     fused_geom='auto',    # coordinate update + bond smearing + direction vectors as one launch on the bond chain's lane (pg_layer_geom):

@@ -1086,7 +1086,8 @@ def test_online_grid_tuning_does_not_change_the_trajectory(model):
 def test_triplet_launch_split_by_row_tiles_is_bit_identical(model):
     """A batch with a few 51+-atom ligands among smaller ones runs the staged triplet kernel as two launches -- the ligands of up to 50 atoms
     on the 3-tile instance, the larger ones with their own queue (BatchPlan.tri_split, PgSegAttn.tri_max_nlig): every segment sees the same
-    arithmetic, so three sampler steps equal the single launch on the 4-tile instance bit for bit.  A 66-atom ligand (5 tiles) likewise."""
+    arithmetic, so three sampler steps equal the single launch on the 4-tile instance bit for bit, whether the second launch runs beside the
+    first (the default) or behind it.  A 66-atom ligand (5 tiles) likewise."""
     from bench import ligphore_workload
     from phoregen_amd import options
     for big in ((55, 50), (66,)):
@@ -1108,16 +1109,17 @@ def test_triplet_launch_split_by_row_tiles_is_bit_identical(model):
                 split = st.plan.tri_split is not None
             model._engine = None
             return out, launches, split
-        two, l2, has = run(tri_split='always')
+        two, l2, has = run(tri_split='always')                       # (the larger ligands' launch on lane 3, beside the other: options.tri_overlap)
         one, l1, _ = run(tri_split=False)
-        assert has and l2 == 2 * l1 == 12
-        assert all(torch.equal(a, b) for a, b in zip(two, one))
+        row, l3, _ = run(tri_split='always', tri_overlap=0)          # ... and behind it on lane 0
+        assert has and l2 == l3 == 2 * l1 == 12
+        assert all(torch.equal(a, b) for a, b in zip(two, one)) and all(torch.equal(a, b) for a, b in zip(row, one))
 
 
 @pytest.mark.parametrize('graphs', [5, 16, 56, 72])
 def test_four_lanes_equal_one_stream_in_every_schedule_regime(model, graphs):
     """The engine picks its launch list by batch size (per-chain closing launch below 16 k bond edges, the v2 position phase below 82 k, the Q
-    rows on a side lane up to 150 k, two triplet launches from 120 k): in each regime 25 forwards on four lanes equal the one-stream list
+    rows on a side lane up to 150 k, two triplet launches side by side from 82 k): in each regime 25 forwards on four lanes equal the one-stream list
     on the same inputs bit for bit (tools/stress_bits.py runs the same hunt with more sizes and repeats)."""
     from bench import ligphore_workload
     from phoregen_amd import options

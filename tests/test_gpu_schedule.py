@@ -57,6 +57,30 @@ def test_checker_notices_a_missing_order_point(model):
     assert n_sensitive >= len(waits) // 2, (n_sensitive, len(waits))
 
 
+def test_triplet_launches_side_by_side_write_disjoint_ligands(model, monkeypatch):
+    """From 82 k bond edges the bond-triplet sub-layer is two launches, the larger ligands' on lane 3 beside the other (options.tri_overlap).
+    The checker carries the set of ligands of the launch's queue on the region it writes: the pair is not a conflict BECAUSE the queues are
+    disjoint (and together cover the batch) -- told that both queues hold the same ligands, it reports the pair."""
+    from bench import ligphore_workload
+    import check_schedule as cs
+    work = ligphore_workload(72)
+    fwd, pipe, info = cs.check_engine(model, work)
+    eng = info['eng']
+    assert not fwd and not pipe and len(eng.tri_calls) == 12 and eng.plan.tri_split is not None
+    assert [eng.prog_fwd[k][2] for k in eng.tri_calls] == [3, 0] * 6
+    small, big = (set(int(v) for v in q[0][:q[1], 2].cpu().tolist()) for q in (eng.plan.tri_split['small'], eng.plan.tri_split['big']))
+    assert not (small & big) and (small | big) == set(int(v) for v in eng.plan.tri_iters[:eng.plan.n_tri_iters, 2].cpu().tolist())
+    real = cs.Buffers.add_queue
+
+    def same_ligands(self, iters, n):
+        real(self, iters, n)
+        self.queues[iters.data_ptr()] = frozenset([0])
+    monkeypatch.setattr(cs.Buffers, 'add_queue', same_ligands)
+    fwd, pipe, _ = cs.check_engine(model, work)
+    model._engine = None
+    assert any(h[6].startswith('ws.hb') and {h[1], h[4]} == {0, 3} and h[2] == h[5] == 'w' for h in fwd), [cs.fmt(h) for h in fwd]
+
+
 @pytest.mark.parametrize('shape,graphs', [('headline', 16), ('config2', 100), ('config4', 128)])
 def test_default_schedule_is_near_the_best_variant(model, shape, graphs):
     """The size thresholds of phoregen_amd/options.py were fitted on the headline shape; here every size-dependent switch is forced both ways on

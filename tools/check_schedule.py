@@ -56,6 +56,11 @@ class Buffers:
         self.items = out
         return self
 
+    def add_queue(self, iters, n):
+        """A triplet queue (BatchPlan.tri_iters, int32 [n, 4]): the ligands it covers, as the set of their first bond rows."""
+        self.queues = getattr(self, 'queues', {})
+        self.queues[iters.data_ptr()] = frozenset(int(v) for v in iters[:n, 2].cpu().tolist())
+
     def region(self, ptr, width=None):
         """(buffer name, first column byte, last column byte + 1) of a pointer; width = bytes per row touched (None: the whole row)."""
         if not ptr:
@@ -110,7 +115,13 @@ def access_of(name, args, buf):
             (wr if (fused or p_ is not s.U) else rd)(v)
             if fused:
                 rd(v)
-        wr(C.cast(s.out, C.c_void_p).value, 512), wr(C.cast(s.dx, C.c_void_p).value)
+        out = reg(C.cast(s.out, C.c_void_p).value, 512)
+        if out:
+            # a staged triplet launch writes the rows of ITS queue's ligands only: two launches over disjoint queues may run beside each
+            # other (engine: options.tri_overlap); the set of ligands rides on the region
+            rows = getattr(buf, 'queues', {}).get(C.cast(s.tri_iters, C.c_void_p).value) if (s.mode == 4 and s.tri_iters) else None
+            W.append(out if rows is None else out + (rows,))
+        wr(C.cast(s.dx, C.c_void_p).value)
         if s.accumulate_dx:
             rd(C.cast(s.dx, C.c_void_p).value)
         v = C.cast(s.tri_counter, C.c_void_p).value
@@ -190,19 +201,21 @@ class Timeline:
         last = {}                         # buffer name -> list of op indices touching it
         for i, (label, lane, clk, R, W) in enumerate(self.ops):
             for kind, regs in (('r', R), ('w', W)):
-                for (name, c0, c1) in regs:
-                    for j, jkind, d0, d1 in last.get(name, ()):
+                for (name, c0, c1, *rows) in regs:
+                    for j, jkind, d0, d1, jrows in last.get(name, ()):
                         if jkind == 'r' and kind == 'r':
                             continue
                         if c1 <= d0 or d1 <= c0:
                             continue
+                        if rows and jrows and not (rows[0] & jrows[0]):
+                            continue                              # disjoint sets of ligands (rows) of the same columns
                         lj, lanej, clkj = self.ops[j][0], self.ops[j][1], self.ops[j][2]
                         if lanej == lane or clk[lanej] >= clkj[lanej]:
                             continue                              # j happens-before i
                         out.append((lj, lanej, jkind, label, lane, kind, name, (max(c0, d0), min(c1, d1))))
             for kind, regs in (('r', R), ('w', W)):
-                for (name, c0, c1) in regs:
-                    last.setdefault(name, []).append((i, kind, c0, c1))
+                for (name, c0, c1, *rows) in regs:
+                    last.setdefault(name, []).append((i, kind, c0, c1, rows))
         # one line per (earlier launch, later launch, buffer)
         seen, uniq = set(), []
         for h in out:
@@ -247,6 +260,9 @@ def check_engine(model, work, guided=False, steps=3, drop_step=None):
     buf.add_ns('ws', eng.ws)
     buf.add_ns('st', st)
     buf.finish()
+    buf.add_queue(eng.plan.tri_iters, eng.plan.n_tri_iters)
+    for q in (eng.plan.tri_split or {}).values():
+        buf.add_queue(q[0], q[1])
     tl = Timeline()
     tl.add_program(eng.prog_fwd, buf, 'fwd')
     fwd = tl.hazards()
