@@ -99,7 +99,7 @@ class Engine:
         self.order_points = o['order_points'] and not o['graph']
         self.tri_split, self.tri_split_from = o['tri_split'], o['tri_split_from']
         self.tri_overlap = o['tri_overlap']
-        self.chain_q = o['chain_q']
+        self.chain_q_from = o['chain_q_from']
         self.tune_grid = o['tune_grid']
         self.tuned_tri_grid = None
         self.geom_split = o['geom_split'] == 'always' or (o['geom_split'] == 'auto' and self.plan.n_bond < o['geom_split_below'])
@@ -519,10 +519,8 @@ class Engine:
         v2 = self.ahead_v2 and ahead        # Y1 of the next layer on lane 1 behind Y2, bond-node of layer 0 on lane 3, finer waits (round 4)
         # the Q rows (a K = 20 product, bound by its 256-wide output) behind P on the bond chain's own lane, or beside P on lane 2: lane 0 in
         # the v2 schedule (there lane 2 would need its own release after the layer's closing launch: measured equal or slower, 8 graphs
-        # 2.05 vs 2.03 ms), lane 2 above it (64 graphs 9.98 -> 9.94 ms; until late in round 6 the largest batches went back to lane 0 from 150 k
-        # bond edges -- with the triplet launches side by side lane 2 wins there too: 100 / 128 / 160 graphs 14.83 -> 14.73 / 18.99 -> 18.91 /
-        # 23.08 -> 23.03 ms, config 4's shape 19.83 -> 19.68; tools/experiments/ab_chain_q.py)
-        chain_q = self.multi_stream and (v2 if self.chain_q == 'auto' else self.chain_q == 'always')
+        # 2.05 vs 2.03 ms) and for the largest batches (128 graphs + 0.3 % on the side lane), lane 2 in between (64 graphs 9.98 -> 9.94 ms)
+        chain_q = self.multi_stream and (v2 or E >= self.chain_q_from)
         # (round 6, with the queue's tail in half-groups: the best grid moved up by 32 -- 8 graphs 2.01 / 1.90 / 1.92 ms with 160 / 192 / 224
         #  workgroups, 16 graphs 3.31 / 2.99 / 2.81 / 2.93 with 160 / 192 / 224 / 256, 32 graphs 5.33 / 4.88 / 5.10 with 192 / 224 / 256; the defaults
         #  below follow, the calibration in begin_sampling still tries the neighbours)

@@ -30,7 +30,7 @@ DEFAULTS = dict(
                           # whose node chain is the longer one (4 / 8 graphs 2.29 -> 2.22 / 2.38 -> 2.30 ms; 12 graphs equal; 16 / 32 graphs + 1 %)
     geom_split_below=16000,   # ... 'auto': fewer bond edges than this
     tune_grid=True,       # small batches: time the neighbouring triplet grids (multiples of 32 workgroups) during the first forwards, keep the fastest
-    chain_q='auto',       # the Q rows of the triplet MLPs behind P on lane 0 ('auto': in the ahead_v2 schedule only) or beside P on lane 2
+    chain_q_from=150000,  # the Q rows of the triplet MLPs behind P on lane 0 from this many bond edges up (below: beside P on lane 2)
     tri_split=True,       # the triplet kernel as two launches when a few ligands need more row tiles than the rest (BatchPlan.tri_split):
                           # True = from `tri_split_from` bond edges up, 'always', False
     tri_split_from=82000,
@@ -61,7 +61,7 @@ _flag = lambda v: v != '0'
 _ENV = {
     'PG_STREAMS': ('streams', _flag), 'PG_TRI_STAGED': ('tri_staged', _flag),
     'PG_NODE_FUSED': ('node_fused', _flag), 'PG_KNN_GROUP': ('knn_group', _flag), 'PG_KNN_MERGE': ('knn_merge', _tri),
-    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_C_PROGRAM': ('c_program', _flag), 'PG_STEP_AHEAD': ('step_ahead', _flag), 'PG_CHAIN_Q': ('chain_q', _tri), 'PG_TRI_SPLIT': ('tri_split', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
+    'PG_LAYER_AHEAD': ('layer_ahead', _flag), 'PG_AHEAD_V2': ('ahead_v2', _tri), 'PG_AHEAD_V2_BELOW': ('ahead_v2_below', int), 'PG_TRI_GRID': ('tri_grid', int), 'PG_POS_TILED': ('pos_tiled', _tri), 'PG_POS_TILED_BELOW': ('pos_tiled_below', int), 'PG_GRAPH': ('graph', _flag), 'PG_ORDER_POINTS': ('order_points', _flag), 'PG_C_PROGRAM': ('c_program', _flag), 'PG_STEP_AHEAD': ('step_ahead', _flag), 'PG_CHAIN_Q_FROM': ('chain_q_from', int), 'PG_TRI_SPLIT': ('tri_split', _flag), 'PG_TUNE_GRID': ('tune_grid', _flag), 'PG_GEOM_SPLIT': ('geom_split', _tri),
     'PG_FUSED_GEOM': ('fused_geom', _tri), 'PG_DGRAD_MM': ('dgrad_mm', _flag),
     'PG_ROWS_SUM': ('rows_sum', _flag), 'PG_TRI_ONEPASS': ('tri_onepass', _flag), 'PG_WIDE_GEMM': ('wide_gemm', _flag), 'PG_BWD_GRID': ('bwd_grid', int), 'PG_BWD_SPLIT': ('bwd_split', lambda v: {'0': 'none', '1': 'knn', '2': 'all'}[v]), 'PG_BWD_ATOM_SORT': ('bwd_atom_sort', _flag),
     'PG_TRI_BWD_FORM': ('tri_bwd_form', int), 'PG_TRI_BWD_GRID': ('tri_bwd_grid', int), 'PG_PH_ONEPASS': ('ph_onepass', _flag),

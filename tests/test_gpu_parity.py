@@ -1119,7 +1119,7 @@ def test_triplet_launch_split_by_row_tiles_is_bit_identical(model):
 @pytest.mark.parametrize('graphs', [5, 16, 56, 72])
 def test_four_lanes_equal_one_stream_in_every_schedule_regime(model, graphs):
     """The engine picks its launch list by batch size (per-chain closing launch below 16 k bond edges, the v2 position phase below 82 k, the Q
-    rows on a side lane above it, two triplet launches side by side from 82 k): in each regime 25 forwards on four lanes equal the one-stream list
+    rows on a side lane up to 150 k, two triplet launches side by side from 82 k): in each regime 25 forwards on four lanes equal the one-stream list
     on the same inputs bit for bit (tools/stress_bits.py runs the same hunt with more sizes and repeats)."""
     from bench import ligphore_workload
     from phoregen_amd import options

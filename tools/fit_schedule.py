@@ -16,7 +16,7 @@ import torch
 
 VARIANTS = {                    # switch -> the forced settings that bracket its threshold
     'ahead_v2': [dict(ahead_v2='never'), dict(ahead_v2='always')],
-    'chain_q': [dict(chain_q='always'), dict(chain_q='never')],
+    'chain_q_from': [dict(chain_q_from=0), dict(chain_q_from=10 ** 9)],
     'tri_split': [dict(tri_split=False), dict(tri_split='always')],
     'tri_overlap': [dict(tri_overlap=0)],
     'pos_tiled': [dict(pos_tiled='never'), dict(pos_tiled='always')],
