@@ -1,3 +1,4 @@
+# One triplet launch with the unrolling picked per group vs two launches: needs tools/experiments/triplet2_per_group_unrolling.patch applied and the library rebuilt.
 import json, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import torch
